@@ -1,0 +1,117 @@
+"""ctypes binding of libqlinear_hip.so (C ABI in include/qlinear_hip.h).
+
+The library is built in-tree (``make -C chatglm_q_amd/csrc`` or ``__graft_entry__.build()``).
+There is no software fallback for device tensors: if the library is missing, every op that
+receives a GPU tensor raises ``QLinearLibraryMissing``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqlinear_hip.so")
+ABI_VERSION = 1
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+OP_W4G32_FWD = 1
+OP_W4G32_FWD_PACKED = 2
+OP_W8_FWD = 3
+OP_W8A8_FWD = 4
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "qlinear_abi_version": (c_int, []),
+    "qlinear_status_string": (c_char_p, [c_int]),
+    "qlinear_launch_count": (c_uint64, []),
+    "qlinear_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "qlinear_w4g32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                  c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                         c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                               c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_qembedding_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                      c_int, c_void_p]),
+    "qlinear_qembedding_w8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                      c_void_p]),
+}
+
+
+class QLinearLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+_load_error: Exception | None = None
+
+
+def _try_load():
+    global _lib, _load_error
+    if _lib is not None or _load_error is not None:
+        return
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        ver = lib.qlinear_abi_version()
+        if ver != ABI_VERSION:
+            raise OSError(f"{LIB_PATH}: ABI version {ver}, expected {ABI_VERSION}")
+        _lib = lib
+    except (OSError, AttributeError) as e:  # missing file, missing dependency or missing symbol
+        _load_error = e
+
+
+def available() -> bool:
+    """True when libqlinear_hip.so is built and loads in this process."""
+    _try_load()
+    return _lib is not None
+
+
+def get_lib():
+    _try_load()
+    if _lib is None:
+        raise QLinearLibraryMissing(
+            f"libqlinear_hip.so is not available ({_load_error}). Build it with "
+            f"`make -C {os.path.join(_HERE, 'csrc')}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no software fallback for GPU tensors.")
+    return _lib
+
+
+def check(status: int, what: str):
+    if status == 0:
+        return
+    msg = get_lib().qlinear_status_string(status).decode()
+    if status < 0:
+        raise ValueError(f"{what}: {msg} (status {status})")
+    raise RuntimeError(f"{what}: HIP error {status}: {msg}")
+
+
+def launch_count() -> int:
+    return int(get_lib().qlinear_launch_count())
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return DTYPE_CODE[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported activation dtype {dtype}; expected float32, float16 or bfloat16") from None
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()

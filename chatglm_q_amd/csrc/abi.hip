@@ -1,0 +1,160 @@
+// extern "C" surface of libqlinear_hip.so: argument validation, kernel selection, status mapping.
+// Contract: include/qlinear_hip.h.  Nothing here allocates, synchronises or touches the default
+// stream; every launch goes to the caller's stream.
+#include <atomic>
+
+#include "launch.h"
+#include "../../include/qlinear_hip.h"
+
+namespace ql {
+
+static std::atomic<uint64_t> g_launches{0};
+
+int finish_launch() {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? QL_OK : (int)e;
+}
+
+static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+static inline bool dtype_ok(int d) { return d == QL_DTYPE_F32 || d == QL_DTYPE_F16 || d == QL_DTYPE_BF16; }
+static inline int64_t esize(int d) { return d == QL_DTYPE_F32 ? 4 : 2; }
+static inline bool fits_i32(int64_t v) { return v > 0 && v < ((int64_t)1 << 31); }
+
+// A rows must be addressable with 16-byte vector loads by the fast kernels
+static inline bool act_vec_ok(const void* A, int64_t lda, int dtype) {
+    return aligned(A, 16) && (lda * esize(dtype)) % 16 == 0;
+}
+
+}  // namespace ql
+
+using namespace ql;
+
+extern "C" {
+
+int qlinear_abi_version(void) { return QLINEAR_ABI_VERSION; }
+
+const char* qlinear_status_string(int status) {
+    switch (status) {
+    case QL_OK: return "ok";
+    case QL_ERR_NULL_POINTER: return "null pointer argument";
+    case QL_ERR_BAD_SHAPE: return "bad shape (M, N, K must be positive, K even and divisible by group, ld* >= row length)";
+    case QL_ERR_BAD_DTYPE: return "unsupported activation dtype (expected f32=0, f16=1, bf16=2)";
+    case QL_ERR_BAD_GROUP: return "unsupported quantisation group size for this entry point";
+    case QL_ERR_MISALIGNED: return "pointer or leading dimension violates the alignment contract";
+    case QL_ERR_WORKSPACE: return "workspace missing or too small (see qlinear_workspace_bytes)";
+    case QL_ERR_UNSUPPORTED: return "shape not supported by this entry point";
+    default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown qlinear status";
+}
+
+uint64_t qlinear_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
+size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t group) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    switch (op) {
+    case QL_OP_W4G32_FWD:
+        if (group == 32 && N % 8 == 0) return w4_canon_workspace_bytes(M, N, K);
+        return 0;
+    default: return 0;
+    }
+}
+
+int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C, int64_t M,
+                      int64_t N, int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!A || !Wq || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (group <= 0 || K % group != 0) return QL_ERR_BAD_GROUP;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast = group == 32 && N % 8 == 0 && act_vec_ok(A, lda, dtype) && aligned(Wq, 8) && aligned(S, 16);
+    if (!fast) return w4_generic(dtype, A, Wq, S, bias, C, M, N, K, group, lda, ldc, st);
+    const size_t need = w4_canon_workspace_bytes(M, N, K);
+    if (need && (!workspace || workspace_bytes < need || !aligned(workspace, 16))) return QL_ERR_WORKSPACE;
+    return w4_canon(dtype, A, Wq, S, bias, C, workspace, M, N, K, lda, ldc, st);
+}
+
+size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
+    if (N <= 0 || K <= 0 || group != 32 || K % 32 != 0 || !dtype_ok(dtype)) return 0;
+    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
+    return (size_t)(Npad * G * 16 + Npad * G * esize(dtype));
+}
+
+int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, int64_t group,
+                         int dtype, void* stream) {
+    if (!Wq || !S || !packed) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || (K & 1)) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(packed, 16)) return QL_ERR_MISALIGNED;
+    return w4_repack(dtype, Wq, S, packed, N, K, (hipStream_t)stream);
+}
+
+int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+                             int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(packed, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
+    return w4_packed(dtype, A, packed, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
+int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                   int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    if (!A || !W || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < N || ldw_k <= 0 || ldw_n <= 0)
+        return QL_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool k_contig = ldw_k == 1 && ldw_n >= K;
+    if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
+        return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, st);
+    return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);
+}
+
+int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
+                                 int dtype, void* stream) {
+    if (!A || !Aq || !a_scale) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(K) || lda < K) return QL_ERR_BAD_SHAPE;
+    return act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (hipStream_t)stream);
+}
+
+int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
+                     void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+    if (!Aq || !a_scale || !W || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (K % 32 != 0) return QL_ERR_UNSUPPORTED;
+    if (!aligned(Aq, 16) || !aligned(W, 16)) return QL_ERR_MISALIGNED;
+    return w8a8_gemm(dtype, Aq, a_scale, W, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
+}
+
+int qlinear_qembedding_w4(const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count, int64_t V,
+                          int64_t D, int64_t group, int dtype, void* stream) {
+    if (!ids || !Wq || !S || !out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(count) || !fits_i32(V) || !fits_i32(D) || (V & 1)) return QL_ERR_BAD_SHAPE;
+    if (group <= 0 || V % group != 0) return QL_ERR_BAD_GROUP;
+    return qembedding_w4(dtype, ids, Wq, S, out, count, V, D, group, (hipStream_t)stream);
+}
+
+int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, void* out, int64_t count, int64_t V,
+                          int64_t D, int dtype, void* stream) {
+    if (!ids || !W || !S || !out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(count) || !fits_i32(V) || !fits_i32(D)) return QL_ERR_BAD_SHAPE;
+    return qembedding_w8(dtype, ids, W, S, out, count, V, D, (hipStream_t)stream);
+}
+
+}  // extern "C"

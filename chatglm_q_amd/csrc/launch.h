@@ -1,0 +1,41 @@
+// Internal launcher interface between abi.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ql {
+
+// Every kernel launch funnels through this: bumps the launch counter and turns the launch status
+// into the ABI's return convention (0 OK, >0 hipError_t).
+int finish_launch();
+
+constexpr int64_t kCanonMChunk = 64;   // rows per pass of the canonical split-K path (bounds the workspace)
+
+// w4_kernels.hip
+int w4_generic(int dtype, const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C, int64_t M,
+               int64_t N, int64_t K, int64_t group, int64_t lda, int64_t ldc, hipStream_t st);
+size_t w4_canon_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int w4_canon(int dtype, const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C, void* ws,
+             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
+int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st);
+int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+              int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
+
+// w8_kernels.hip
+int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
+               int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
+int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
+            int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
+int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
+                      hipStream_t st);
+int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
+              void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st);
+
+// embed_kernels.hip
+int qembedding_w4(int dtype, const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count,
+                  int64_t V, int64_t D, int64_t group, hipStream_t st);
+int qembedding_w8(int dtype, const int64_t* ids, const int8_t* W, const void* S, void* out, int64_t count,
+                  int64_t V, int64_t D, hipStream_t st);
+
+}  // namespace ql

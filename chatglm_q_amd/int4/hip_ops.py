@@ -1,0 +1,138 @@
+"""Host wrappers for the int4 group-quantised HIP kernels.
+
+Mirrors the wrapper layer of the reference (chatglm_q/int4/triton_ops.py:10-11,90-139): same
+function names, argument meaning and pre-launch checks, with the Triton launch replaced by a call
+into libqlinear_hip.so.  The reference's ``assert``s are kept as real exceptions (asserts vanish
+under ``python -O``).
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+
+
+def check_input(a: Tensor) -> bool:
+    """True when ``a`` lives on a GPU, i.e. the HIP kernels handle it
+    (chatglm_q/int4/triton_ops.py:10-11)."""
+    return a.get_device() >= 0
+
+
+def _check_w4_args(a: Tensor, b: Tensor, b_scale: Tensor):
+    # chatglm_q/int4/triton_ops.py:102-111
+    if b.dim() != 2:
+        raise AssertionError(f"qweight must be 2-D, got {tuple(b.shape)}")
+    if b_scale.dim() != 2:
+        raise AssertionError(f"scale must be 2-D, got {tuple(b_scale.shape)}")
+    if a.shape[-1] != b.shape[0] * 2:
+        raise AssertionError(f"K mismatch: a has {a.shape[-1]}, packed weight implies {b.shape[0] * 2}")
+    if b.shape[1] != b_scale.shape[1]:
+        raise AssertionError(f"N mismatch: weight {b.shape[1]} vs scale {b_scale.shape[1]}")
+    if b.dtype != torch.uint8:
+        raise AssertionError(f"qweight must be uint8, got {b.dtype}")
+    if a.dtype != b_scale.dtype:
+        raise AssertionError(f"activation dtype {a.dtype} != scale dtype {b_scale.dtype}")
+    if b.shape[0] % b_scale.shape[0] != 0:
+        raise AssertionError(f"packed rows {b.shape[0]} not divisible by groups {b_scale.shape[0]}")
+    if a.get_device() < 0:
+        raise AssertionError("activations must be on a GPU")
+    if b.device != a.device:
+        raise AssertionError(f"b.device={b.device}, a.device={a.device}")
+    if b_scale.device != a.device:
+        raise AssertionError(f"b_scale.device={b_scale.device}, a.device={a.device}")
+
+
+def _rows(a: Tensor) -> Tensor:
+    """Flatten leading dims to (M, K) with unit inner stride (the C ABI takes lda explicitly)."""
+    a2 = a.reshape(-1, a.shape[-1])
+    if a2.stride(1) != 1 or (a2.shape[0] > 1 and a2.stride(0) < a2.shape[1]):
+        a2 = a2.contiguous()
+    # the vector kernels read rows with 16-byte loads
+    if a2.data_ptr() % 16 or (a2.shape[0] > 1 and (a2.stride(0) * a2.element_size()) % 16):
+        a2 = a2.clone(memory_format=torch.contiguous_format)
+    return a2
+
+
+def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
+    return int(_lib.get_lib().qlinear_w4g32_packed_bytes(N, K, group, _lib.dtype_code(dtype)))
+
+
+def repack_w4g32(b: Tensor, b_scale: Tensor) -> Tensor:
+    """Build the derived streaming layout (include/qlinear_hip.h) from canonical buffers.
+    Returns a uint8 tensor; it is a cache, never part of a state_dict."""
+    lib = _lib.get_lib()
+    K, N = b.shape[0] * 2, b.shape[1]
+    group = K // b_scale.shape[0]
+    b = b.contiguous()
+    b_scale = b_scale.contiguous()
+    nbytes = packed_nbytes(N, K, b_scale.dtype, group)
+    if nbytes == 0:
+        raise ValueError(f"no packed layout for N={N}, K={K}, group={group}")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    with torch.cuda.device(b.device):
+        st = lib.qlinear_w4g32_repack(b.data_ptr(), b_scale.data_ptr(), packed.data_ptr(), N, K, group,
+                                      _lib.dtype_code(b_scale.dtype), _lib.stream_ptr(b.device))
+    _lib.check(st, "qlinear_w4g32_repack")
+    return packed
+
+
+def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
+               packed: Tensor | None = None) -> Tensor:
+    """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernel."""
+    _check_w4_args(a, b, b_scale)
+    lib = _lib.get_lib()
+    out_shape = (*a.shape[:-1], b.shape[1])
+    a2 = _rows(a)
+    M, K = a2.shape
+    G, N = b_scale.shape
+    group = K // G
+    c = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    if M == 0:
+        return c.reshape(out_shape)
+    code = _lib.dtype_code(a.dtype)
+    if bias is not None:
+        bias = bias.contiguous()
+    with torch.cuda.device(a.device):
+        stream = _lib.stream_ptr(a.device)
+        if packed is not None:
+            st = lib.qlinear_w4g32_fwd_packed(a2.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
+                                              group, a2.stride(0) if M > 1 else K, N, code, None, 0, stream)
+            _lib.check(st, "qlinear_w4g32_fwd_packed")
+        else:
+            if not b.is_contiguous():
+                b = b.contiguous()
+            if not b_scale.is_contiguous():
+                b_scale = b_scale.contiguous()
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD, M, N, K, group))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
+            st = lib.qlinear_w4g32_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                       M, N, K, group, a2.stride(0) if M > 1 else K, N, code, _lib.ptr(ws), ws_bytes,
+                                       stream)
+            _lib.check(st, "qlinear_w4g32_fwd")
+    return c.reshape(out_shape)
+
+
+def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
+    """Same contract as the reference wrapper (chatglm_q/int4/triton_ops.py:90-139).
+
+    A: (..., K) float; B: (K//2, N) uint8; B_scale: (G, N) float; returns (..., N).
+    ``allow_tf32`` is accepted and ignored: CDNA4 has no TF32, fp32 inputs use IEEE fp32 FMA, which
+    is what the reference's own tests request (``allow_tf32=False``, tests/test_triton_ops_int4.py:20).
+    """
+    del allow_tf32
+    return w4_forward(a, b, b_scale)
+
+
+def qembedding_w4(ids: Tensor, weight: Tensor, scale: Tensor, group_size: int) -> Tensor:
+    lib = _lib.get_lib()
+    V, D = weight.shape[0] * 2, weight.shape[1]
+    idx = ids.reshape(-1).to(torch.int64).contiguous()
+    out = torch.empty((idx.numel(), D), device=weight.device, dtype=scale.dtype)
+    if idx.numel():
+        with torch.cuda.device(weight.device):
+            st = lib.qlinear_qembedding_w4(idx.data_ptr(), weight.data_ptr(), scale.data_ptr(), out.data_ptr(),
+                                           idx.numel(), V, D, group_size, _lib.dtype_code(scale.dtype),
+                                           _lib.stream_ptr(weight.device))
+        _lib.check(st, "qlinear_qembedding_w4")
+    return out.reshape(*ids.shape, D)

@@ -1,0 +1,197 @@
+"""int4 group-quantised linear / embedding modules (drop-in for chatglm_q/int4/qlinear.py).
+
+Public surface kept from the reference: ``DEFAULT_GROUP_SIZE``, ``KERNEL_IMPL``, ``check_input``,
+``unpack_int4``, ``DynamicQuantizeMatMul``, ``dynamic_quant_matmul``, ``DynamicQuantizeLinear``,
+``QEmbedding`` with the same constructor signatures and the same registered buffers
+(``weight`` (in/2, out) uint8, ``weight_scale`` (in/group, out), ``bias``), so a checkpoint loader that
+``copy_``s into ``state_dict()`` (chatglm_q/loader.py:90-104) works unchanged.
+
+Dispatch rule (same predicate as the reference, chatglm_q/int4/qlinear.py:47-50): GPU activations go
+to the HIP kernels - and raise if libqlinear_hip.so is missing, there is no silent fallback on a
+GPU - while CPU activations take the dense formula ``A @ unpack_int4(B, scale)``, which is the
+reference's own CPU branch and BASELINE config 1's plumbing path.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import Tensor, nn
+from torch.autograd.function import FunctionCtx
+
+from .. import _lib
+from . import hip_ops
+from .hip_ops import check_input
+
+DEFAULT_GROUP_SIZE = 32  # chatglm_q/int4/qlinear.py:5
+
+# "hip" when the C-ABI library is loadable, "none" otherwise (the reference's values are
+# "triton" / "none", chatglm_q/int4/qlinear.py:13,17).
+KERNEL_IMPL = "hip" if _lib.available() else "none"
+if KERNEL_IMPL == "none":
+    print("libqlinear_hip.so not found: GPU tensors will raise; CPU tensors use the dense torch formula.")
+
+# Largest row count served by the derived-layout GEMV kernel; above it the canonical kernel runs.
+PACKED_MAX_ROWS = int(os.environ.get("QLINEAR_PACKED_MAX_ROWS", "4"))
+# "auto" (packed for decode shapes), "canonical" (never repack) - for A/B measurements.
+W4_LAYOUT = os.environ.get("QLINEAR_W4_LAYOUT", "auto")
+
+
+@torch.no_grad()
+def unpack_int4(x: Tensor, x_scale: Tensor) -> Tensor:
+    """Dense (K, N) dequantised weight in the scale's dtype (chatglm_q/int4/qlinear.py:20-33).
+
+    Byte [k//2, n]: low nibble = row 2*(k//2), high nibble = the next row; value = (nibble - 8) * scale
+    of the row's group.
+    """
+    K = x.shape[0] * 2
+    G, N = x_scale.shape
+    if x.shape[1] != N:
+        raise AssertionError(f"N mismatch: {x.shape[1]} vs {N}")
+    if K % G != 0:
+        raise AssertionError(f"K={K}, G={G}")
+    codes = torch.stack(((x & 0xF), (x >> 4)), dim=1).reshape(K, N).to(torch.int8) - 8
+    return (codes.reshape(G, K // G, N) * x_scale[:, None, :]).reshape(K, N)
+
+
+class DynamicQuantizeMatMul(torch.autograd.Function):
+    """A: (m, k) float; B: (k//2, n) uint8; b_scale: (g, n) float (chatglm_q/int4/qlinear.py:36-68).
+
+    Forward runs the HIP kernel for GPU tensors.  Backward (the reference's transposed Triton kernels,
+    out of this build's scope - SURVEY.md 8f N4) is the dense formula on whatever device A lives on.
+    """
+
+    @staticmethod
+    def forward(ctx: FunctionCtx, A: Tensor, B: Tensor, b_scale: Tensor):
+        ctx.save_for_backward(A, B, b_scale)
+        if check_input(A):
+            return hip_ops.dynamic_quant_matmul_s4(A, B, b_scale)
+        return A.matmul(unpack_int4(B, b_scale))
+
+    @staticmethod
+    def backward(ctx: FunctionCtx, grad_out: Tensor):
+        A, B, b_scale = ctx.saved_tensors
+        grad_A = None
+        if ctx.needs_input_grad[0]:
+            grad_A = grad_out.matmul(unpack_int4(B, b_scale).t())
+        return grad_A, None, None
+
+    @staticmethod
+    def symbolic(g, A, B, b_scale):
+        raise NotImplementedError()
+
+
+def dynamic_quant_matmul(A: Tensor, B: Tensor, b_scale: Tensor) -> Tensor:
+    return DynamicQuantizeMatMul.apply(A, B, b_scale)
+
+
+class DynamicQuantizeLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias=True, group_size=DEFAULT_GROUP_SIZE,
+                 device=None, dtype=None):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        if in_features % group_size != 0:
+            raise AssertionError(f"in_features={in_features}, group_size={group_size}")
+        self.group_size = group_size
+        self.groups = in_features // group_size
+        self.register_buffer("weight", torch.empty((in_features // 2, out_features), device=device, dtype=torch.uint8))
+        self.register_buffer("weight_scale", torch.empty((self.groups, out_features), device=device, dtype=dtype))
+        if bias:
+            self.register_buffer("bias", torch.empty(out_features, device=device, dtype=dtype))
+        else:
+            self.register_buffer("bias", None)
+        # derived streaming layout: a cache keyed on the canonical buffers' identity + version,
+        # never registered, never saved (SURVEY.md 8b "Buffer ownership")
+        self._packed: Tensor | None = None
+        self._packed_key = None
+
+    # -- derived layout -----------------------------------------------------------------------
+    def _canonical_key(self):
+        w, s = self.weight, self.weight_scale
+        return (w.data_ptr(), w._version, s.data_ptr(), s._version, s.dtype, w.device)
+
+    def _packed_supported(self) -> bool:
+        return (W4_LAYOUT != "canonical" and self.group_size == 32 and self.weight.is_cuda
+                and self.weight.is_contiguous() and self.weight_scale.is_contiguous())
+
+    @torch.no_grad()
+    def prepare(self):
+        """Build (or refresh) the derived layout now, e.g. before capturing a HIP graph."""
+        if not self._packed_supported():
+            self._packed, self._packed_key = None, None
+            return self
+        key = self._canonical_key()
+        if self._packed is None or self._packed_key != key:
+            self._packed = hip_ops.repack_w4g32(self.weight, self.weight_scale)
+            self._packed_key = key
+        return self
+
+    def forward(self, input: Tensor):
+        if check_input(input):
+            if input.requires_grad and torch.is_grad_enabled():
+                out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
+                if self.bias is not None:
+                    out += self.bias
+                return out
+            rows = input.numel() // max(input.shape[-1], 1)
+            packed = None
+            if rows <= PACKED_MAX_ROWS and self._packed_supported():
+                self.prepare()
+                packed = self._packed
+            # bias is added inside the kernel epilogue AFTER the rounding to the output dtype,
+            # i.e. the same two roundings as "out = matmul(); out += bias" (qlinear.py:90-94)
+            return hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed)
+        out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
+        if self.bias is not None:
+            out += self.bias
+        return out
+
+    @torch.no_grad()
+    def apply_weights_(self, q_weight: Tensor, scale: Tensor, bias: Tensor = None):
+        self.weight.copy_(q_weight)
+        self.weight_scale.copy_(scale)
+        if bias is not None:
+            self.bias.copy_(bias)
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, group_size={}, bias={}".format(
+            self.in_features, self.out_features, self.group_size, self.bias is not None)
+
+    def reset_parameters(self):
+        pass
+
+
+class QEmbedding(nn.Module):
+    """int4 embedding; packing runs along the vocabulary axis (chatglm_q/int4/qlinear.py:111-142)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, group_size=DEFAULT_GROUP_SIZE, device=None, dtype=None):
+        super().__init__()
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        if num_embeddings % group_size != 0:
+            raise AssertionError(f"num_embeddings={num_embeddings}, group_size={group_size}")
+        self.group_size = group_size
+        self.groups = num_embeddings // group_size
+        self.register_buffer("weight", torch.empty((num_embeddings // 2, embedding_dim), device=device, dtype=torch.uint8))
+        self.register_buffer("weight_scale", torch.empty((self.groups, embedding_dim), device=device, dtype=dtype))
+
+    def forward(self, input: Tensor):
+        if check_input(input) and self.weight.is_contiguous() and self.weight_scale.is_contiguous():
+            return hip_ops.qembedding_w4(input, self.weight, self.weight_scale, self.group_size)
+        rows = self.weight[input // 2]
+        shifts = ((input % 2) * 4)[..., None].to(rows.dtype)
+        codes = ((rows >> shifts) & 0xF).to(torch.int8) - 8
+        return codes * self.weight_scale[input // self.group_size]
+
+    @torch.no_grad()
+    def apply_weights_(self, q_weight: Tensor, scale: Tensor):
+        self.weight.copy_(q_weight)
+        self.weight_scale.copy_(scale)
+
+    def extra_repr(self) -> str:
+        return "num_embeddings={}, embedding_dim={}, group_size={}".format(
+            self.num_embeddings, self.embedding_dim, self.group_size)
+
+    def reset_parameters(self):
+        pass

@@ -1,0 +1,132 @@
+"""Host wrappers for the int8 per-channel HIP kernels.
+
+Mirrors chatglm_q/int8/triton_ops.py:9-10,87-127 (``check_input``, ``dynamic_quant_matmul``) and adds
+the int8-activation path (``dynamic_quant_matmul_a8``) whose semantic the reference states in
+chatglm_q/int8/qlinear.py:56-70 and chatglm_q/int8/quantizer.py:11-19.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+from ..int4.hip_ops import _rows
+
+
+def check_input(a: Tensor) -> bool:
+    return a.get_device() >= 0
+
+
+def _check_w8_args(a: Tensor, b: Tensor, b_scale: Tensor):
+    # chatglm_q/int8/triton_ops.py:97-105
+    if b.dim() != 2:
+        raise AssertionError(f"weight must be 2-D, got {tuple(b.shape)}")
+    if b_scale.dim() != 1:
+        raise AssertionError(f"scale must be 1-D, got {tuple(b_scale.shape)}")
+    if a.shape[-1] != b.shape[0]:
+        raise AssertionError(f"K mismatch: {a.shape[-1]} vs {b.shape[0]}")
+    if b.shape[1] != b_scale.shape[0]:
+        raise AssertionError(f"N mismatch: {b.shape[1]} vs {b_scale.shape[0]}")
+    if b.dtype != torch.int8:
+        raise AssertionError(f"weight must be int8, got {b.dtype}")
+    if a.dtype != b_scale.dtype:
+        raise AssertionError(f"activation dtype {a.dtype} != scale dtype {b_scale.dtype}")
+    if a.get_device() < 0:
+        raise AssertionError("activations must be on a GPU")
+    if b.device != a.device:
+        raise AssertionError(f"b.device={b.device}, a.device={a.device}")
+    if b_scale.device != a.device:
+        raise AssertionError(f"b_scale.device={b_scale.device}, a.device={a.device}")
+
+
+def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """``a @ (b * b_scale) (+ bias)``; ``b`` is the logical (K, N) int8 matrix with ANY strides - the
+    module passes ``weight.t()`` (strides (1, K)), the reference test a contiguous (K, N)."""
+    _check_w8_args(a, b, b_scale)
+    lib = _lib.get_lib()
+    out_shape = (*a.shape[:-1], b.shape[1])
+    a2 = _rows(a)
+    M, K = a2.shape
+    N = b.shape[1]
+    # same rule as the reference wrapper: copy only when both strides exceed 1 (triton_ops.py:109-110)
+    if b.stride(0) > 1 and b.stride(1) > 1:
+        b = b.contiguous()
+    c = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    if M == 0:
+        return c.reshape(out_shape)
+    b_scale = b_scale.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    ldw_k = b.stride(0) if K > 1 else 1
+    ldw_n = b.stride(1) if N > 1 else max(K, 1)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
+                                ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, _lib.dtype_code(a.dtype), None, 0,
+                                _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w8_fwd")
+    return c.reshape(out_shape)
+
+
+def dynamic_quant_matmul(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
+    """Same contract as the reference wrapper (chatglm_q/int8/triton_ops.py:87-127); ``allow_tf32`` is
+    accepted and ignored (no TF32 on CDNA4; IEEE fp32 FMA)."""
+    del allow_tf32
+    return w8_forward(a, b, b_scale)
+
+
+def act_quant_rowwise(a: Tensor):
+    """Row-wise symmetric int8 quantisation of activations in fp32 arithmetic.
+    Returns (a_q (M, K) int8, a_scale (M,) float32)."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    a_q = torch.empty((M, K), device=a.device, dtype=torch.int8)
+    a_s = torch.empty((M,), device=a.device, dtype=torch.float32)
+    if M:
+        with torch.cuda.device(a.device):
+            st = lib.qlinear_act_quant_i8_rowwise(a2.data_ptr(), a_q.data_ptr(), a_s.data_ptr(), M, K,
+                                                  a2.stride(0) if M > 1 else K, _lib.dtype_code(a.dtype),
+                                                  _lib.stream_ptr(a.device))
+        _lib.check(st, "qlinear_act_quant_i8_rowwise")
+    return a_q, a_s
+
+
+def w8a8_forward(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """fp activations -> int8 rows -> i8 x i8 -> i32 MFMA -> ``acc * a_scale[m] * w_scale[n]`` (+ bias).
+    ``weight_nk`` is the module's (N, K) row-major int8 buffer."""
+    lib = _lib.get_lib()
+    if weight_nk.dtype != torch.int8 or weight_nk.dim() != 2:
+        raise AssertionError("weight must be a 2-D int8 (N, K) tensor")
+    if a.shape[-1] != weight_nk.shape[1]:
+        raise AssertionError(f"K mismatch: {a.shape[-1]} vs {weight_nk.shape[1]}")
+    if a.dtype != w_scale.dtype:
+        raise AssertionError(f"activation dtype {a.dtype} != scale dtype {w_scale.dtype}")
+    weight_nk = weight_nk.contiguous()
+    N, K = weight_nk.shape
+    out_shape = (*a.shape[:-1], N)
+    a_q, a_s = act_quant_rowwise(a)
+    M = a_q.shape[0]
+    c = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    if M:
+        if bias is not None:
+            bias = bias.contiguous()
+        with torch.cuda.device(a.device):
+            st = lib.qlinear_w8a8_fwd(a_q.data_ptr(), a_s.data_ptr(), weight_nk.data_ptr(), w_scale.contiguous().data_ptr(),
+                                      _lib.ptr(bias), c.data_ptr(), M, N, K, N, _lib.dtype_code(a.dtype),
+                                      _lib.stream_ptr(a.device))
+        _lib.check(st, "qlinear_w8a8_fwd")
+    return c.reshape(out_shape)
+
+
+def qembedding_w8(ids: Tensor, weight: Tensor, scale: Tensor) -> Tensor:
+    lib = _lib.get_lib()
+    V, D = weight.shape
+    idx = ids.reshape(-1).to(torch.int64).contiguous()
+    out = torch.empty((idx.numel(), D), device=weight.device, dtype=scale.dtype)
+    if idx.numel():
+        with torch.cuda.device(weight.device):
+            st = lib.qlinear_qembedding_w8(idx.data_ptr(), weight.data_ptr(), scale.data_ptr(), out.data_ptr(),
+                                           idx.numel(), V, D, _lib.dtype_code(scale.dtype),
+                                           _lib.stream_ptr(weight.device))
+        _lib.check(st, "qlinear_qembedding_w8")
+    return out.reshape(*ids.shape, D)

@@ -1,0 +1,117 @@
+"""int8 per-output-channel linear / embedding modules (drop-in for chatglm_q/int8/qlinear.py).
+
+Same public names, constructor signatures and registered buffers as the reference: ``weight``
+(out, in) int8, ``weight_scale`` (out,), ``bias``.  GPU activations run the HIP kernels (and raise if
+libqlinear_hip.so is missing); CPU activations take the dense formula ``A @ (B * b_scale)``, the
+reference's own CPU branch (chatglm_q/int8/qlinear.py:35-38) and BASELINE config 1.
+
+``DynamicQuantizeLinear.act_quant`` (default False) switches the module to the int8-activation MFMA
+path: row-wise symmetric activation quantisation followed by a true i8 x i8 -> i32 contraction.  The
+reference executes that semantic only in its ONNX export (chatglm_q/int8/qlinear.py:56-70); it is NOT
+bit-compatible with the weight-only path (quantisation error ~1e-2 relative) and is opt-in.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+from torch.autograd.function import FunctionCtx
+
+from .. import _lib
+from . import hip_ops
+from .hip_ops import check_input
+
+KERNEL_IMPL = "hip" if _lib.available() else "none"
+
+
+class DynamicQuantizeMatMul(torch.autograd.Function):
+    """A: (m, k) float; B: (k, n) int8; b_scale: (n,) float (chatglm_q/int8/qlinear.py:19-52)."""
+
+    @staticmethod
+    def forward(ctx: FunctionCtx, A: Tensor, B: Tensor, b_scale: Tensor):
+        ctx.save_for_backward(A, B, b_scale)
+        if check_input(A):
+            return hip_ops.dynamic_quant_matmul(A, B, b_scale)
+        return A.matmul(B * b_scale)
+
+    @staticmethod
+    def backward(ctx: FunctionCtx, grad_out: Tensor):
+        A, B, b_scale = ctx.saved_tensors
+        grad_A = None
+        if ctx.needs_input_grad[0]:
+            grad_A = grad_out.matmul(B.t() * b_scale[:, None])
+        return grad_A, None, None
+
+
+def dynamic_quant_matmul(A: Tensor, B: Tensor, b_scale: Tensor) -> Tensor:
+    return DynamicQuantizeMatMul.apply(A, B, b_scale)
+
+
+def dynamic_quant_matmul_a8(A: Tensor, weight_nk: Tensor, b_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """int8-activation variant: ``weight_nk`` is the (N, K) buffer (NOT transposed)."""
+    if not check_input(A):
+        raise RuntimeError("the int8-activation path exists only on the GPU (v_mfma_i32_32x32x32_i8)")
+    return hip_ops.w8a8_forward(A, weight_nk, b_scale, bias)
+
+
+class DynamicQuantizeLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("weight", torch.empty((out_features, in_features), device=device, dtype=torch.int8))
+        self.register_buffer("weight_scale", torch.empty(out_features, device=device, dtype=dtype))
+        if bias:
+            self.register_buffer("bias", torch.empty(out_features, device=device, dtype=dtype))
+        else:
+            self.register_buffer("bias", None)
+        self.act_quant = False
+
+    def forward(self, input: Tensor):
+        if check_input(input) and not (input.requires_grad and torch.is_grad_enabled()):
+            if self.act_quant:
+                return hip_ops.w8a8_forward(input, self.weight, self.weight_scale, self.bias)
+            # bias fused after the output rounding: same two roundings as qlinear.py:90-93
+            return hip_ops.w8_forward(input, self.weight.t(), self.weight_scale, self.bias)
+        out = dynamic_quant_matmul(input, self.weight.t(), self.weight_scale)
+        if self.bias is not None:
+            out += self.bias
+        return out
+
+    @torch.no_grad()
+    def apply_weights_(self, q_weight: Tensor, scale: Tensor, bias: Tensor = None):
+        self.weight.copy_(q_weight)
+        self.weight_scale.copy_(scale)
+        if bias is not None:
+            self.bias.copy_(bias)
+
+    def extra_repr(self) -> str:
+        return "in_features={}, out_features={}, bias={}".format(
+            self.in_features, self.out_features, self.bias is not None)
+
+    def reset_parameters(self):
+        pass
+
+
+class QEmbedding(nn.Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int, device=None, dtype=None):
+        super().__init__()
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        self.register_buffer("weight", torch.empty((num_embeddings, embedding_dim), device=device, dtype=torch.int8))
+        self.register_buffer("weight_scale", torch.empty(embedding_dim, device=device, dtype=dtype))
+
+    def forward(self, input: Tensor):
+        if check_input(input) and self.weight.is_contiguous():
+            return hip_ops.qembedding_w8(input, self.weight, self.weight_scale)
+        return self.weight[input] * self.weight_scale
+
+    @torch.no_grad()
+    def apply_weights_(self, q_weight: Tensor, scale: Tensor):
+        self.weight.copy_(q_weight)
+        self.weight_scale.copy_(scale)
+
+    def extra_repr(self) -> str:
+        return "num_embeddings={}, embedding_dim={}".format(self.num_embeddings, self.embedding_dim)
+
+    def reset_parameters(self):
+        pass

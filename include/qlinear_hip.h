@@ -1,0 +1,135 @@
+/* qlinear_hip.h - C ABI of libqlinear_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the quantized-linear forward path of K024/chatglm-q.  Each entry point
+ * replaces one host->device launch site of the reference (paths relative to the reference
+ * checkout):
+ *
+ *   qlinear_w4g32_fwd / _fwd_packed  <- dynamic_quant_matmul_s4      chatglm_q/int4/triton_ops.py:90-139
+ *                                       (kernel _dynamic_quant_matmul_s4_kernel, :18-87)
+ *   qlinear_w8_fwd                   <- dynamic_quant_matmul         chatglm_q/int8/triton_ops.py:87-127
+ *                                       (kernel _dynamic_quant_matmul_kernel, :13-84)
+ *   qlinear_act_quant_i8_rowwise,
+ *   qlinear_w8a8_fwd                 <- the int8-activation semantic that exists only in
+ *                                       DynamicQuantizeMatMul.symbolic chatglm_q/int8/qlinear.py:56-70
+ *                                       and quantize_int8           chatglm_q/int8/quantizer.py:11-19
+ *   qlinear_qembedding_*             <- QEmbedding.forward           chatglm_q/int4/qlinear.py:122-131,
+ *                                                                    chatglm_q/int8/qlinear.py:118-120
+ *
+ * Conventions
+ *   - plain C types only; all pointers are DEVICE pointers unless stated; the library never
+ *     allocates, frees or retains them; the caller owns outputs and workspaces.
+ *   - every launch goes to the hipStream_t passed in (as void*); no hidden synchronisation,
+ *     no use of the default stream, no mutable global state apart from an idempotent
+ *     per-process device-property cache.  Thread-safe.
+ *   - return value: 0 = OK; < 0 = argument error (QL_ERR_*); > 0 = hipError_t of the launch.
+ *     Nothing is thrown across the ABI, nothing aborts.
+ *   - dtype: activation / scale / bias / output element type (QL_DTYPE_*); scales, bias and the
+ *     output always have the activation dtype, as the reference asserts
+ *     (chatglm_q/int4/triton_ops.py:108).
+ *   - rounding: every dequantised weight is rounded to the activation dtype before it is
+ *     multiplied, products accumulate in fp32, the sum is rounded once to the activation dtype,
+ *     and the optional bias is added after that rounding (a second rounding) - the reference's
+ *     exact sequence (chatglm_q/int4/triton_ops.py:72-80, chatglm_q/int4/qlinear.py:92-93).
+ */
+#ifndef QLINEAR_HIP_H
+#define QLINEAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLINEAR_ABI_VERSION 1
+
+/* activation dtypes */
+#define QL_DTYPE_F32 0
+#define QL_DTYPE_F16 1
+#define QL_DTYPE_BF16 2
+
+/* status codes */
+#define QL_OK 0
+#define QL_ERR_NULL_POINTER (-1)
+#define QL_ERR_BAD_SHAPE (-2)      /* M/N/K <= 0, K odd, K % group != 0, ld* too small */
+#define QL_ERR_BAD_DTYPE (-3)
+#define QL_ERR_BAD_GROUP (-4)      /* group size unsupported by this entry point */
+#define QL_ERR_MISALIGNED (-5)     /* pointer / leading dimension breaks the alignment contract */
+#define QL_ERR_WORKSPACE (-6)      /* workspace missing or too small (see qlinear_workspace_bytes) */
+#define QL_ERR_UNSUPPORTED (-7)
+
+/* operations, for qlinear_workspace_bytes */
+#define QL_OP_W4G32_FWD 1
+#define QL_OP_W4G32_FWD_PACKED 2
+#define QL_OP_W8_FWD 3
+#define QL_OP_W8A8_FWD 4
+
+int qlinear_abi_version(void);
+const char* qlinear_status_string(int status);
+
+/* Number of kernel launches this process has issued through the library (monotonic, relaxed).
+ * Lets a caller prove that a result came from the HIP path and not from any fallback. */
+uint64_t qlinear_launch_count(void);
+
+/* Bytes of scratch the op needs for this shape (0 = none).  The caller allocates it (e.g. from
+ * torch's caching allocator so stream semantics hold) and passes it to the op. */
+size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t group);
+
+/* ---- int4 group-quantised weights, canonical (reference) layout ---------------------------
+ * A   (M, K) activations, row stride lda elements, unit inner stride
+ * Wq  (K/2, N) uint8, contiguous; byte [k/2, n] = row 2*(k/2) low nibble, row 2*(k/2)+1 high
+ *     nibble; stored nibble = q + 8 (chatglm_q/int4/quantizer.py:24-28)
+ * S   (K/group, N) scales, contiguous, activation dtype
+ * bias (N) or NULL;  C (M, N) row stride ldc
+ * Any group size dividing K is accepted; group == 32 with N % 8 == 0 takes the fast kernels. */
+int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C,
+                      int64_t M, int64_t N, int64_t K, int64_t group, int64_t lda, int64_t ldc,
+                      int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- int4 g32, derived streaming layout ----------------------------------------------------
+ * A lazily built, non-persistent re-arrangement of the SAME bytes (weights transposed to
+ * column-major with the 32 nibbles of one (column, group) in one 16-byte unit, scales regrouped
+ * per 4 columns) so that one wave owns whole output columns and no cross-workgroup reduction is
+ * needed.  Built once per weight by qlinear_w4g32_repack from the canonical buffers; canonical
+ * buffers remain the source of truth (state_dict).  group must be 32. */
+size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype);
+int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K,
+                         int64_t group, int dtype, void* stream);
+int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C,
+                             int64_t M, int64_t N, int64_t K, int64_t group, int64_t lda,
+                             int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* ---- int8 per-output-channel weights -------------------------------------------------------
+ * W  int8, logical (K, N) with element strides (ldw_k, ldw_n) - exactly what the reference
+ *    wrapper receives: the module passes weight.t() of its (N, K) row-major buffer, i.e.
+ *    (ldw_k, ldw_n) = (1, K) (chatglm_q/int8/qlinear.py:90); the reference test passes a
+ *    contiguous (K, N), i.e. (N, 1) (tests/test_triton_ops.py:11).
+ * S  (N) scales, activation dtype. */
+int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C,
+                   int64_t M, int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda,
+                   int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- int8 activations x int8 weights (true i8 x i8 -> i32 MFMA contraction) ---------------
+ * Row-wise symmetric activation quantisation in fp32 arithmetic:
+ *   a_scale[m] = max(max_k |A[m,k]| / 127, 1e-10);  Aq = clamp(rint(A / a_scale), -127, 127)
+ * (quantize_int8, chatglm_q/int8/quantizer.py:11-19).  Aq is (M, K) contiguous. */
+int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K,
+                                 int64_t lda, int dtype, void* stream);
+/* C[m,n] = round(acc_i32[m,n] * (a_scale[m] * w_scale[n])) (+ bias); W is (N, K) row-major. */
+int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S,
+                     const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc,
+                     int dtype, void* stream);
+
+/* ---- quantised embedding gathers ("next" row N3) -------------------------------------------
+ * ids: (count) int64 token ids.  int4: Wq (V/2, D) packs along the vocabulary axis, S (V/group, D).
+ * int8: W (V, D), S (D).  out: (count, D) activation dtype. */
+int qlinear_qembedding_w4(const int64_t* ids, const uint8_t* Wq, const void* S, void* out,
+                          int64_t count, int64_t V, int64_t D, int64_t group, int dtype, void* stream);
+int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, void* out,
+                          int64_t count, int64_t V, int64_t D, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLINEAR_HIP_H */

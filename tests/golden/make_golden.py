@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container, where the reference checkout is mounted at
+/root/reference (read-only).  Nothing from the reference is copied: this script
+imports it, feeds it seeded inputs and stores inputs + outputs as .npz data.
+
+Two independent reference routes are recorded for every matmul case:
+  * ``out_fallback``  - the reference's torch path on CPU tensors
+                        (chatglm_q/int4/qlinear.py:50, chatglm_q/int8/qlinear.py:38),
+                        reached through DynamicQuantizeLinear.forward / the functional form.
+  * ``out_triton``    - the reference's actual @triton.jit kernels executed by the
+                        Triton interpreter (TRITON_INTERPRET=1) on CPU tensors
+                        (chatglm_q/int4/triton_ops.py:18-87, chatglm_q/int8/triton_ops.py:13-84).
+
+bf16 arrays are stored as uint16 bit patterns (numpy has no bf16); key suffix ``_bf16bits``.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+os.environ["TRITON_INTERPRET"] = "1"
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import math  # noqa: E402
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from chatglm_q.int4 import qlinear as ref4  # noqa: E402
+from chatglm_q.int4 import quantizer as refq4  # noqa: E402
+from chatglm_q.int4 import triton_ops as reft4  # noqa: E402
+from chatglm_q.int8 import qlinear as ref8  # noqa: E402
+from chatglm_q.int8 import quantizer as refq8  # noqa: E402
+from chatglm_q.int8 import triton_ops as reft8  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def to_np(t: torch.Tensor):
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+    return t.contiguous().numpy()
+
+
+def put(d: dict, name: str, t: torch.Tensor):
+    if t.dtype == torch.bfloat16:
+        d[name + "_bf16bits"] = to_np(t)
+    else:
+        d[name] = to_np(t)
+
+
+def triton_int4(a, bq, bs):
+    """Reference int4 Triton kernel under the interpreter (wrapper bypassed: it asserts CUDA).
+
+    Returns None for bf16: with triton 3.6 the kernel's ``int8 * bf16`` promotes to fp32 and
+    ``tl.dot`` rejects the mixed operands, so the reference Triton route does not exist for bf16
+    in this environment; bf16 cases are pinned by the fallback route only."""
+    if a.dtype == torch.bfloat16:
+        return None
+    out_shape = (*a.shape[:-1], bq.shape[1])
+    a2 = a.flatten(0, -2).contiguous()
+    M, K = a2.shape
+    G, N = bs.shape
+    group_k = K // G
+    block_k = min(64, group_k)
+    c = torch.empty((M, N), dtype=a.dtype)
+    grid = (math.ceil(M / 16) * math.ceil(N / 128),)
+    kern = reft4._dynamic_quant_matmul_s4_kernel
+    kern[grid](a2, bq, bs, c, M, N, K,
+               a2.stride(0), a2.stride(1), bq.stride(0), bq.stride(1),
+               bs.stride(0), bs.stride(1), c.stride(0), c.stride(1),
+               BLOCK_K=block_k, GROUP_K=group_k, allow_tf32=False)
+    return c.reshape(out_shape)
+
+
+def triton_int8(a, b_kn, bs):
+    if a.dtype == torch.bfloat16:
+        return None     # same triton-3.6 bf16 promotion limitation as triton_int4
+    out_shape = (*a.shape[:-1], b_kn.shape[1])
+    a2 = a.flatten(0, -2).contiguous()
+    M, K = a2.shape
+    N = b_kn.shape[1]
+    c = torch.empty((M, N), dtype=a.dtype)
+    grid = (math.ceil(M / 16) * math.ceil(N / 128), 1)
+    kern = reft8._dynamic_quant_matmul_kernel
+    kern[grid](a2, b_kn, bs, c, M, N, K,
+               a2.stride(0), a2.stride(1), b_kn.stride(0), b_kn.stride(1), bs.stride(0),
+               c.stride(0), c.stride(1), allow_tf32=False)
+    return c.reshape(out_shape)
+
+
+def gen_int4():
+    cases = [
+        # name, a-shape, K, N, dtype, bias
+        ("ref_test_shape", (32, 512), 512, 256, "f32", False),   # tests/test_triton_ops_int4.py:12-13
+        ("decode_k4096", (1, 4096), 4096, 128, "f16", False),
+        ("ragged_k448_n384", (1, 448), 448, 384, "f16", True),   # 14 groups, N % 128 != 0
+        ("bf16_small", (3, 128), 128, 128, "bf16", True),
+        ("m17", (17, 512), 512, 256, "f16", False),
+        ("rank3", (2, 3, 256), 256, 128, "f16", True),
+        ("f32_bias", (5, 256), 256, 160, "f32", True),
+        ("bf16_m9", (9, 512), 512, 64, "bf16", False),
+    ]
+    d = {}
+    names = []
+    for i, (name, ashape, K, N, dt, has_bias) in enumerate(cases):
+        torch.manual_seed(1000 + i)
+        tdt = DT[dt]
+        a = torch.randn(ashape).to(tdt)
+        w = (torch.randn((K, N)) / math.sqrt(K)).to(tdt)
+        bq, bs = refq4.quantize_int4(w)
+        assert bs.dtype == tdt
+        bias = (torch.randn(N) * 0.1).to(tdt) if has_bias else None
+        layer = ref4.DynamicQuantizeLinear(K, N, bias=has_bias, dtype=tdt)
+        layer.apply_weights_(bq, bs, bias)
+        out_fb = layer(a)                                     # route 1 incl. bias add
+        out_tr = triton_int4(a, bq, bs)                       # route 2
+        if has_bias and out_tr is not None:
+            out_tr += bias                                    # same in-place add as qlinear.py:92-93
+        dense = ref4.unpack_int4(bq, bs)
+        p = f"{name}/"
+        put(d, p + "a", a); d[p + "qweight"] = to_np(bq); put(d, p + "scale", bs)
+        if has_bias:
+            put(d, p + "bias", bias)
+        if K * N <= 65536:                                    # keep the fixture file small
+            put(d, p + "dense", dense)
+        put(d, p + "out_fallback", out_fb)
+        names.append(f"{name}:{dt}:{int(has_bias)}")
+        if out_tr is not None:
+            put(d, p + "out_triton", out_tr)
+            print("int4", name, dt, "fallback-vs-triton max abs",
+                  (out_fb.float() - out_tr.float()).abs().max().item())
+
+    # hand-built edge case: nibble 0 (-> -8, never produced by the quantiser but decoded by the
+    # kernel), nibble 15 (+7), an all-zero group (scale clamps to 1e-10 in fp32).
+    torch.manual_seed(77)
+    K, N = 64, 128
+    bq = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8)
+    bq[0, :] = 0x00
+    bq[1, :] = 0xFF
+    bq[2, :] = 0x0F
+    bq[3, :] = 0xF0
+    w0 = torch.randn((K, N)) / 8
+    w0[32:, :16] = 0.0                                        # all-zero group for 16 columns
+    _, bs = refq4.quantize_int4(w0)
+    a = torch.randn((4, K))
+    out_fb = ref4.dynamic_quant_matmul(a, bq, bs)
+    out_tr = triton_int4(a, bq, bs)
+    p = "edge_nibbles/"
+    put(d, p + "a", a); d[p + "qweight"] = to_np(bq); put(d, p + "scale", bs)
+    put(d, p + "dense", ref4.unpack_int4(bq, bs)); put(d, p + "out_fallback", out_fb); put(d, p + "out_triton", out_tr)
+    names.append("edge_nibbles:f32:0")
+    d["__cases__"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "int4_matmul.npz"), **d)
+
+
+def gen_int8():
+    d = {}
+    names = []
+    # reference test shape: tests/test_triton_ops.py:10-12 (B given as contiguous (K, N), negative scales)
+    torch.manual_seed(2000)
+    A = torch.randn((10, 128))
+    B = torch.randint(-127, 127, (128, 256), dtype=torch.int8)
+    S = torch.randn((256,)) / 256
+    p = "ref_test_shape/"
+    put(d, p + "a", A); d[p + "w_kn"] = to_np(B); put(d, p + "scale", S)
+    put(d, p + "out_fallback", ref8.dynamic_quant_matmul(A, B, S)); put(d, p + "out_triton", triton_int8(A, B, S))
+    names.append("ref_test_shape:f32:0:kn")
+
+    cases = [
+        ("decode_k4096", (1, 4096), 4096, 64, "f16", False),
+        ("m128", (128, 512), 512, 384, "f32", True),
+        ("bf16_m3", (3, 256), 256, 128, "bf16", True),
+        ("rank3_f16", (2, 5, 384), 384, 192, "f16", True),
+        ("k_tail_f16", (7, 200), 200, 96, "f16", False),       # K % 64 != 0 -> masked tail (triton_ops.py:66-69)
+    ]
+    for i, (name, ashape, K, N, dt, has_bias) in enumerate(cases):
+        torch.manual_seed(2001 + i)
+        tdt = DT[dt]
+        a = torch.randn(ashape).to(tdt)
+        w = (torch.randn((N, K)) / math.sqrt(K)).to(tdt)
+        wq, ws = refq8.quantize_int8(w)
+        bias = (torch.randn(N) * 0.1).to(tdt) if has_bias else None
+        layer = ref8.DynamicQuantizeLinear(K, N, bias=has_bias, dtype=tdt)
+        layer.apply_weights_(wq, ws, bias)
+        out_fb = layer(a)
+        out_tr = triton_int8(a, wq.t(), ws)                  # (K, N) view with strides (1, K), as qlinear.py:90
+        if has_bias and out_tr is not None:
+            out_tr += bias
+        p = f"{name}/"
+        put(d, p + "a", a); d[p + "weight_nk"] = to_np(wq); put(d, p + "scale", ws)
+        if has_bias:
+            put(d, p + "bias", bias)
+        put(d, p + "out_fallback", out_fb)
+        names.append(f"{name}:{dt}:{int(has_bias)}:nk")
+        if out_tr is not None:
+            put(d, p + "out_triton", out_tr)
+            print("int8", name, dt, "fallback-vs-triton max abs",
+                  (out_fb.float() - out_tr.float()).abs().max().item())
+
+    # edge: weight -128 (never produced by the quantiser, representable in the buffer)
+    torch.manual_seed(88)
+    wq = torch.randint(-128, 128, (64, 96), dtype=torch.int8)
+    wq[:, 0] = -128
+    ws = (torch.rand(64) / 100 + 1e-3)
+    a = torch.randn((3, 96))
+    p = "edge_m128/"
+    put(d, p + "a", a); d[p + "weight_nk"] = to_np(wq); put(d, p + "scale", ws)
+    put(d, p + "out_fallback", ref8.dynamic_quant_matmul(a, wq.t(), ws)); put(d, p + "out_triton", triton_int8(a, wq.t(), ws))
+    names.append("edge_m128:f32:0:nk")
+    d["__cases__"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "int8_matmul.npz"), **d)
+
+
+def gen_quantizers():
+    d = {}
+    for dt in ("f32", "f16"):
+        tdt = DT[dt]
+        torch.manual_seed(3000)
+        w = (torch.randn((128, 96)) / 8).to(tdt)
+        # exact ties: make group 0 of column 0 have max 7.0 so scale == 1 and x.5 values tie
+        w[:32, 0] = torch.tensor([7.0, 0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5] * 4).to(tdt)
+        w[32:64, 1] = 0.0                                     # all-zero group -> scale floor
+        q, s = refq4.quantize_int4(w)
+        put(d, f"int4_{dt}/w", w); d[f"int4_{dt}/q"] = to_np(q); put(d, f"int4_{dt}/scale", s)
+        x = (torch.randn((24, 160))).to(tdt)
+        x[0, :8] = torch.tensor([127.0, 0.5, 1.5, 2.5, -0.5, -1.5, 63.5, -126.5]).to(tdt)
+        x[0, 8:] = x[0, 8:].clamp(-100, 100)
+        x[1, :] = 0.0
+        q8, s8 = refq8.quantize_int8(x)
+        put(d, f"int8_{dt}/x", x); d[f"int8_{dt}/q"] = to_np(q8); put(d, f"int8_{dt}/scale", s8)
+    np.savez_compressed(os.path.join(OUT, "quantizers.npz"), **d)
+
+
+def gen_w8a8():
+    """Exact-integer stage of the W8A8 semantic: quantize_int8 on activations
+    (fp32 arithmetic) composed with an integer matmul; plus the reference's W8A16 output on the
+    same inputs so the quantisation error can be reported."""
+    d = {}
+    torch.manual_seed(4000)
+    M, K, N = 16, 512, 256
+    a = torch.randn((M, K))
+    w = torch.randn((N, K)) / math.sqrt(K)
+    wq, ws = refq8.quantize_int8(w)
+    aq, a_s = refq8.quantize_int8(a)
+    acc = aq.to(torch.int32) @ wq.to(torch.int32).t()
+    out = acc.float() * (a_s[:, None] * ws[None, :])
+    put(d, "a", a); d["weight_nk"] = to_np(wq); put(d, "w_scale", ws)
+    d["a_q"] = to_np(aq); put(d, "a_scale", a_s); d["acc_i32"] = to_np(acc); put(d, "out_w8a8", out)
+    put(d, "out_w8a16", ref8.dynamic_quant_matmul(a, wq.t(), ws))
+    # fp16 activations -> quantised in fp32 arithmetic
+    a16 = a.half()
+    aq16, as16 = refq8.quantize_int8(a16.float())
+    put(d, "a_f16", a16); d["a_q_f16"] = to_np(aq16); put(d, "a_scale_f16", as16)
+    np.savez_compressed(os.path.join(OUT, "w8a8.npz"), **d)
+
+
+def gen_embedding():
+    d = {}
+    torch.manual_seed(5000)
+    V, D = 128, 64
+    emb = torch.randn((V, D)).half()
+    q4, s4 = refq4.quantize_int4(emb)          # packs along the vocabulary axis (quantizer.py:70)
+    e4 = ref4.QEmbedding(V, D, dtype=torch.float16)
+    e4.apply_weights_(q4, s4)
+    ids = torch.tensor([[0, 1, 2, 31, 32, 33, 127], [5, 64, 65, 96, 97, 126, 3]])
+    d["ids"] = ids.numpy()
+    d["int4/qweight"] = to_np(q4); put(d, "int4/scale", s4); put(d, "int4/out", e4(ids))
+    q8, s8 = refq8.quantize_int8(emb.t().float())
+    e8 = ref8.QEmbedding(V, D, dtype=torch.float32)
+    e8.apply_weights_(q8.t(), s8)
+    d["int8/weight"] = to_np(q8.t().contiguous()); put(d, "int8/scale", s8); put(d, "int8/out", e8(ids))
+    np.savez_compressed(os.path.join(OUT, "qembedding.npz"), **d)
+
+
+def gen_model():
+    """Tiny-config int4g32 ChatGLM2 (hidden 128, FFN 224 = 7 groups, 2 layers, vocab 256): every buffer, the ids, prefill
+    logits, one cached decode step, and the sampler's output on fixed logits.  Pins the build's own
+    model graph / decode loop (harness for BASELINE configs 4 and 5)."""
+    from chatglm_q import model as refm
+    from chatglm_q import loader as refl
+    from chatglm_q.decoder import top_p_sampling
+    cfg = refm.ChatGLM2Config(hidden_size=128, inner_hidden_size=224, head_hidden_size=32,
+                              num_multi_query_groups=2, num_attention_heads=4, num_layers=2,
+                              vocab_size=256, max_sequence_length=64)
+    d = {}
+    for dt in ("f32", "f16"):
+        tdt = DT[dt]
+        torch.manual_seed(6000)
+        m = refl.create_quant_int4_model(cfg, dtype=tdt)
+        sd = m.state_dict()
+        gen = torch.Generator().manual_seed(6001)
+        for k, v in sd.items():
+            if v.dtype == torch.uint8:
+                v.copy_(torch.randint(0, 256, v.shape, dtype=torch.uint8, generator=gen))
+            elif k.endswith("weight_scale"):
+                v.copy_((torch.rand(v.shape, generator=gen) * 0.02 + 0.005).to(v.dtype))
+            elif k.endswith("bias"):
+                v.copy_((torch.randn(v.shape, generator=gen) * 0.02).to(v.dtype))
+            elif "ln" in k or "norm" in k:
+                v.copy_((1.0 + 0.1 * torch.randn(v.shape, generator=gen)).to(v.dtype))
+            else:
+                v.copy_((torch.randn(v.shape, generator=gen) * 0.02).to(v.dtype))
+        m.eval()
+        ids = torch.randint(0, 256, (1, 12), generator=gen)
+        with torch.no_grad():
+            _, logits, kv = m(input_ids=ids)
+            nxt = torch.randint(0, 256, (1, 1), generator=gen)
+            _, logits2, kv2 = m(input_ids=nxt, past_key_values=kv)
+            # chunked prefill: 7 + 5 tokens
+            _, la, kva = m(input_ids=ids[:, :7])
+            _, lb, kvb = m(input_ids=ids[:, 7:], past_key_values=kva)
+        p = f"{dt}/"
+        for k, v in sd.items():
+            put(d, p + "sd/" + k, v)
+        d[p + "ids"] = ids.numpy(); d[p + "next_id"] = nxt.numpy()
+        put(d, p + "prefill_logits", logits); put(d, p + "decode_logits", logits2)
+        put(d, p + "chunked_last_logits", lb[:, -1])
+        put(d, p + "kv0_k", kv2[0][0]); put(d, p + "kv0_v", kv2[0][1])
+        print("model", dt, "chunked-vs-full last-logit max abs",
+              (lb[:, -1].float() - logits[:, -1].float()).abs().max().item())
+    d["config"] = np.array([cfg.hidden_size, cfg.inner_hidden_size, cfg.head_hidden_size,
+                            cfg.num_multi_query_groups, cfg.num_attention_heads, cfg.num_layers,
+                            cfg.vocab_size, cfg.max_sequence_length])
+    # sampler (chatglm_q/decoder.py:12-27)
+    torch.manual_seed(6100)
+    lg = torch.randn(512) * 3
+    probs_in = lg.clone()
+    torch.manual_seed(6101)
+    picks = [int(top_p_sampling(probs_in, top_k=100, top_p=0.8, temperature=1.0)) for _ in range(8)]
+    put(d, "sampler/logits", lg); d["sampler/picks_seed6101"] = np.array(picks)
+    # deterministic part of the sampler: the renormalised top-k/top-p distribution
+    pr = torch.softmax(lg.float() / 1.0, dim=-1)
+    pr, idx = torch.sort(pr, dim=-1, descending=True)
+    pr, idx = pr[:100], idx[:100]
+    cum = torch.cumsum(pr, dim=-1)
+    pr[(cum - pr) > 0.8] = 0.0
+    pr = pr / pr.sum()
+    put(d, "sampler/probs", pr); d["sampler/indices"] = idx.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model"]
+    torch.set_num_threads(4)
+    for w in which:
+        {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
+         "embedding": gen_embedding, "model": gen_model}[w]()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,180 @@
+"""CPU tests of the host side: module API mirrors the reference (names, buffers, dtypes, CPU branch),
+quantizer writers are format-exact, the C ABI library loads and exports everything the header declares.
+No compute call goes to the GPU here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from oracle import qlinear_oracle as O
+
+from chatglm_q_amd import _lib
+from chatglm_q_amd.int4 import qlinear as q4, quantizer as z4
+from chatglm_q_amd.int8 import qlinear as q8, quantizer as z8
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INT4 = G.load("int4_matmul.npz")
+INT8 = G.load("int8_matmul.npz")
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+REL = {"f32": 1e-5, "f16": 1e-3, "bf16": 4e-3}
+
+
+def t2n(t):
+    return t.float().numpy() if t.dtype == torch.bfloat16 else t.numpy()
+
+
+def test_public_surface_matches_reference_names():
+    for name in ("DEFAULT_GROUP_SIZE", "KERNEL_IMPL", "check_input", "unpack_int4", "DynamicQuantizeMatMul",
+                 "dynamic_quant_matmul", "DynamicQuantizeLinear", "QEmbedding"):
+        assert hasattr(q4, name), name
+    for name in ("KERNEL_IMPL", "check_input", "DynamicQuantizeMatMul", "dynamic_quant_matmul",
+                 "DynamicQuantizeLinear", "QEmbedding"):
+        assert hasattr(q8, name), name
+    assert q4.DEFAULT_GROUP_SIZE == 32
+    assert q4.KERNEL_IMPL in ("hip", "none")
+    assert q4.check_input(torch.zeros(1)) is False
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    assert _lib.available(), "libqlinear_hip.so must be built (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "qlinear_hip.h")).read()
+    declared = set(re.findall(r"\b(qlinear_\w+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert _lib.get_lib().qlinear_abi_version() == 1
+    assert _lib.get_lib().qlinear_status_string(0) == b"ok"
+    assert b"group" in _lib.get_lib().qlinear_status_string(-4)
+    # host-only queries (no GPU needed)
+    assert _lib.get_lib().qlinear_w4g32_packed_bytes(4096, 4096, 32, 1) == 4096 * 128 * 16 + 4096 * 128 * 2
+    assert _lib.get_lib().qlinear_w4g32_packed_bytes(4096, 4096, 64, 1) == 0
+    assert _lib.get_lib().qlinear_workspace_bytes(1, 1, 4096, 4096, 32) == 8 * 1 * 4096 * 4
+    assert _lib.get_lib().qlinear_workspace_bytes(1, 1, 4096, 512, 32) == 0
+
+
+def test_argument_errors_come_back_as_status_codes_without_a_gpu():
+    lib = _lib.get_lib()
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.addressof(buf)
+    assert lib.qlinear_w4g32_fwd(None, None, None, None, None, 1, 8, 64, 32, 64, 8, 1, None, 0, None) == -1
+    assert lib.qlinear_w4g32_fwd(p, p, p, None, p, 0, 8, 64, 32, 64, 8, 1, None, 0, None) == -2
+    assert lib.qlinear_w4g32_fwd(p, p, p, None, p, 1, 8, 64, 32, 64, 8, 7, None, 0, None) == -3
+    assert lib.qlinear_w4g32_fwd(p, p, p, None, p, 1, 8, 64, 24, 64, 8, 1, None, 0, None) == -4
+    assert lib.qlinear_w4g32_fwd_packed(p, p, None, p, 1, 8, 64, 64, 64, 8, 1, None, 0, None) == -4
+    assert lib.qlinear_w8a8_fwd(p, p, p, p, None, p, 1, 8, 40, 8, 1, None) == -7
+    with pytest.raises(ValueError, match="group"):
+        _lib.check(-4, "x")
+
+
+@pytest.mark.parametrize("entry", [":".join(c) for c in G.cases(INT4)])
+def test_int4_module_cpu_branch_matches_reference(entry):
+    name, dt, has_bias = entry.split(":")
+    c = G.case(INT4, name, dt)
+    K, N = c["qweight"].shape[0] * 2, c["qweight"].shape[1]
+    layer = q4.DynamicQuantizeLinear(K, N, bias=has_bias == "1", dtype=TDT[dt])
+    assert [k for k, _ in layer.named_buffers()] == (["weight", "weight_scale", "bias"] if has_bias == "1" else ["weight", "weight_scale"])
+    assert layer.weight.shape == (K // 2, N) and layer.weight.dtype == torch.uint8
+    assert layer.weight_scale.shape == (K // 32, N) and layer.weight_scale.dtype == TDT[dt]
+    layer.apply_weights_(torch.from_numpy(c["qweight"]), G.to_torch(c["scale"], dt),
+                         G.to_torch(c["bias"], dt) if has_bias == "1" else None)
+    out = layer(G.to_torch(c["a"], dt))
+    assert out.dtype == TDT[dt]
+    assert O.rel_l2(t2n(out), c["out_fallback"]) <= REL[dt]
+    if "dense" in c:
+        dense = q4.unpack_int4(layer.weight, layer.weight_scale)
+        assert np.array_equal(t2n(dense).astype(np.float32), np.asarray(c["dense"], np.float32))
+
+
+@pytest.mark.parametrize("entry", [":".join(c) for c in G.cases(INT8)])
+def test_int8_module_cpu_branch_matches_reference(entry):
+    name, dt, has_bias, layout = entry.split(":")
+    c = G.case(INT8, name, dt)
+    a = G.to_torch(c["a"], dt)
+    if layout == "kn":
+        out = q8.dynamic_quant_matmul(a, torch.from_numpy(c["w_kn"]), G.to_torch(c["scale"], dt))
+    else:
+        N, K = c["weight_nk"].shape
+        layer = q8.DynamicQuantizeLinear(K, N, bias=has_bias == "1", dtype=TDT[dt])
+        assert layer.weight.shape == (N, K) and layer.weight.dtype == torch.int8
+        assert layer.weight_scale.shape == (N,)
+        layer.apply_weights_(torch.from_numpy(c["weight_nk"]), G.to_torch(c["scale"], dt),
+                             G.to_torch(c["bias"], dt) if has_bias == "1" else None)
+        out = layer(a)
+    assert O.rel_l2(t2n(out), c["out_fallback"]) <= REL[dt]
+
+
+def test_baseline_config1_int8_128x4096x4096_cpu_plumbing():
+    """BASELINE.json configs[0]: int8 QLinear forward (128 x 4096 -> 4096) on CPU through the module API."""
+    torch.manual_seed(0)
+    a = torch.randn(128, 4096)
+    w = torch.randn(4096, 4096) / 64
+    layer = z8.get_quant_int8_linear(torch.nn.Linear(4096, 4096, bias=True))
+    q, s = z8.quantize_int8(w)
+    layer.apply_weights_(q, s, torch.zeros(4096))
+    out = layer(a)
+    assert out.shape == (128, 4096) and out.dtype == torch.float32
+    ref = O.w8_matmul(a.numpy()[:4], np.ascontiguousarray(q.numpy().T), s.numpy(), np.zeros(4096, np.float32), dtype="f32")
+    assert np.allclose(out.numpy()[:4], ref, atol=1e-4, rtol=1e-4)
+    sd = layer.state_dict()
+    assert sorted(sd) == ["bias", "weight", "weight_scale"] and sd["weight"].dtype == torch.int8
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_quantizer_writers_are_format_exact(dt):
+    z = G.load("quantizers.npz")
+    q, s = z4.quantize_int4(torch.from_numpy(z[f"int4_{dt}/w"]))
+    assert np.array_equal(q.numpy(), z[f"int4_{dt}/q"])
+    assert np.array_equal(s.numpy().astype(np.float32), z[f"int4_{dt}/scale"].astype(np.float32))
+    q8_, s8 = z8.quantize_int8(torch.from_numpy(z[f"int8_{dt}/x"]))
+    assert np.array_equal(q8_.numpy(), z[f"int8_{dt}/q"])
+    assert np.array_equal(s8.numpy().astype(np.float32), z[f"int8_{dt}/scale"].astype(np.float32))
+
+
+def test_qembedding_cpu_branch():
+    z = G.load("qembedding.npz")
+    ids = torch.from_numpy(z["ids"])
+    e4 = q4.QEmbedding(128, 64, dtype=torch.float16)
+    e4.apply_weights_(torch.from_numpy(z["int4/qweight"]), torch.from_numpy(z["int4/scale"]))
+    assert np.array_equal(e4(ids).numpy(), z["int4/out"])
+    e8 = q8.QEmbedding(128, 64, dtype=torch.float32)
+    e8.apply_weights_(torch.from_numpy(z["int8/weight"]), torch.from_numpy(z["int8/scale"]))
+    assert np.array_equal(e8(ids).numpy(), z["int8/out"])
+
+
+def test_loader_style_in_place_fill_and_converters():
+    """The reference loader copies tensors straight into state_dict() (chatglm_q/loader.py:90-104)."""
+    layer = q4.DynamicQuantizeLinear(64, 16, bias=True, dtype=torch.float16)
+    sd = layer.state_dict()
+    sd["weight"].copy_(torch.full((32, 16), 0x88, dtype=torch.uint8))
+    sd["weight_scale"].copy_(torch.ones(2, 16).half())
+    sd["bias"].copy_(torch.arange(16).half())
+    out = layer(torch.randn(3, 64).half())
+    assert torch.equal(out, torch.arange(16).half().expand(3, 16))      # all weights decode to zero
+    lin = torch.nn.Linear(64, 16)
+    ql = z4.get_quant_int4_linear(lin)
+    assert ql.weight.shape == (32, 16) and ql.bias is not None
+    assert torch.allclose(ql(torch.eye(64))[:4], lin(torch.eye(64))[:4], atol=0.05)
+    with pytest.raises(AssertionError):
+        q4.DynamicQuantizeLinear(100, 16, group_size=32)
+
+
+def test_autograd_through_cpu_branch():
+    torch.manual_seed(1)
+    a = torch.randn(4, 64, requires_grad=True)
+    w = torch.randn(64, 16) / 8
+    q, s = z4.quantize_int4(w)
+    q4.dynamic_quant_matmul(a, q, s).sum().backward()
+    assert torch.allclose(a.grad, torch.ones(4, 16) @ q4.unpack_int4(q, s).t(), atol=1e-5)
+
+
+def test_gpu_tensor_without_library_raises(monkeypatch):
+    """The product path must fail loudly, never fall back, when the HIP extension is missing."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_load_error", OSError("simulated missing library"))
+    with pytest.raises(_lib.QLinearLibraryMissing):
+        _lib.get_lib()
