@@ -18,6 +18,11 @@ ABI_VERSION = 1
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
+FLAG_STRICT_ROUNDING = 1
+
+# QLINEAR_STRICT=1: reproduce the reference's per-weight rounding bit for bit in every kernel
+STRICT_DEFAULT = os.environ.get("QLINEAR_STRICT", "0") not in ("0", "", "false", "False")
+
 OP_W4G32_FWD = 1
 OP_W4G32_FWD_PACKED = 2
 OP_W8_FWD = 3
@@ -34,9 +39,9 @@ EXPORTS = {
     "qlinear_w4g32_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                         c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+                                         c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                               c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+                               c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_int, c_void_p]),

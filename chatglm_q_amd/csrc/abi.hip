@@ -94,8 +94,8 @@ int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t
 }
 
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                             int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, int flags,
+                             void* workspace, size_t workspace_bytes, void* stream) {
     (void)workspace;
     (void)workspace_bytes;
     if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
@@ -103,12 +103,14 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
     if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
     if (!aligned(packed, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
-    return w4_packed(dtype, A, packed, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+    return w4_packed(dtype, A, packed, bias, C, M, N, K, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0,
+                     (hipStream_t)stream);
 }
 
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
-                   int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, void* workspace,
-                   size_t workspace_bytes, void* stream) {
+                   int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, int flags,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    (void)flags;
     (void)workspace;
     (void)workspace_bytes;
     if (!A || !W || !S || !C) return QL_ERR_NULL_POINTER;

@@ -67,10 +67,23 @@ __device__ __forceinline__ void store_out(T* c, float acc, const T* bias_n) {
 // ---------------------------------------------------------------------------------------------
 // Wave-level helpers (wave64).
 // ---------------------------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave, result in every lane.  Four DPP steps (full-rate VALU modifiers, no
+// LDS round trip as ds_bpermute-based shuffles have) leave each 16-lane row's sum in all of its lanes;
+// the four row sums are then read through SGPRs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+    v += dpp_move<0x141>(v);   // row_half_mirror      : i <-> 7 - i  (joins the two quads of each 8)
+    v += dpp_move<0x140>(v);   // row_mirror           : i <-> 15 - i (joins the two halves of the row)
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -2,13 +2,12 @@
 //
 // Replaces _dynamic_quant_matmul_s4_kernel (chatglm_q/int4/triton_ops.py:18-87).
 //
-// Three kernels, all weight-only dequant fused into the contraction, fp32 accumulation:
+// Kernels on the reference (canonical) layout, weight-only dequant fused into the contraction,
+// fp32 accumulation:
 //   w4_generic_kernel      any group size / any N; one thread per output element (robustness path)
-//   w4_canon_kernel        reference (K/2, N) layout, group 32: 128-column x 16-group tiles,
+//   w4_canon_kernel        (K/2, N) layout, group 32: 128-column x 16-group tiles,
 //                          split-K over workgroups + splitk_reduce_kernel
-//   w4_packed_gemv_kernel  derived column-major layout: one wave owns 4 output columns for all of K,
-//                          no cross-workgroup reduction, no LDS, no barriers (decode shapes, M <= 4)
-// plus w4_repack_kernel that builds the derived layout from the canonical buffers.
+// The derived-layout kernels live in w4_packed.hip.
 #include "launch.h"
 #include "w4_dequant.h"
 
@@ -205,142 +204,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // =============================================================================================
-// derived streaming layout ("packed"), group 32
-//   weights : Wt[n][g] = one 16-byte unit holding the 32 nibbles of column n, group g; n padded
-//             to a multiple of 4.  Word j of the unit holds k = 8j .. 8j+7 at nibble positions
-//             p(kk) = (kk >> 1) + 4 (kk & 1), i.e. nibbles (p, p+4) are the k-adjacent pair
-//             (2p, 2p+1): one v_and_or_b32 yields a k-pair ready for v_dot2c_f32_f16.
-//   scales  : Sp[t][g][c], t = n / 4, c = n % 4 (one 8-byte load per lane per group for fp16).
-// =============================================================================================
-__device__ __forceinline__ int packed_pos(int kk) { return (kk >> 1) + 4 * (kk & 1); }
-
-template <typename T>
-__global__ __launch_bounds__(256) void w4_repack_kernel(const uint8_t* __restrict__ Wq, const T* __restrict__ S,
-                                                        u32x4* __restrict__ Wt, T* __restrict__ Sp, int N, int Npad,
-                                                        int G) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int g = blockIdx.y;
-    if (n >= Npad) return;
-    u32x4 out = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};   // q == 0 for padded columns
-    float sc = 0.f;
-    if (n < N) {
-        u32 words[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u32 b = Wq[((int64_t)g * 16 + r) * N + n];
-            const int k0 = 2 * r, k1 = 2 * r + 1;                         // k within the group
-            words[k0 >> 3] |= (b & 0xFu) << (4 * packed_pos(k0 & 7));
-            words[k1 >> 3] |= (b >> 4) << (4 * packed_pos(k1 & 7));
-        }
-        out = u32x4{words[0], words[1], words[2], words[3]};
-        sc = Act<T>::load(S + (int64_t)g * N + n);
-    }
-    Wt[(int64_t)n * G + g] = out;
-    Act<T>::store(Sp + ((int64_t)(n >> 2) * G + g) * 4 + (n & 3), sc);
-}
-
-template <typename T, int MB>
-__global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
-                                                             const T* __restrict__ Sp, const T* __restrict__ bias,
-                                                             T* __restrict__ C, int M, int N, int K, int G,
-                                                             int64_t lda, int64_t ldc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wave;       // column quad owned by this wave
-    if (t * 4 >= N) return;                    // waves are independent: no barriers below
-    const int m0 = blockIdx.y * MB;
-
-    float acc[MB][4];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
-
-    const u32x4* wbase = Wt + (int64_t)t * 4 * G;
-    const T* sbase = Sp + (int64_t)t * G * 4;
-    const T* arow[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
-
-#pragma unroll 2
-    for (int g = lane; g < G; g += 64) {
-        u32x4 w[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = __builtin_nontemporal_load(wbase + (int64_t)c * G + g);
-
-        if constexpr (Act<T>::code == QL_DTYPE_F16) {
-            const u32x2 sv = *reinterpret_cast<const u32x2*>(sbase + (int64_t)g * 4);
-            const h2 s2[4] = {as_h2((sv[0] & 0xFFFFu) | (sv[0] << 16)), as_h2((sv[0] >> 16) | (sv[0] & 0xFFFF0000u)),
-                              as_h2((sv[1] & 0xFFFFu) | (sv[1] << 16)), as_h2((sv[1] >> 16) | (sv[1] & 0xFFFF0000u))};
-            h2 av[MB][16];
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u32x4 x = *reinterpret_cast<const u32x4*>(arow[m] + g * 32 + 8 * j);
-                    av[m][4 * j + 0] = as_h2(x[0]);
-                    av[m][4 * j + 1] = as_h2(x[1]);
-                    av[m][4 * j + 2] = as_h2(x[2]);
-                    av[m][4 * j + 3] = as_h2(x[3]);
-                }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const NibblePairs e = nibble_pairs_f16(w[c][j]);   // e_i = (k = 8j+2i, 8j+2i+1)
-                    const h2 w0 = e.e0 * s2[c], w1 = e.e1 * s2[c], w2 = e.e2 * s2[c], w3 = e.e3 * s2[c];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        float v = acc[m][c];
-                        v = __builtin_amdgcn_fdot2(w0, av[m][4 * j + 0], v, false);
-                        v = __builtin_amdgcn_fdot2(w1, av[m][4 * j + 1], v, false);
-                        v = __builtin_amdgcn_fdot2(w2, av[m][4 * j + 2], v, false);
-                        v = __builtin_amdgcn_fdot2(w3, av[m][4 * j + 3], v, false);
-                        acc[m][c] = v;
-                    }
-                }
-        } else {
-            float s[4], m8s[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s[c] = Act<T>::load(sbase + (int64_t)g * 4 + c);
-                m8s[c] = -8.0f * s[c];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    float a[MB];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) a[m] = Act<T>::load(arow[m] + g * 32 + 8 * j + kk);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float wq = dequant_nibble<T>(w[c][j], (kk >> 1) + 4 * (kk & 1), s[c], m8s[c]);
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(a[m], wq, acc[m][c]);
-                    }
-                }
-        }
-    }
-
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[m][c] = wave_sum(acc[m][c]);
-
-    if (lane == 0) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (m0 + m >= M) break;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int n = t * 4 + c;
-                if (n < N) store_out<T>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
-            }
-        }
-    }
-}
-
-// =============================================================================================
 // host-side launchers (called from abi.hip)
 // =============================================================================================
 template <typename T>
@@ -394,36 +257,6 @@ static int launch_w4_canon(const void* A_, const uint8_t* Wq, const void* S_, co
     return 0;
 }
 
-template <typename T>
-static int launch_w4_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
-    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    u32x4* Wt = (u32x4*)packed;
-    T* Sp = (T*)((char*)packed + Npad * G * 16);
-    dim3 grid((unsigned)((Npad + 255) / 256), (unsigned)G);
-    w4_repack_kernel<T><<<grid, 256, 0, st>>>(Wq, (const T*)S, Wt, Sp, (int)N, (int)Npad, (int)G);
-    return finish_launch();
-}
-
-template <typename T, int MB>
-static int launch_w4_packed_mb(const T* A, const void* packed, const T* bias, T* C, int M, int N, int K, int64_t lda,
-                               int64_t ldc, hipStream_t st) {
-    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    const u32x4* Wt = (const u32x4*)packed;
-    const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
-    const int quads = (int)(Npad / 4);
-    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((M + MB - 1) / MB));
-    w4_packed_gemv_kernel<T, MB><<<grid, 256, 0, st>>>(A, Wt, Sp, bias, C, M, N, K, (int)G, lda, ldc);
-    return finish_launch();
-}
-
-template <typename T>
-static int launch_w4_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                            int64_t K, int64_t lda, int64_t ldc, hipStream_t st) {
-    if (M == 1) return launch_w4_packed_mb<T, 1>((const T*)A, packed, (const T*)bias, (T*)C, 1, (int)N, (int)K, lda, ldc, st);
-    if (M == 2) return launch_w4_packed_mb<T, 2>((const T*)A, packed, (const T*)bias, (T*)C, 2, (int)N, (int)K, lda, ldc, st);
-    return launch_w4_packed_mb<T, 4>((const T*)A, packed, (const T*)bias, (T*)C, (int)M, (int)N, (int)K, lda, ldc, st);
-}
-
 #define QL_DISPATCH_DTYPE(dtype, fn, ...)                         \
     switch (dtype) {                                              \
     case QL_DTYPE_F32: return fn<float>(__VA_ARGS__);             \
@@ -440,12 +273,4 @@ int w4_canon(int dtype, const void* A, const uint8_t* Wq, const void* S, const v
              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, hipStream_t st) {
     QL_DISPATCH_DTYPE(dtype, launch_w4_canon, A, Wq, S, bias, C, ws, M, N, K, lda, ldc, st)
 }
-int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
-    QL_DISPATCH_DTYPE(dtype, launch_w4_repack, Wq, S, packed, N, K, st)
-}
-int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-              int64_t K, int64_t lda, int64_t ldc, hipStream_t st) {
-    QL_DISPATCH_DTYPE(dtype, launch_w4_packed, A, packed, bias, C, M, N, K, lda, ldc, st)
-}
-
 }  // namespace ql

@@ -1,0 +1,589 @@
+// int4g32 decode-shape GEMV on the derived streaming layout (gfx950 / MI355X).
+//
+// Layout ("packed", built once per weight by w4_repack_kernel from the canonical buffers):
+//   weights : Wt[n][g] = one 16-byte unit holding the 32 nibbles of column n, group g; n padded to
+//             a multiple of 4.  Word j of the unit holds k = 8j .. 8j+7 at nibble positions
+//             p(kk) = (kk >> 1) + 4 (kk & 1), i.e. nibbles (p, p+4) are the k-adjacent pair
+//             (2p, 2p+1): one v_and_or_b32 yields a k-pair ready for v_dot2c_f32_f16.
+//   scales  : Sp[t][g][c], t = n / 4, c = n % 4 (one 8-byte load per lane per group for fp16).
+//
+// Work decomposition: one WAVE owns 4 output columns for ALL of K; lane l of the wave walks the
+// groups l, l+64, ... .  Every weight load instruction is 64 lanes x 16 B = 1 KiB contiguous, no
+// partial sums ever leave the wave (6 cross-lane steps at the end), no cross-workgroup reduction.
+// The activation row is shared by the block's 4 waves through LDS (16-byte chunks, XOR-swizzled so
+// that the 64-byte-strided per-lane reads are bank-conflict free).
+//
+// Latency structure (the whole 1x4096->4096 problem is ~37 KB per CU, i.e. one HBM round trip):
+// the loads of the first TWO group tiles are issued before anything else waits, later tiles are
+// issued two iterations ahead of their use; activations are the OLDEST entries of the vector-memory
+// queue so that their s_waitcnt does not drain the weight loads behind them.
+#include <stdlib.h>
+
+#include "launch.h"
+#include "w4_dequant.h"
+
+namespace ql {
+
+__device__ __forceinline__ int packed_pos(int kk) { return (kk >> 1) + 4 * (kk & 1); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void w4_repack_kernel(const uint8_t* __restrict__ Wq, const T* __restrict__ S,
+                                                        u32x4* __restrict__ Wt, T* __restrict__ Sp, int N, int Npad,
+                                                        int G) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (n >= Npad) return;
+    u32x4 out = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};   // q == 0 for padded columns
+    float sc = 0.f;
+    if (n < N) {
+        u32 words[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const u32 b = Wq[((int64_t)g * 16 + r) * N + n];
+            const int k0 = 2 * r, k1 = 2 * r + 1;                         // k within the group
+            words[k0 >> 3] |= (b & 0xFu) << (4 * packed_pos(k0 & 7));
+            words[k1 >> 3] |= (b >> 4) << (4 * packed_pos(k1 & 7));
+        }
+        out = u32x4{words[0], words[1], words[2], words[3]};
+        sc = Act<T>::load(S + (int64_t)g * N + n);
+    }
+    Wt[(int64_t)n * G + g] = out;
+    Act<T>::store(Sp + ((int64_t)(n >> 2) * G + g) * 4 + (n & 3), sc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit activation kernel (fp16 / bf16)
+// ---------------------------------------------------------------------------------------------
+// Two arithmetic modes, selected per call (QL_FLAG_STRICT_ROUNDING):
+//
+//  strict (fp16 only): every dequantised weight (n - 8) * s is rounded to fp16 before it meets the
+//      activation - bit-for-bit the reference's rounding sequence (chatglm_q/int4/triton_ops.py:72-73).
+//      Per 8 weights: 1 shift, 4 v_and_or, 4 exact offset removals, 4 v_pk_mul_f16, 4 v_dot2c.
+//
+//  exact-dequant (default): the offset form produced by the exponent splice is fed to v_dot2c AS IS
+//      and the group's affine correction is applied once per (column, group) in fp32:
+//          sum_k a_k (n_k - 8) s  =  s * u * ( sum_k a_k v_k  -  o * sum_k a_k ),   v_k = splice(n_k)
+//      fp16: v = 0x6400 | (n << 4) = 16 (64 + n)   -> u = 1/16, o = 1152   (nibble at mantissa bits 4..7)
+//      bf16: v = 0x4300 | n        = 128 + n       -> u = 1,    o = 136    (nibble at mantissa bits 0..3)
+//      Products a_k v_k are exact in fp32; the cancellation costs < 2^-17 relative per group
+//      (offset/step = 64 resp. 128), so this mode is CLOSER to real-number arithmetic than the
+//      reference's per-weight fp16 rounding and differs from it by that rounding only (~2e-4 relative,
+//      inside the 1e-3 tolerance).  Per 8 weights: 3 shifts, 4 v_and_or, 4 v_dot2c.
+//
+// LDS image of the activation rows: 16-byte chunk cc of row m (k = 8 cc .. 8 cc + 7) lives at chunk
+// position  m * K/8 + 4 g + (j ^ ((g >> 2) & 3))  with g = cc >> 2 (its group), j = cc & 3.
+// A lane reads the 4 chunks of ITS group (64-byte lane stride); the XOR spreads each 16-lane
+// ds_read_b128 service group over all 16 four-bank slots.
+__device__ __forceinline__ int a_chunk_pos(int g, int j) { return 4 * g + (j ^ ((g >> 2) & 3)); }
+
+template <typename T> struct Splice;
+template <> struct Splice<f16> {
+    static constexpr u32 kMagic = 0x64006400u, kMask = 0x00F000F0u, kOnes = 0x3C003C00u;
+    static constexpr float kOffset = 1152.0f, kUnit = 0.0625f;
+    // nibble pair i = positions (i, i + 4) of the word = k pair (2i, 2i+1); bring it to bits 4..7 / 20..23
+    static __device__ __forceinline__ u32 align(u32 w, int i) { return i == 0 ? (w << 4) : (i == 1 ? w : (w >> (4 * i - 4))); }
+    static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
+        return __builtin_amdgcn_fdot2(as_h2(x), as_h2(a), acc, false);
+    }
+    static __device__ __forceinline__ float lo(u32 s) { return (float)as_h2(s).x; }
+    static __device__ __forceinline__ float hi(u32 s) { return (float)as_h2(s).y; }
+};
+template <> struct Splice<__bf16> {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    static constexpr u32 kMagic = 0x43004300u, kMask = 0x000F000Fu, kOnes = 0x3F803F80u;
+    static constexpr float kOffset = 136.0f, kUnit = 1.0f;
+    static __device__ __forceinline__ u32 align(u32 w, int i) { return w >> (4 * i); }
+    static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x), __builtin_bit_cast(bf2, a), acc, false);
+    }
+    static __device__ __forceinline__ float lo(u32 s) { return u32_as_f32(s << 16); }
+    static __device__ __forceinline__ float hi(u32 s) { return u32_as_f32(s & 0xFFFF0000u); }
+};
+
+template <int MB, bool A_LDS>
+struct PackedTile16 {
+    u32x4 w[4];
+    u32x2 s;
+    u32x4 a[A_LDS ? 1 : MB][A_LDS ? 1 : 4];   // activations only when they are NOT staged in LDS
+};
+
+// VAR is a developer knob (tools/microbench): 0 = product kernel; the other values strip parts of the
+// kernel to attribute time.  Only VAR == 0 is instantiated unless QL_DEV_VARIANTS is defined.
+//   1: no math (loaded words are XOR-folded), 2: math with a constant activation (no LDS reads),
+//   4: as 2 and no activation staging at all (no staging loads, no LDS writes, no barrier)
+// KS: the block's 4 waves cover 4/KS column quads x KS slices of K (combined through LDS at the end):
+// shapes with few columns but a long K (w_out: 13696 -> 4096) get 4x the workgroups and 4x the loads
+// in flight per column instead of one wave walking 7 tiles in sequence.
+template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
+__global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+                                                                const T* __restrict__ Sp, const T* __restrict__ bias,
+                                                                T* __restrict__ C, int M, int N, int K, int G,
+                                                                int64_t lda, int64_t ldc) {
+    static_assert(!STRICT || Act<T>::code == QL_DTYPE_F16, "strict rounding mode exists for fp16 only");
+    constexpr bool A_LDS = ACH > 0;
+    typedef Splice<T> SP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QW = 4 / KS;                 // column quads per block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave % KS;
+    const int t_raw = blockIdx.x * QW + wave / KS;
+    const bool wave_active = t_raw * 4 < N;
+    const int t = wave_active ? t_raw : 0;     // inactive waves shadow quad 0 (they must reach the barriers)
+    const int m0 = blockIdx.y * MB;
+    const int gs = (G + KS - 1) / KS;          // groups per K slice
+    const int g_begin = ks * gs;
+    const int g_end = min(G, g_begin + gs);
+    const int iters = g_end > g_begin ? (g_end - g_begin + 63) >> 6 : 0;
+    const int cpr = K >> 3;                    // 16-byte chunks per activation row
+
+    // splice constants live in registers so that (w & mask) | magic is ONE v_and_or_b32
+    // (two 32-bit literals cannot be encoded in one VOP3 instruction)
+    u32 k_mask, k_magic;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask) : "i"(STRICT ? 0x000F000Fu : SP::kMask));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(SP::kMagic));
+
+    const T* arow[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
+
+    // (1) activation staging loads first: oldest in the VM queue
+    u32x4 areg[A_LDS ? ACH : 1];
+    if constexpr (A_LDS && VAR != 4) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            // unconditional (clamped) load: a load under a per-element condition makes hipcc branch
+            // around it and drain the queue (vmcnt(0)) per element
+            const int c = min(tid + i * 256, MB * cpr - 1);
+            const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
+            areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
+        }
+    }
+
+    const u32x4* wbase = Wt + (int64_t)t * 4 * G;
+    const T* sbase = Sp + (int64_t)t * G * 4;
+
+    auto load_tile = [&](int it) {
+        PackedTile16<MB, A_LDS> tl;
+        const int g = g_begin + it * 64 + lane;
+        const int gc = g < g_end ? g : G - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tl.w[c] = __builtin_nontemporal_load(wbase + (int64_t)c * G + gc);
+        tl.s = *reinterpret_cast<const u32x2*>(sbase + (int64_t)gc * 4);   // masked at use, not here:
+                                                                           // touching it now would drain the queue
+        if constexpr (!A_LDS) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tl.a[m][j] = *reinterpret_cast<const u32x4*>(arow[m] + gc * 32 + 8 * j);
+        }
+        return tl;
+    };
+
+    // (2) two weight tiles in flight before anything waits
+    PackedTile16<MB, A_LDS> t0 = load_tile(0);
+    PackedTile16<MB, A_LDS> t1;
+    if (iters > 1) t1 = load_tile(1);          // wave-uniform branch around the whole tile
+
+    // (3) stage the activations (waits only for the staging loads, which are older than the tiles)
+    if constexpr (A_LDS && VAR != 4) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * 256;
+            if (c < MB * cpr) {
+                const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
+                *reinterpret_cast<u32x4*>(smem + ((int64_t)m * cpr + a_chunk_pos(cc >> 2, cc & 3)) * 16) = areg[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    float acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    auto compute_tile = [&](const PackedTile16<MB, A_LDS>& tl, int it) {
+        const int g = g_begin + it * 64 + lane;
+        const int gc = g < g_end ? g : G - 1;
+        u32 av[MB][16];                                       // av[m][i] = (a[2i], a[2i+1]) of this lane's group
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 x;
+                if constexpr (VAR == 2 || VAR == 4)
+                    x = u32x4{SP::kOnes, SP::kOnes, SP::kOnes, SP::kOnes};
+                else if constexpr (A_LDS)
+                    x = *reinterpret_cast<const u32x4*>(smem + ((int64_t)m * cpr + a_chunk_pos(gc, j)) * 16);
+                else
+                    x = tl.a[m][j];
+                av[m][4 * j + 0] = x[0];
+                av[m][4 * j + 1] = x[1];
+                av[m][4 * j + 2] = x[2];
+                av[m][4 * j + 3] = x[3];
+            }
+        const u32x2 sv = g < g_end ? tl.s : u32x2{0u, 0u};    // out-of-range lanes contribute 0
+        if constexpr (VAR == 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[0][c] += u32_as_f32((tl.w[c][0] ^ tl.w[c][1] ^ tl.w[c][2] ^ tl.w[c][3] ^ sv[0] ^ sv[1] ^ av[0][c]) &
+                                        0x3fffffffu);
+            return;
+        }
+        if constexpr (STRICT) {
+            const h2 k1032 = {(f16)1032.0f, (f16)1032.0f};
+            const h2 kInv16 = {(f16)0.0625f, (f16)0.0625f};
+            const h2 kM72 = {(f16)-72.0f, (f16)-72.0f};
+            u32 k_mask_hi;
+            asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+            const h2 s2[4] = {as_h2((sv[0] & 0xFFFFu) | (sv[0] << 16)), as_h2((sv[0] >> 16) | (sv[0] & 0xFFFF0000u)),
+                              as_h2((sv[1] & 0xFFFFu) | (sv[1] << 16)), as_h2((sv[1] >> 16) | (sv[1] & 0xFFFF0000u))};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 w = tl.w[c][j], w8 = w >> 8;
+                    // exact (n - 8) as fp16 pairs, then ONE rounding per weight in the scale multiply
+                    const h2 w0 = (as_h2((w & k_mask) | k_magic) - k1032) * s2[c];
+                    const h2 w1 = (as_h2((w & k_mask_hi) | k_magic) * kInv16 + kM72) * s2[c];
+                    const h2 w2 = (as_h2((w8 & k_mask) | k_magic) - k1032) * s2[c];
+                    const h2 w3 = (as_h2((w8 & k_mask_hi) | k_magic) * kInv16 + kM72) * s2[c];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        float v = acc[m][c];
+                        v = __builtin_amdgcn_fdot2(w0, as_h2(av[m][4 * j + 0]), v, false);
+                        v = __builtin_amdgcn_fdot2(w1, as_h2(av[m][4 * j + 1]), v, false);
+                        v = __builtin_amdgcn_fdot2(w2, as_h2(av[m][4 * j + 2]), v, false);
+                        v = __builtin_amdgcn_fdot2(w3, as_h2(av[m][4 * j + 3]), v, false);
+                        acc[m][c] = v;
+                    }
+                }
+        } else {
+            float corr[MB];                                   // offset * sum of this group's activations
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                float e = 0.f, o = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    e = SP::dot(SP::kOnes, av[m][i], e);
+                    o = SP::dot(SP::kOnes, av[m][i + 1], o);
+                }
+                corr[m] = SP::kOffset * (e + o);
+            }
+            const float sc[4] = {SP::lo(sv[0]) * SP::kUnit, SP::hi(sv[0]) * SP::kUnit, SP::lo(sv[1]) * SP::kUnit,
+                                 SP::hi(sv[1]) * SP::kUnit};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float e[MB], o[MB];                           // two independent dot chains per row
+#pragma unroll
+                for (int m = 0; m < MB; ++m) e[m] = o[m] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 w = tl.w[c][j];
+                    const u32 x0 = (SP::align(w, 0) & k_mask) | k_magic;
+                    const u32 x1 = (SP::align(w, 1) & k_mask) | k_magic;
+                    const u32 x2 = (SP::align(w, 2) & k_mask) | k_magic;
+                    const u32 x3 = (SP::align(w, 3) & k_mask) | k_magic;
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        e[m] = SP::dot(x0, av[m][4 * j + 0], e[m]);
+                        o[m] = SP::dot(x1, av[m][4 * j + 1], o[m]);
+                        e[m] = SP::dot(x2, av[m][4 * j + 2], e[m]);
+                        o[m] = SP::dot(x3, av[m][4 * j + 3], o[m]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(sc[c], (e[m] + o[m]) - corr[m], acc[m][c]);
+            }
+        }
+    };
+
+    // ping-pong over two register tiles: a tile's registers are refilled (for two iterations later)
+    // right after its math, so one tile is always in flight under the other tile's math and no
+    // register copy ever touches a pending load
+    for (int it = 0; it < iters; it += 2) {
+        compute_tile(t0, it);
+        if (it + 2 < iters) t0 = load_tile(it + 2);
+        if (it + 1 < iters) {
+            compute_tile(t1, it + 1);
+            if (it + 3 < iters) t1 = load_tile(it + 3);
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = wave_sum(acc[m][c]);
+
+    if constexpr (KS > 1) {
+        // combine the K slices of a quad: slice 0 of each quad adds its partners' sums
+        float* red = reinterpret_cast<float*>(smem + (A_LDS ? (((size_t)MB * K * sizeof(T) + 15) & ~(size_t)15) : 0));
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[(wave * MB + m) * 4 + c] = acc[m][c];
+        }
+        __syncthreads();
+        if (ks == 0 && lane == 0) {
+#pragma unroll
+            for (int p = 1; p < KS; ++p)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[m][c] += red[((wave + p) * MB + m) * 4 + c];
+        }
+    }
+
+    if (wave_active && ks == 0 && lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m0 + m >= M) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = t * 4 + c;
+                if (n < N) store_out<T>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic dtype kernel (fp32 / bf16): same decomposition, per-nibble dequant, activations from global
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct PackedTileG {
+    u32x4 w[4];
+    float s[4];
+};
+
+template <typename T, int MB>
+__global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+                                                             const T* __restrict__ Sp, const T* __restrict__ bias,
+                                                             T* __restrict__ C, int M, int N, int K, int G,
+                                                             int64_t lda, int64_t ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave;
+    if (t * 4 >= N) return;                    // no barriers in this kernel
+    const int m0 = blockIdx.y * MB;
+    const int iters = (G + 63) >> 6;
+    const u32x4* wbase = Wt + (int64_t)t * 4 * G;
+    const T* sbase = Sp + (int64_t)t * G * 4;
+    const T* arow[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
+
+    auto load_tile = [&](int it) {
+        PackedTileG<T> tl;
+        const int g = it * 64 + lane;
+        const int gc = g < G ? g : G - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tl.w[c] = __builtin_nontemporal_load(wbase + (int64_t)c * G + gc);
+            tl.s[c] = Act<T>::load(sbase + (int64_t)gc * 4 + c);         // masked at use
+        }
+        return tl;
+    };
+
+    float acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    PackedTileG<T> t0 = load_tile(0);
+    for (int it = 0; it < iters; ++it) {
+        PackedTileG<T> t1 = t0;
+        if (it + 1 < iters) t1 = load_tile(it + 1);
+        const int g = it * 64 + lane;
+        const int gc = g < G ? g : G - 1;
+        float m8s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (g >= G) t0.s[c] = 0.f;                                   // out-of-range lanes contribute 0
+            m8s[c] = -8.0f * t0.s[c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float a[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) a[m] = Act<T>::load(arow[m] + gc * 32 + 8 * j + kk);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float wq = dequant_nibble<T>(t0.w[c][j], packed_pos(kk), t0.s[c], m8s[c]);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(a[m], wq, acc[m][c]);
+                }
+            }
+        t0 = t1;
+    }
+
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = wave_sum(acc[m][c]);
+
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m0 + m >= M) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = t * 4 + c;
+                if (n < N) store_out<T>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_w4_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
+    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
+    u32x4* Wt = (u32x4*)packed;
+    T* Sp = (T*)((char*)packed + Npad * G * 16);
+    dim3 grid((unsigned)((Npad + 255) / 256), (unsigned)G);
+    w4_repack_kernel<T><<<grid, 256, 0, st>>>(Wq, (const T*)S, Wt, Sp, (int)N, (int)Npad, (int)G);
+    return finish_launch();
+}
+
+struct PackedArgs {
+    const void* A;
+    const void* packed;
+    const void* bias;
+    void* C;
+    int M, N, K;
+    int64_t lda, ldc;
+    bool strict;
+    hipStream_t st;
+};
+
+#ifdef QL_DEV_VARIANTS
+static int dev_variant() {
+    static const int v = [] { const char* e = getenv("QL_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#endif
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// K slices per block: as many as keep every lane of a wave busy (>= 64 groups per slice) while the
+// grid is still small (fewer than ~8 blocks per CU); QLINEAR_W4_KSPLIT overrides for measurements.
+static int choose_ksplit(int64_t quads, int64_t G) {
+    static const int forced = env_int("QLINEAR_W4_KSPLIT", 0);
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    int ks = 1;
+    while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 2048) ks *= 2;
+    return ks;
+}
+
+template <typename T, int MB, int ACH, int KS, bool STRICT>
+static int launch_16(const PackedArgs& p) {
+    const int64_t G = p.K / 32, Npad = (p.N + 3) & ~(int64_t)3;
+    const u32x4* Wt = (const u32x4*)p.packed;
+    const T* Sp = (const T*)((const char*)p.packed + Npad * G * 16);
+    const int quads = (int)(Npad / 4);
+    constexpr int QW = 4 / KS;
+    dim3 grid((unsigned)((quads + QW - 1) / QW), (unsigned)((p.M + MB - 1) / MB));
+    const size_t lds = (ACH > 0 ? (((size_t)MB * p.K * sizeof(T) + 15) & ~(size_t)15) : 0) +
+                       (KS > 1 ? (size_t)4 * MB * 4 * sizeof(float) : 0);
+#ifdef QL_DEV_VARIANTS
+    if constexpr (MB == 1 && !STRICT) {
+        if (dev_variant() == 1) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 1><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            return finish_launch();
+        }
+        if (dev_variant() == 2) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 2><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            return finish_launch();
+        }
+        if (dev_variant() == 4) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 4><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            return finish_launch();
+        }
+    }
+#endif
+    w4_packed_gemv_16_kernel<T, MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias,
+                                                                               (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+    return finish_launch();
+}
+
+template <typename T, int MB, int KS, bool STRICT>
+static int launch_16_ach(const PackedArgs& p) {
+    const int64_t chunks = (int64_t)MB * (p.K / 8);
+    const bool lds_ok = (size_t)MB * p.K * sizeof(T) <= 60 * 1024;
+#ifdef QL_DEV_VARIANTS
+    if (dev_variant() == 3) return launch_16<T, MB, 0, KS, STRICT>(p);     // activations straight from global
+#endif
+    if (lds_ok && chunks <= 2 * 256) return launch_16<T, MB, 2, KS, STRICT>(p);
+    if (lds_ok && chunks <= 4 * 256) return launch_16<T, MB, 4, KS, STRICT>(p);
+    if (lds_ok && chunks <= 8 * 256) return launch_16<T, MB, 8, KS, STRICT>(p);
+    return launch_16<T, MB, 0, KS, STRICT>(p);
+}
+
+template <typename T, int MB, bool STRICT>
+static int launch_16_mb(const PackedArgs& p) {
+    const int64_t Npad = (p.N + 3) & ~(int64_t)3;
+    switch (choose_ksplit(Npad / 4, p.K / 32)) {
+    case 4: return launch_16_ach<T, MB, 4, STRICT>(p);
+    case 2: return launch_16_ach<T, MB, 2, STRICT>(p);
+    default: return launch_16_ach<T, MB, 1, STRICT>(p);
+    }
+}
+
+template <typename T, bool STRICT>
+static int launch_16_any(const PackedArgs& p) {
+    if (p.M == 1) return launch_16_mb<T, 1, STRICT>(p);
+    if (p.M == 2) return launch_16_mb<T, 2, STRICT>(p);
+    return launch_16_mb<T, 4, STRICT>(p);
+}
+
+template <typename T, int MB>
+static int launch_generic_mb(const PackedArgs& p) {
+    const int64_t G = p.K / 32, Npad = (p.N + 3) & ~(int64_t)3;
+    const u32x4* Wt = (const u32x4*)p.packed;
+    const T* Sp = (const T*)((const char*)p.packed + Npad * G * 16);
+    const int quads = (int)(Npad / 4);
+    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
+    w4_packed_gemv_kernel<T, MB><<<grid, 256, 0, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N,
+                                                         p.K, (int)G, p.lda, p.ldc);
+    return finish_launch();
+}
+
+int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w4_repack<float>(Wq, S, packed, N, K, st);
+    case QL_DTYPE_F16: return launch_w4_repack<f16>(Wq, S, packed, N, K, st);
+    case QL_DTYPE_BF16: return launch_w4_repack<__bf16>(Wq, S, packed, N, K, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+              int64_t K, int64_t lda, int64_t ldc, bool strict, hipStream_t st) {
+    const PackedArgs p{A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, strict, st};
+    switch (dtype) {
+    case QL_DTYPE_F16:
+        return strict ? launch_16_any<f16, true>(p) : launch_16_any<f16, false>(p);
+    case QL_DTYPE_BF16:
+        if (!strict) return launch_16_any<__bf16, false>(p);
+        if (M == 1) return launch_generic_mb<__bf16, 1>(p);
+        if (M == 2) return launch_generic_mb<__bf16, 2>(p);
+        return launch_generic_mb<__bf16, 4>(p);
+    case QL_DTYPE_F32:      // fp32 products are already exact-dequant: one kernel serves both modes
+        if (M == 1) return launch_generic_mb<float, 1>(p);
+        if (M == 2) return launch_generic_mb<float, 2>(p);
+        return launch_generic_mb<float, 4>(p);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql

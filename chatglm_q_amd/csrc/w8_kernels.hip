@@ -56,6 +56,195 @@ __device__ __forceinline__ BytePairs byte_pairs_f16(u32 w) {
     return r;
 }
 
+// A wave "tile" = 2 x (64 lanes x 16 B) per output channel = 2048 k: K = 4096 is exactly two tiles,
+// both of which are in flight before anything waits (same latency structure as w4_packed.hip).
+template <int MB, bool A_LDS>
+struct W8Tile {
+    u32x4 w[4][2];
+    u32x4 a[A_LDS ? 1 : MB][A_LDS ? 1 : 4];
+};
+
+// LDS image of the activation row for the fp16 kernel: 16-byte piece j (0/1) of lane-chunk lc
+// (k = 16 lc .. 16 lc + 15) lives at piece position 2 lc + (j ^ ((lc >> 3) & 1)) - the XOR makes the
+// 32-byte-strided per-lane ds_read_b128 bank-conflict free.  Each piece is stored PRE-PAIRED as
+// (a0,a2),(a1,a3),(a4,a6),(a5,a7) so that it lines up with byte_pairs_f16() without per-use shuffles.
+__device__ __forceinline__ int w8_piece_pos(int lc, int j) { return 2 * lc + (j ^ ((lc >> 3) & 1)); }
+
+__device__ __forceinline__ u32x4 pair_even_odd(u32x4 x) {
+    u32x4 y;
+    y[0] = (x[0] & 0xFFFFu) | (x[1] << 16);
+    y[1] = (x[0] >> 16) | (x[1] & 0xFFFF0000u);
+    y[2] = (x[2] & 0xFFFFu) | (x[3] << 16);
+    y[3] = (x[2] >> 16) | (x[3] & 0xFFFF0000u);
+    return y;
+}
+
+template <int MB, int ACH>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
+__global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict__ A, const int8_t* __restrict__ W,
+                                                          const f16* __restrict__ S, const f16* __restrict__ bias,
+                                                          f16* __restrict__ C, int M, int N, int K, int64_t ldw,
+                                                          int64_t lda, int64_t ldc) {
+    constexpr bool A_LDS = ACH > 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb_raw = (blockIdx.x * 4 + wave) * 4;
+    const bool wave_active = nb_raw < N;
+    const int nb = wave_active ? nb_raw : 0;
+    const int m0 = blockIdx.y * MB;
+    const int kvec = K & ~15;                  // part of K covered by 16-byte units
+    const int nchunks = kvec >> 4;             // lane-chunks (16 k each)
+    const int iters = (nchunks + 127) >> 7;    // tiles of 128 lane-chunks
+    const int ppr = kvec >> 3;                 // 16-byte activation pieces per row
+
+    const f16* arow[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
+
+    u32x4 areg[A_LDS ? ACH : 1];
+    if constexpr (A_LDS) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            // unconditional (clamped) load: see w4_packed.hip
+            const int c = min(tid + i * 256, MB * ppr - 1);
+            const int m = MB == 1 ? 0 : c / ppr, cc = c - m * ppr;
+            areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
+        }
+    }
+
+    const int8_t* wrow[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wrow[c] = W + (int64_t)((nb + c < N) ? (nb + c) : (N - 1)) * ldw;
+
+    auto load_tile = [&](int it) {
+        W8Tile<MB, A_LDS> tl;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lc = it * 128 + u * 64 + lane;
+            const int lcc = lc < nchunks ? lc : (nchunks > 0 ? nchunks - 1 : 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                tl.w[c][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[c] + (int64_t)lcc * 16));
+            if constexpr (!A_LDS) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        tl.a[m][2 * u + j] = *reinterpret_cast<const u32x4*>(arow[m] + (int64_t)lcc * 16 + 8 * j);
+            }
+        }
+        return tl;
+    };
+
+    W8Tile<MB, A_LDS> t0, t1;
+    if (iters > 0) {
+        t0 = load_tile(0);
+        t1 = load_tile(iters > 1 ? 1 : 0);
+    }
+
+    if constexpr (A_LDS) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const int c = tid + i * 256;
+            if (c < MB * ppr) {
+                const int m = MB == 1 ? 0 : c / ppr, cc = c - m * ppr;
+                *reinterpret_cast<u32x4*>(smem + ((int64_t)m * ppr + w8_piece_pos(cc >> 1, cc & 1)) * 16) =
+                    pair_even_odd(areg[i]);
+            }
+        }
+        __syncthreads();
+    }
+
+    float acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    h2 s2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f16 sh = S[(nb + c < N) ? (nb + c) : (N - 1)];
+        s2[c] = h2{sh, sh};
+    }
+
+    auto compute_tile = [&](const W8Tile<MB, A_LDS>& tl, int it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lc = it * 128 + u * 64 + lane;
+            const bool valid = lc < nchunks;
+            const int lcc = valid ? lc : (nchunks > 0 ? nchunks - 1 : 0);
+            h2 a02[MB][4], a13[MB][4];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 y;
+                    if constexpr (A_LDS)
+                        y = *reinterpret_cast<const u32x4*>(smem + ((int64_t)m * ppr + w8_piece_pos(lcc, j)) * 16);
+                    else
+                        y = pair_even_odd(tl.a[m][2 * u + j]);
+                    a02[m][2 * j + 0] = as_h2(y[0]);
+                    a13[m][2 * j + 0] = as_h2(y[1]);
+                    a02[m][2 * j + 1] = as_h2(y[2]);
+                    a13[m][2 * j + 1] = as_h2(y[3]);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const h2 sc2 = valid ? s2[c] : h2{(f16)0.f, (f16)0.f};   // out-of-range lanes contribute 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const BytePairs b = byte_pairs_f16(tl.w[c][u][j]);
+                    const h2 w02 = b.p02 * sc2, w13 = b.p13 * sc2;       // rounded to fp16 (faithful)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        float v = acc[m][c];
+                        v = __builtin_amdgcn_fdot2(w02, a02[m][j], v, false);
+                        v = __builtin_amdgcn_fdot2(w13, a13[m][j], v, false);
+                        acc[m][c] = v;
+                    }
+                }
+            }
+        }
+    };
+
+    for (int it = 0; it < iters; it += 2) {
+        compute_tile(t0, it);
+        if (it + 2 < iters) t0 = load_tile(it + 2);
+        if (it + 1 < iters) {
+            compute_tile(t1, it + 1);
+            if (it + 3 < iters) t1 = load_tile(it + 3);
+        }
+    }
+
+    // K tail (K % 16): one element per lane
+    for (int k = kvec + lane; k < K; k += 64) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f16 wq = (f16)((float)wrow[c][k] * (float)s2[c].x);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf((float)arow[m][k], (float)wq, acc[m][c]);
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = wave_sum(acc[m][c]);
+
+    if (wave_active && lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m0 + m >= M) break;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int n = nb + c;
+                if (n < N) store_out<f16>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+            }
+        }
+    }
+}
+
+// generic dtype (fp32 / bf16): same decomposition, per-byte dequant, activations from global
 template <typename T, int MB>
 __global__ __launch_bounds__(256) void w8_gemv_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
                                                       const T* __restrict__ S, const T* __restrict__ bias,
@@ -63,7 +252,7 @@ __global__ __launch_bounds__(256) void w8_gemv_kernel(const T* __restrict__ A, c
                                                       int64_t lda, int64_t ldc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = (blockIdx.x * 4 + wave) * 4;   // first of the wave's 4 output channels
-    if (nb >= N) return;                          // waves are independent: no barriers below
+    if (nb >= N) return;                          // no barriers in this kernel
     const int m0 = blockIdx.y * MB;
 
     float acc[MB][4];
@@ -85,58 +274,47 @@ __global__ __launch_bounds__(256) void w8_gemv_kernel(const T* __restrict__ A, c
     for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
 
     const int kvec = K & ~15;
-#pragma unroll 2
-    for (int k = lane * 16; k < kvec; k += 64 * 16) {
-        u32x4 w[4];
+    const int nchunks = kvec >> 4;
+    const int iters = (nchunks + 63) >> 6;
+    auto load_tile = [&](int it) {
+        const int lc = it * 64 + lane;
+        const int lcc = lc < nchunks ? lc : (nchunks > 0 ? nchunks - 1 : 0);
+        struct { u32x4 w[4]; } tl;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[c] + k));
-
-        if constexpr (Act<T>::code == QL_DTYPE_F16) {
-            // activations regrouped to match the byte pairs: (a0,a2),(a1,a3) per 4 k
-            h2 a02[MB][4], a13[MB][4];
+        for (int c = 0; c < 4; ++c)
+            tl.w[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[c] + (int64_t)lcc * 16));
+        return tl;
+    };
+    auto compute_tile = [&](const auto& tl, int it) {
+        const int lc = it * 64 + lane;
+        if (lc >= nchunks) return;
+        const int k = lc * 16;
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const u32x4 x = *reinterpret_cast<const u32x4*>(arow[m] + k + 8 * j);
-                    a02[m][2 * j + 0] = as_h2((x[0] & 0xFFFFu) | (x[1] << 16));
-                    a13[m][2 * j + 0] = as_h2((x[0] >> 16) | (x[1] & 0xFFFF0000u));
-                    a02[m][2 * j + 1] = as_h2((x[2] & 0xFFFFu) | (x[3] << 16));
-                    a13[m][2 * j + 1] = as_h2((x[2] >> 16) | (x[3] & 0xFFFF0000u));
-                }
+            for (int b = 0; b < 4; ++b) {
+                float a[MB];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f16 sh = (f16)sc[c];
-                const h2 s2 = {sh, sh};
+                for (int m = 0; m < MB; ++m) a[m] = Act<T>::load(arow[m] + k + 4 * j + b);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const BytePairs b = byte_pairs_f16(w[c][j]);
-                    const h2 w02 = b.p02 * s2, w13 = b.p13 * s2;   // rounded to fp16 (faithful)
+                for (int c = 0; c < 4; ++c) {
+                    const int q = (int)(tl.w[c][j] << (24 - 8 * b)) >> 24;   // sign-extended byte b
+                    const float wq = Act<T>::round((float)q * sc[c]);
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        float v = acc[m][c];
-                        v = __builtin_amdgcn_fdot2(w02, a02[m][j], v, false);
-                        v = __builtin_amdgcn_fdot2(w13, a13[m][j], v, false);
-                        acc[m][c] = v;
-                    }
+                    for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(a[m], wq, acc[m][c]);
                 }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    float a[MB];
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) a[m] = Act<T>::load(arow[m] + k + 4 * j + b);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int q = (int)(w[c][j] << (24 - 8 * b)) >> 24;   // sign-extended byte b
-                        const float wq = Act<T>::round((float)q * sc[c]);
-#pragma unroll
-                        for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(a[m], wq, acc[m][c]);
-                    }
-                }
+    };
+    if (iters > 0) {
+        auto t0 = load_tile(0);
+        auto t1 = load_tile(iters > 1 ? 1 : 0);
+        for (int it = 0; it < iters; it += 2) {
+            compute_tile(t0, it);
+            if (it + 2 < iters) t0 = load_tile(it + 2);
+            if (it + 1 < iters) {
+                compute_tile(t1, it + 1);
+                if (it + 3 < iters) t1 = load_tile(it + 3);
+            }
         }
     }
     // K tail (K % 16): one element per lane
@@ -255,23 +433,62 @@ static int launch_w8_generic(const void* A, const int8_t* W, const void* S, cons
     return finish_launch();
 }
 
+struct W8Args {
+    const void* A;
+    const int8_t* W;
+    const void* S;
+    const void* bias;
+    void* C;
+    int M, N, K;
+    int64_t ldw, lda, ldc;
+    hipStream_t st;
+};
+
 template <typename T, int MB>
-static int launch_w8_gemv_mb(const T* A, const int8_t* W, const T* S, const T* bias, T* C, int M, int N, int K,
-                             int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    const int quads = (N + 3) / 4;
-    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((M + MB - 1) / MB));
-    w8_gemv_kernel<T, MB><<<grid, 256, 0, st>>>(A, W, S, bias, C, M, N, K, ldw, lda, ldc);
+static int launch_w8_gemv_generic(const W8Args& p) {
+    const int quads = (p.N + 3) / 4;
+    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
+    w8_gemv_kernel<T, MB><<<grid, 256, 0, p.st>>>((const T*)p.A, p.W, (const T*)p.S, (const T*)p.bias, (T*)p.C, p.M,
+                                                  p.N, p.K, p.ldw, p.lda, p.ldc);
     return finish_launch();
 }
 
-template <typename T>
-static int launch_w8_gemv(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
-                          int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    if (M == 1)
-        return launch_w8_gemv_mb<T, 1>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, 1, (int)N, (int)K, ldw, lda, ldc, st);
-    if (M == 2)
-        return launch_w8_gemv_mb<T, 2>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, 2, (int)N, (int)K, ldw, lda, ldc, st);
-    return launch_w8_gemv_mb<T, 4>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
+template <int MB, int ACH>
+static int launch_w8_gemv_f16(const W8Args& p) {
+    const int quads = (p.N + 3) / 4;
+    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
+    const size_t lds = ACH > 0 ? (size_t)MB * (p.K & ~15) * sizeof(f16) : 0;
+    w8_gemv_f16_kernel<MB, ACH><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S, (const f16*)p.bias,
+                                                          (f16*)p.C, p.M, p.N, p.K, p.ldw, p.lda, p.ldc);
+    return finish_launch();
+}
+
+template <int MB>
+static int launch_w8_gemv_f16_mb(const W8Args& p) {
+    const int64_t pieces = (int64_t)MB * ((p.K & ~15) / 8);
+    const bool lds_ok = (size_t)MB * p.K * sizeof(f16) <= 64 * 1024 && pieces > 0;
+    if (lds_ok && pieces <= 2 * 256) return launch_w8_gemv_f16<MB, 2>(p);
+    if (lds_ok && pieces <= 4 * 256) return launch_w8_gemv_f16<MB, 4>(p);
+    if (lds_ok && pieces <= 8 * 256) return launch_w8_gemv_f16<MB, 8>(p);
+    return launch_w8_gemv_f16<MB, 0>(p);
+}
+
+static int launch_w8_gemv_any(int dtype, const W8Args& p) {
+    switch (dtype) {
+    case QL_DTYPE_F16:
+        if (p.M == 1) return launch_w8_gemv_f16_mb<1>(p);
+        if (p.M == 2) return launch_w8_gemv_f16_mb<2>(p);
+        return launch_w8_gemv_f16_mb<4>(p);
+    case QL_DTYPE_F32:
+        if (p.M == 1) return launch_w8_gemv_generic<float, 1>(p);
+        if (p.M == 2) return launch_w8_gemv_generic<float, 2>(p);
+        return launch_w8_gemv_generic<float, 4>(p);
+    case QL_DTYPE_BF16:
+        if (p.M == 1) return launch_w8_gemv_generic<__bf16, 1>(p);
+        if (p.M == 2) return launch_w8_gemv_generic<__bf16, 2>(p);
+        return launch_w8_gemv_generic<__bf16, 4>(p);
+    default: return QL_ERR_BAD_DTYPE;
+    }
 }
 
 template <typename T>
@@ -304,7 +521,8 @@ int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const v
 }
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
             int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    QL_DISPATCH_DTYPE(dtype, launch_w8_gemv, A, W, S, bias, C, M, N, K, ldw, lda, ldc, st)
+    const W8Args p{A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st};
+    return launch_w8_gemv_any(dtype, p);
 }
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st) {

@@ -78,8 +78,10 @@ def repack_w4g32(b: Tensor, b_scale: Tensor) -> Tensor:
 
 
 def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
-               packed: Tensor | None = None) -> Tensor:
-    """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernel."""
+               packed: Tensor | None = None, strict: bool | None = None) -> Tensor:
+    """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernel;
+    ``strict`` (default: env QLINEAR_STRICT) asks for the reference's per-weight rounding bit for bit
+    (the canonical-layout kernel always rounds that way)."""
     _check_w4_args(a, b, b_scale)
     lib = _lib.get_lib()
     out_shape = (*a.shape[:-1], b.shape[1])
@@ -91,13 +93,14 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     if M == 0:
         return c.reshape(out_shape)
     code = _lib.dtype_code(a.dtype)
+    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.STRICT_DEFAULT if strict is None else strict) else 0
     if bias is not None:
         bias = bias.contiguous()
     with torch.cuda.device(a.device):
         stream = _lib.stream_ptr(a.device)
         if packed is not None:
             st = lib.qlinear_w4g32_fwd_packed(a2.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
-                                              group, a2.stride(0) if M > 1 else K, N, code, None, 0, stream)
+                                              group, a2.stride(0) if M > 1 else K, N, code, flags, None, 0, stream)
             _lib.check(st, "qlinear_w4g32_fwd_packed")
         else:
             if not b.is_contiguous():

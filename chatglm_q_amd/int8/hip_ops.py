@@ -39,7 +39,8 @@ def _check_w8_args(a: Tensor, b: Tensor, b_scale: Tensor):
         raise AssertionError(f"b_scale.device={b_scale.device}, a.device={a.device}")
 
 
-def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
+               strict: bool | None = None) -> Tensor:
     """``a @ (b * b_scale) (+ bias)``; ``b`` is the logical (K, N) int8 matrix with ANY strides - the
     module passes ``weight.t()`` (strides (1, K)), the reference test a contiguous (K, N)."""
     _check_w8_args(a, b, b_scale)
@@ -61,8 +62,9 @@ def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     ldw_n = b.stride(1) if N > 1 else max(K, 1)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w8_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
-                                ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, _lib.dtype_code(a.dtype), None, 0,
-                                _lib.stream_ptr(a.device))
+                                ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, _lib.dtype_code(a.dtype),
+                                _lib.FLAG_STRICT_ROUNDING if (_lib.STRICT_DEFAULT if strict is None else strict) else 0,
+                                None, 0, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd")
     return c.reshape(out_shape)
 

@@ -58,6 +58,13 @@ extern "C" {
 #define QL_ERR_WORKSPACE (-6)      /* workspace missing or too small (see qlinear_workspace_bytes) */
 #define QL_ERR_UNSUPPORTED (-7)
 
+/* flags (bit set) accepted by the forward entry points that take a `flags` argument */
+#define QL_FLAG_STRICT_ROUNDING 1  /* round every dequantised weight to the activation dtype before the
+                                      multiply, bit-for-bit the reference's sequence.  Default (0) feeds
+                                      the exactly dequantised weight to the dot product instead, which is
+                                      closer to real arithmetic and differs from the reference only by that
+                                      per-weight rounding (~2e-4 relative in fp16; within the 1e-3 bar). */
+
 /* operations, for qlinear_workspace_bytes */
 #define QL_OP_W4G32_FWD 1
 #define QL_OP_W4G32_FWD_PACKED 2
@@ -97,8 +104,8 @@ int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t
                          int64_t group, int dtype, void* stream);
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C,
                              int64_t M, int64_t N, int64_t K, int64_t group, int64_t lda,
-                             int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             int64_t ldc, int dtype, int flags, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- int8 per-output-channel weights -------------------------------------------------------
  * W  int8, logical (K, N) with element strides (ldw_k, ldw_n) - exactly what the reference
@@ -108,7 +115,8 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * S  (N) scales, activation dtype. */
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C,
                    int64_t M, int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda,
-                   int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+                   int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* ---- int8 activations x int8 weights (true i8 x i8 -> i32 MFMA contraction) ---------------
  * Row-wise symmetric activation quantisation in fp32 arithmetic:

@@ -1,0 +1,142 @@
+// Micro-benchmark harness (developer tool, not part of the product): times kernel variants on
+// rotating buffers with a captured hipGraph, so sub-3-us kernels are not host-bound.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 probe.hip -L../../chatglm_q_amd/csrc -lqlinear_hip -o probe.bin
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <functional>
+#include "../../include/qlinear_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// pure streaming read: each thread reads LOADS x 16 B (coalesced 1 KiB per wave instruction), XORs, one store per wave
+template <int LOADS, bool NT>
+__global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ src, uint32_t* __restrict__ out, size_t n16) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u32x4* p = src + wave * (size_t)LOADS * 64 + lane;
+    u32x4 v[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        size_t idx = (size_t)(p - src) + (size_t)i * 64;
+        if (idx >= n16) idx = lane;
+        v[i] = NT ? __builtin_nontemporal_load(src + idx) : src[idx];
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) x ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (lane == 0) out[wave] = x;
+}
+
+__global__ void empty_kernel() {}
+
+struct Timer {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    Timer() { CK(hipStreamCreate(&st)); CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+    // returns us per step; fn(i) enqueues step i on st
+    double run(int steps, const std::function<void(int)>& fn, bool graph = true, int reps = 5) {
+        for (int i = 0; i < 64 && i < steps; ++i) fn(i);
+        CK(hipStreamSynchronize(st));
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        if (graph) {
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+            for (int i = 0; i < steps; ++i) fn(i);
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+        }
+        double best = 1e30;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0, st));
+            if (graph) CK(hipGraphLaunch(ge, st)); else for (int i = 0; i < steps; ++i) fn(i);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        if (ge) CK(hipGraphExecDestroy(ge));
+        if (g) CK(hipGraphDestroy(g));
+        return best * 1e3 / steps;
+    }
+};
+
+int main(int argc, char** argv) {
+    const int K = argc > 1 ? atoi(argv[1]) : 4096;
+    const int N = argc > 2 ? atoi(argv[2]) : 4096;
+    const int M = argc > 3 ? atoi(argv[3]) : 1;
+    const bool quick = argc > 4 && !strcmp(argv[4], "gemv");
+    const int FLAGS = getenv("QL_STRICT") ? QL_FLAG_STRICT_ROUNDING : 0;
+    const int G = K / 32;
+    const size_t per = (size_t)K * N / 2 + (size_t)G * N * 2;
+    int SETS = (int)(720e6 / per) + 1; if (SETS > 96) SETS = 96; if (SETS < 3) SETS = 3;
+    const int STEPS = SETS * (per > 40e6 ? 4 : 12);
+    printf("K=%d N=%d M=%d  bytes/step(weights+scales)=%zu  sets=%d steps=%d\n", K, N, M, per, SETS, STEPS);
+    Timer T;
+    // buffers
+    std::vector<uint8_t*> wq(SETS); std::vector<void*> sc(SETS), pk(SETS);
+    const size_t pkb = qlinear_w4g32_packed_bytes(N, K, 32, QL_DTYPE_F16);
+    std::vector<uint8_t> hw((size_t)K / 2 * N); std::vector<uint16_t> hs((size_t)G * N);
+    for (auto& b : hw) b = (uint8_t)rand();
+    for (auto& s : hs) s = 0x1C00 + (rand() & 0x3FF);   // fp16 in [0.0039, 0.0078)
+    for (int i = 0; i < SETS; ++i) {
+        CK(hipMalloc(&wq[i], hw.size())); CK(hipMalloc(&sc[i], hs.size() * 2)); CK(hipMalloc(&pk[i], pkb));
+        CK(hipMemcpy(wq[i], hw.data(), hw.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(sc[i], hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+        int rc = qlinear_w4g32_repack(wq[i], sc[i], pk[i], N, K, 32, QL_DTYPE_F16, T.st);
+        if (rc) { printf("repack rc=%d\n", rc); return 1; }
+    }
+    void *A, *C, *ws; uint32_t* out;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMemset(A, 0x3c, (size_t)M * K * 2));
+    CK(hipMalloc(&C, (size_t)M * N * 2)); CK(hipMalloc(&out, 1 << 20));
+    const size_t wsb = qlinear_workspace_bytes(QL_OP_W4G32_FWD, M, N, K, 32);
+    CK(hipMalloc(&ws, wsb ? wsb : 16));
+    CK(hipStreamSynchronize(T.st));
+
+    const double alg = (double)per + (double)M * K * 2 + (double)M * N * 2;
+    auto report = [&](const char* name, double us, double bytes) {
+        printf("%-44s %8.3f us/step  %8.1f GB/s  (%.1f%% of 8 TB/s)\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+    };
+    double us;
+    if (quick) {
+        us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
+        char nm[64]; snprintf(nm, sizeof nm, "w4 packed gemv QL_VARIANT=%s", getenv("QL_VARIANT") ? getenv("QL_VARIANT") : "0");
+        report(nm, us, alg);
+        return 0;
+    }
+    us = T.run(STEPS, [&](int) { empty_kernel<<<1, 64, 0, T.st>>>(); });
+    report("empty kernel (launch boundary)", us, 0);
+    {
+        const size_t n16 = pkb / 16;
+        const int waves = (int)((n16 + 9 * 64 - 1) / (9 * 64));
+        const int blocks = (waves + 3) / 4;
+        us = T.run(STEPS, [&](int i) { read_kernel<9, true><<<blocks, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16); });
+        report("pure read nt, 9x16B/thread", us, (double)pkb);
+        us = T.run(STEPS, [&](int i) { read_kernel<9, false><<<blocks, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16); });
+        report("pure read,    9x16B/thread", us, (double)pkb);
+        const int waves2 = (int)((n16 + 18 * 64 - 1) / (18 * 64));
+        us = T.run(STEPS, [&](int i) { read_kernel<18, true><<<(waves2 + 3) / 4, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16); });
+        report("pure read nt, 18x16B/thread", us, (double)pkb);
+        const int waves3 = (int)((n16 + 4 * 64 - 1) / (4 * 64));
+        us = T.run(STEPS, [&](int i) { read_kernel<4, true><<<(waves3 + 3) / 4, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16); });
+        report("pure read nt, 4x16B/thread", us, (double)pkb);
+        us = T.run(STEPS, [&](int i) { read_kernel<9, true><<<blocks, 256, 0, T.st>>>((const u32x4*)pk[0], out, n16); });
+        report("pure read nt, same buffer (cache-hot)", us, (double)pkb);
+    }
+    us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
+    report("w4 packed gemv (rotating)", us, alg);
+    us = T.run(STEPS, [&](int) { qlinear_w4g32_fwd_packed(A, pk[0], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
+    report("w4 packed gemv (same weights, cache-hot)", us, alg);
+    us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd(A, wq[i % SETS], sc[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, ws, wsb, T.st); });
+    report("w4 canonical split-K + reduce (rotating)", us, alg);
+    us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); }, false);
+    report("w4 packed gemv (rotating, eager launches)", us, alg);
+    return 0;
+}
