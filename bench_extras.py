@@ -143,11 +143,35 @@ def w8a8_config3(torch, device):
             "frac_of_i8_mfma_peak": round(ops / (ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, 4)}
 
 
+def prefill_gemm(torch, device):
+    """BASELINE config 5 building block: int4g32 GEMM with M = 8192 rows (seq 2048 x batch 4) per layer shape,
+    fp16 MFMA with in-register dequant (reference rounding sequence)."""
+    gen = torch.Generator(device=device).manual_seed(17)
+    M = 8192
+    out = {}
+    for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 4096, 27392), ("w_out", 13696, 4096)]:
+        layer = _w4_layer(torch, device, K, N, False, gen)
+        x = torch.randn(M, K, device=device, dtype=torch.float16)
+
+        def fn():
+            with torch.no_grad():
+                layer(x)
+
+        ms = _graph_time(torch, device, fn)
+        flops = 2.0 * M * N * K
+        out[name] = {"M": M, "K": K, "N": N, "ms": round(ms, 4), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
+                     "frac_of_2.5PF_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 4)}
+        del layer, x
+        torch.cuda.empty_cache()
+    return out
+
+
 def run(torch, device):
     out = {}
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
-                     ("w8a8_config3", w8a8_config3)]:
+                     ("w8a8_config3", w8a8_config3),
+                     ("prefill_gemm_M8192", prefill_gemm)]:
         try:
             out[name] = fn(torch, device)
         except Exception as e:      # keep going: extras are informative only

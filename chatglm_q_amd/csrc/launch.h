@@ -22,6 +22,10 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, hipStream_t st);
 
+// w4_gemm.hip (M > 4, fp16 / bf16, MFMA)
+int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
+
 // w8_kernels.hip
 int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);

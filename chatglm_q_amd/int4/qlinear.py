@@ -31,7 +31,8 @@ KERNEL_IMPL = "hip" if _lib.available() else "none"
 if KERNEL_IMPL == "none":
     print("libqlinear_hip.so not found: GPU tensors will raise; CPU tensors use the dense torch formula.")
 
-# Largest row count served by the derived-layout GEMV kernel; above it the canonical kernel runs.
+# fp32 activations: largest row count served by the derived-layout GEMV kernel (above it the canonical
+# kernel runs).  fp16 / bf16 use the derived layout for every row count (GEMV up to 4 rows, MFMA GEMM above).
 PACKED_MAX_ROWS = int(os.environ.get("QLINEAR_PACKED_MAX_ROWS", "4"))
 # "auto" (packed for decode shapes), "canonical" (never repack) - for A/B measurements.
 W4_LAYOUT = os.environ.get("QLINEAR_W4_LAYOUT", "auto")
@@ -136,7 +137,7 @@ class DynamicQuantizeLinear(nn.Module):
                 return out
             rows = input.numel() // max(input.shape[-1], 1)
             packed = None
-            if rows <= PACKED_MAX_ROWS and self._packed_supported():
+            if (rows <= PACKED_MAX_ROWS or input.dtype in (torch.float16, torch.bfloat16)) and self._packed_supported():
                 self.prepare()
                 packed = self._packed
             # bias is added inside the kernel epilogue AFTER the rounding to the output dtype,

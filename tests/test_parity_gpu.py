@@ -69,8 +69,9 @@ def test_int4_golden(entry, layout):
         packed = h4.repack_w4g32(qw, sc)
         outs = []
         a2 = a.reshape(-1, a.shape[-1])
-        for m0 in range(0, a2.shape[0], 4):          # the packed GEMV serves <= 4 rows per call
-            outs.append(h4.w4_forward(a2[m0:m0 + 4], qw, sc, bias, packed, strict=layout.endswith("strict")))
+        step = a2.shape[0] if dt != "f32" else 4     # fp32: the packed GEMV serves <= 4 rows per call
+        for m0 in range(0, a2.shape[0], step):
+            outs.append(h4.w4_forward(a2[m0:m0 + step], qw, sc, bias, packed, strict=layout.endswith("strict")))
         out = torch.cat(outs).reshape(*a.shape[:-1], -1)
     else:
         out = h4.w4_forward(a, qw, sc, bias)
@@ -119,6 +120,12 @@ W4_SHAPES = [
     (33, 512, 384, "f16", False),
     (1, 4096, 4096, "bf16", False),
     (4, 1024, 512, "bf16", True),
+    (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
+    (200, 1024, 640, "f16", False),     # MT = 4, ragged M (200 = 128 + 72)
+    (129, 96, 136, "f16", True),        # odd group count (3): half-empty last K step; ragged N
+    (2048, 4096, 256, "f16", False),    # prefill-sized M
+    (70, 13696, 128, "bf16", True),     # bf16 MFMA, K = 13696
+    (40, 512, 264, "bf16", False),
     (1, 4096, 4096, "f32", False),
     (7, 1024, 264, "f32", True),
     (2, 64, 36, "f16", True),           # N % 8 != 0 -> generic kernel / packed padding
@@ -139,11 +146,12 @@ def test_int4_vs_oracle(M, K, N, dt, has_bias, layout):
     if layout.startswith("packed"):
         packed = h4.repack_w4g32(qd, sd)
         strict = layout.endswith("strict")
-        out = torch.cat([h4.w4_forward(ad[m0:m0 + 4], qd, sd, bd, packed, strict=strict) for m0 in range(0, M, 4)])
+        step = M if dt != "f32" else 4               # fp16 / bf16: one call (GEMV <= 4 rows, MFMA GEMM above)
+        out = torch.cat([h4.w4_forward(ad[m0:m0 + step], qd, sd, bd, packed, strict=strict) for m0 in range(0, M, step)])
     else:
         out = h4.w4_forward(ad, qd, sd, bd)
     assert_close(out, ref, dt, f"{M}x{K}x{N}")
-    if layout != "packed" and dt == "f16":
+    if (layout != "packed" or M > 4) and dt == "f16":
         # the reference's rounding sequence reproduced: only fp32 summation-order noise is left, which
         # flips an output's fp16 rounding now and then - an order of magnitude below the 1e-3 bar
         assert O.rel_l2(t2n(out), ref) <= 1.5e-4, O.rel_l2(t2n(out), ref)
