@@ -166,12 +166,80 @@ def prefill_gemm(torch, device):
     return out
 
 
+def _chatglm2_6b(torch, device, dtype, seed=0):
+    from chatglm_q_amd import model as M
+    cfg = M.ChatGLM2Config()
+    prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    with torch.device(device):
+        m = M.create_quant_int4_model(cfg, dtype=dtype)
+    M.fill_synthetic_(m, seed)
+    return m.eval(), cfg
+
+
+LINEAR_BYTES_PER_TOKEN = 3362254848       # QLinear bytes touched per decoded token
+
+
+def e2e_generate(torch, device):
+    """BASELINE config 4: ChatGLM2-6B int4g32 (synthetic weights), batch 1, prompt 32 ids, 128 generated tokens,
+    greedy, EOS ignored.  Timing definitions of the reference (chatglm_q/decoder.py:99-106)."""
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    model, cfg = _chatglm2_6b(torch, device, torch.float16)
+    for mod in model.modules():
+        if hasattr(mod, "prepare"):
+            mod.prepare()
+    prompt = [(37 * i + 11) % cfg.vocab_size for i in range(32)]
+    dec = ChatGLMDecoder(None, model)
+    out = {}
+    for label, kw in [("graph_sync_every_token", dict(use_graph=True, sync_every_token=True)),
+                      ("graph_device_loop", dict(use_graph=True, sync_every_token=False)),
+                      ("eager", dict(use_graph=False))]:
+        n = 128 if label != "eager" else 32
+        toks = list(dec.generate_ids(prompt, max_generated_tokens=n, greedy=True, ignore_eos=True, **kw))
+        s = dec.last_stats
+        out[label] = {"generated": len(toks), "prefill_s": round(s["init_s"], 4),
+                      "gen_tok_per_s": round(s["gen_tok_per_s"], 1), "avg_tok_per_s": round(s["avg_tok_per_s"], 1),
+                      "linear_GBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 1e9, 1),
+                      "linear_frac_of_8TBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 8e12, 4)}
+    out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, greedy, fp16, synthetic weights"
+    # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 512 positions (M = 2048 rows per forward)
+    from chatglm_q_amd.decoder import DecodeSession
+    B, S, CH = 4, 2048, 512
+    ids = torch.randint(0, cfg.vocab_size, (B, S), device=device)
+    sess = DecodeSession(model, B, S, use_graph=False)
+    sess.prefill(ids[:, :CH], CH)                               # warm-up (lazy layouts, allocator)
+    torch.cuda.synchronize()
+    sess = DecodeSession(model, B, S, use_graph=False)
+    t0 = time.perf_counter()
+    sess.prefill(ids, CH)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lin_flops = 2.0 * B * S * (4096 * 4608 + 4096 * 4096 + 4096 * 27392 + 13696 * 4096) * 28
+    out["chunked_prefill_seq2048_batch4"] = {
+        "chunk": CH, "seconds": round(dt, 4), "tokens_per_s": round(B * S / dt, 1),
+        "linear_TFLOPs_if_all_time_were_linear": round(lin_flops / dt / 1e12, 1),
+        "note": "whole forward incl. plain-torch attention (O(S^2) fp32 softmax) and norms; lm_head for the last position only"}
+    del model, sess
+    torch.cuda.empty_cache()
+    return out
+
+
+def e2e_cpu(torch, device):
+    """Same harness on the host CPU (reference-formula CPU branch of the modules), bounded: 4-token prompt, 2 decode steps."""
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    model, cfg = _chatglm2_6b(torch, torch.device("cpu"), torch.float32)
+    dec = ChatGLMDecoder(None, model)
+    toks = list(dec.generate_ids([11, 48, 85, 122], max_generated_tokens=3, greedy=True, ignore_eos=True, use_graph=False))
+    s = dec.last_stats
+    return {"workload": "same model and loop on the host CPU, fp32, 4-token prompt + 3 tokens", "threads": torch.get_num_threads(),
+            "generated": len(toks), "prefill_s": round(s["init_s"], 2), "gen_tok_per_s": round(s["gen_tok_per_s"], 4)}
+
+
 def run(torch, device):
     out = {}
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
-                     ("prefill_gemm_M8192", prefill_gemm)]:
+                     ("prefill_gemm_M8192", prefill_gemm), ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)
         except Exception as e:      # keep going: extras are informative only

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 import torch
 
@@ -49,6 +49,12 @@ EXPORTS = {
                                       c_int, c_void_p]),
     "qlinear_qembedding_w8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                       c_void_p]),
+    "qlinear_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_int,
+                                c_void_p]),
+    "qlinear_add_rmsnorm": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
+    "qlinear_rope_kv_write": (c_int, [c_void_p] * 7 + [c_int64] * 7 + [c_int, c_void_p]),
+    "qlinear_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_void_p]),
+    "qlinear_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 
 

@@ -137,7 +137,7 @@ int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, co
     if (!Aq || !a_scale || !W || !S || !C) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
-    if (K % 32 != 0) return QL_ERR_UNSUPPORTED;
+    if (K % 16 != 0) return QL_ERR_UNSUPPORTED;     /* rows are read in 16-byte units */
     if (!aligned(Aq, 16) || !aligned(W, 16)) return QL_ERR_MISALIGNED;
     return w8a8_gemm(dtype, Aq, a_scale, W, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
 }
@@ -157,6 +157,64 @@ int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, vo
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(count) || !fits_i32(V) || !fits_i32(D)) return QL_ERR_BAD_SHAPE;
     return qembedding_w8(dtype, ids, W, S, out, count, V, D, (hipStream_t)stream);
+}
+
+int qlinear_rmsnorm(const void* X, const void* W, void* Out, int64_t rows, int64_t dim, int64_t ldx, int64_t ldo,
+                    float eps, int dtype, void* stream) {
+    if (!X || !W || !Out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(rows) || !fits_i32(dim) || ldx < dim || ldo < dim || dim % 8 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(X, 16) || !aligned(W, 16) || !aligned(Out, 16) || (ldx * esize(dtype)) % 16 || (ldo * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return rmsnorm(dtype, X, nullptr, W, nullptr, Out, rows, dim, ldx, ldo, eps, (hipStream_t)stream);
+}
+
+int qlinear_add_rmsnorm(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows,
+                        int64_t dim, int64_t ld, float eps, int dtype, void* stream) {
+    if (!X || !Delta || !W || !Hout || !Out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(rows) || !fits_i32(dim) || ld < dim || dim % 8 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(X, 16) || !aligned(Delta, 16) || !aligned(W, 16) || !aligned(Hout, 16) || !aligned(Out, 16) ||
+        (ld * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return rmsnorm(dtype, X, Delta, W, Hout, Out, rows, dim, ld, ld, eps, (hipStream_t)stream);
+}
+
+int qlinear_rope_kv_write(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Qout,
+                          void* Kcache, void* Vcache, int64_t B, int64_t S, int64_t H, int64_t G, int64_t D,
+                          int64_t capacity, int64_t ldqkv, int dtype, void* stream) {
+    if (!QKV || !table || !pos || !widx || !Qout || !Kcache || !Vcache) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(B) || !fits_i32(S) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) ||
+        (D % 8) || H % G != 0 || ldqkv < (H + 2 * G) * D)
+        return QL_ERR_BAD_SHAPE;
+    if (!aligned(QKV, 16) || !aligned(table, 16) || !aligned(Qout, 16) || !aligned(Kcache, 16) || !aligned(Vcache, 16) ||
+        (ldqkv * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return rope_kv_write(dtype, QKV, table, pos, widx, Qout, Kcache, Vcache, B, S, H, G, D, capacity, ldqkv,
+                         (hipStream_t)stream);
+}
+
+int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, void* Out,
+                             int64_t B, int64_t H, int64_t G, int64_t D, int64_t capacity, int dtype, void* stream) {
+    if (!Q || !Kcache || !Vcache || !mask || !Out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(B) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) || H % G != 0)
+        return QL_ERR_BAD_SHAPE;
+    if ((D != 128 && D != 64 && D != 32) || (capacity + 33 * D + 8) * 4 > 64 * 1024) return QL_ERR_UNSUPPORTED;
+    if (!aligned(Kcache, 16) || !aligned(Vcache, 16)) return QL_ERR_MISALIGNED;
+    return decode_attention(dtype, Q, Kcache, Vcache, mask, Out, B, H, G, D, capacity, (hipStream_t)stream);
+}
+
+int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
+                     void* stream) {
+    if (!In || !Out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(rows) || !fits_i32(hidden) || ldin < 2 * hidden || ldo < hidden || hidden % 8 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(In, 16) || !aligned(Out, 16) || (ldin * esize(dtype)) % 16 || (ldo * esize(dtype)) % 16 ||
+        (hidden * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return silu_mul(dtype, In, Out, rows, hidden, ldin, ldo, (hipStream_t)stream);
 }
 
 }  // extern "C"

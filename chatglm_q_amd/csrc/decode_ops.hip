@@ -1,0 +1,343 @@
+// Fused neighbours of the QLinear calls inside one decode step, gfx950.
+//
+// Once the 113 QLinear launches of a token run near the HBM rate, the ~50 tiny elementwise / reduction
+// launches per layer that torch issues around them dominate a decode step (each costs the ~1.5 us
+// dependent-launch boundary).  These four kernels replace them one-for-one with the SAME rounding
+// sequence the model graph defines (chatglm_q/model.py lines cited per kernel; every intermediate the
+// reference materialises in the activation dtype is rounded to it here too):
+//   rmsnorm            chatglm_q/model.py:62-73
+//   rope_kv_write      chatglm_q/model.py:139-155 (split, rotary on the first half of each head, cache write)
+//   decode_attention   chatglm_q/model.py:157-175 (q / sqrt(d), q k^T, + mask, fp32 softmax, p v)
+//   silu_mul           chatglm_q/model.py:200-201
+// All are HBM/latency-bound row kernels: one 256-thread block per row / per head, 16-byte accesses.
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+
+// 8 consecutive activations <-> fp32 (one 16-byte access for the 16-bit dtypes)
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            T lo, hi;
+            const uint16_t l16 = (uint16_t)(r[e] & 0xFFFFu), h16 = (uint16_t)(r[e] >> 16);
+            __builtin_memcpy(&lo, &l16, 2);
+            __builtin_memcpy(&hi, &h16, 2);
+            v[2 * e] = (float)lo;
+            v[2 * e + 1] = (float)hi;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Act<T>::load(p + e);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const T lo = (T)v[2 * e], hi = (T)v[2 * e + 1];
+            uint16_t l16, h16;
+            __builtin_memcpy(&l16, &lo, 2);
+            __builtin_memcpy(&h16, &hi, 2);
+            r[e] = (u32)l16 | ((u32)h16 << 16);
+        }
+        *reinterpret_cast<u32x4*>(p) = r;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Act<T>::store(p + e, v[e]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = round(round(x * rsqrt(mean(x^2) + eps)) * w)        (+ optional residual stream update)
+//   FUSE_ADD: x = round(x_in + delta) is written back to Hout first (the block's residual add,
+//   chatglm_q/model.py:243,245) and normalised in the same pass: one launch instead of two.
+// Row kept in registers (VPT x 8 values per thread): one read of the row, one barrier pair.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VPT, bool FUSE_ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, const T* __restrict__ Delta,
+                                                      const T* __restrict__ Wt, T* __restrict__ Hout, T* __restrict__ Out,
+                                                      int dim, int64_t ldx, int64_t ldo, float eps) {
+    __shared__ float red[4];
+    const T* x = X + (int64_t)blockIdx.x * ldx;
+    T* o = Out + (int64_t)blockIdx.x * ldo;
+    float v[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = (threadIdx.x + u * 256) * 8;
+        if (i < dim) {
+            load8<T>(x + i, v[u]);
+            if constexpr (FUSE_ADD) {
+                float d[8];
+                load8<T>(Delta + (int64_t)blockIdx.x * ldx + i, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = Act<T>::round(v[u][e] + d[e]);
+                store8<T>(Hout + (int64_t)blockIdx.x * ldx + i, v[u]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[u][e], v[u][e], ss);
+        }
+    }
+    ss = block_sum_256(ss, red);
+    const float r = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = (threadIdx.x + u * 256) * 8;
+        if (i < dim) {
+            float w[8], y[8];
+            load8<T>(Wt + i, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = Act<T>::round(v[u][e] * r) * w[e];
+            store8<T>(o + i, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused_qkv (rows, (H + 2G) D): rotate q and k pairs (re, im) by (cos, sin) of the row's position, write
+// q (rows, H D); k, v into the caches at row `write_index[s]`.
+//   table: (max_pos, D/2, 2) in the activation dtype (second half of the pairs = (1, 0) pass-through)
+// rows = B * S, row = b * S + s.  caches: (B, capacity, G, D).  One thread = 4 pairs = 8 values.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict__ QKV, const T* __restrict__ table,
+                                                            const int64_t* __restrict__ pos, const int64_t* __restrict__ widx,
+                                                            T* __restrict__ Qout, T* __restrict__ Kc, T* __restrict__ Vc,
+                                                            int S, int H, int G, int D, int capacity, int64_t ldqkv) {
+    const int row = blockIdx.x, b = row / S, s = row - b * S;
+    const T* in = QKV + (int64_t)row * ldqkv;
+    const T* cs = table + pos[row] * D;                      // D/2 pairs x 2 = D values
+    const int64_t wrow = widx[s];
+    const int per_head = D / 8;                              // 8-value units per head
+    const int n_units = (H + 2 * G) * per_head;
+    for (int i = threadIdx.x; i < n_units; i += 256) {
+        const int head = i / per_head, u = i - head * per_head;
+        float x[8];
+        load8<T>(in + head * D + u * 8, x);
+        T* dst;
+        if (head < H)
+            dst = Qout + (int64_t)row * (H * D) + head * D;
+        else if (head < H + G)
+            dst = Kc + (((int64_t)b * capacity + wrow) * G + (head - H)) * D;
+        else
+            dst = Vc + (((int64_t)b * capacity + wrow) * G + (head - H - G)) * D;
+        if (head < H + G) {
+            float c[8], y[8];
+            load8<T>(cs + u * 8, c);                         // (cos, sin) x 4 pairs
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                y[2 * p] = x[2 * p] * c[2 * p] - x[2 * p + 1] * c[2 * p + 1];
+                y[2 * p + 1] = x[2 * p] * c[2 * p + 1] + x[2 * p + 1] * c[2 * p];
+            }
+            store8<T>(dst + u * 8, y);
+        } else {
+            store8<T>(dst + u * 8, x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one query position per block: block = (b, head).  q (B, H, D) [S == 1]; caches (B, capacity, G, D);
+// mask (B, capacity) additive fp32.  out (B, H D).
+//   qs = round(q / sqrt(D));  s_t = round(sum_d qs_d k_td) + mask_t;  p = round(softmax_fp32(s));
+//   out_d = round(sum_t p_t v_td)
+// QK: thread = position, the key row read with 16-byte loads, all issued before the first use.
+// PV: thread = (8-wide d chunk, position slice): 16-byte loads of V, slices combined through LDS.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kc,
+                                                               const T* __restrict__ Vc, const float* __restrict__ mask,
+                                                               T* __restrict__ Out, int H, int G, int capacity,
+                                                               float sqrt_d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = D / 8;                                 // 8-wide chunks per head row
+    constexpr int SL = 256 / CH;                              // position slices in the PV phase
+    float* sc = reinterpret_cast<float*>(smem);               // capacity scores / probabilities
+    float* qs = sc + capacity;                                // D scaled query values
+    float* red = qs + D;                                      // 4
+    float* part = red + 4;                                    // SL x D partial outputs
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int g = h / (H / G);
+    const T* q = Q + ((int64_t)b * H + h) * D;
+    for (int d = threadIdx.x; d < D; d += 256) qs[d] = Act<T>::round(Act<T>::load(q + d) / sqrt_d);
+    __syncthreads();
+    const T* kb = Kc + ((int64_t)b * capacity * G + g) * D;
+    const T* vb = Vc + ((int64_t)b * capacity * G + g) * D;
+    const float* mk = mask + (int64_t)b * capacity;
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < capacity; t += 256) {
+        const T* k = kb + (int64_t)t * G * D;
+        float kv[CH][8];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) load8<T>(k + c * 8, kv[c]);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qs[c * 8 + e], kv[c][e], acc);
+        const float s = Act<T>::round(acc) + mk[t];
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max_256(mx, red);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < capacity; t += 256) {
+        const float e = __expf(sc[t] - mx);
+        sc[t] = e;
+        sum += e;
+    }
+    sum = block_sum_256(sum, red);
+    const float inv = 1.0f / sum;
+    for (int t = threadIdx.x; t < capacity; t += 256) sc[t] = Act<T>::round(sc[t] * inv);
+    __syncthreads();
+    const int c = threadIdx.x % CH, sl = threadIdx.x / CH;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    int t = sl;
+    for (; t + 3 * SL < capacity; t += 4 * SL) {              // 4 independent 16-byte loads in flight
+        float v0[8], v1[8], v2[8], v3[8];
+        load8<T>(vb + (int64_t)t * G * D + c * 8, v0);
+        load8<T>(vb + (int64_t)(t + SL) * G * D + c * 8, v1);
+        load8<T>(vb + (int64_t)(t + 2 * SL) * G * D + c * 8, v2);
+        load8<T>(vb + (int64_t)(t + 3 * SL) * G * D + c * 8, v3);
+        const float p0 = sc[t], p1 = sc[t + SL], p2 = sc[t + 2 * SL], p3 = sc[t + 3 * SL];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = __builtin_fmaf(p3, v3[e], __builtin_fmaf(p2, v2[e], __builtin_fmaf(p1, v1[e], __builtin_fmaf(p0, v0[e], o[e]))));
+    }
+    for (; t < capacity; t += SL) {
+        float v0[8];
+        load8<T>(vb + (int64_t)t * G * D + c * 8, v0);
+        const float p0 = sc[t];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p0, v0[e], o[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[sl * D + c * 8 + e] = o[e];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float tot = 0.f;
+        for (int s2 = 0; s2 < SL; ++s2) tot += part[s2 * D + d];
+        Act<T>::store(Out + ((int64_t)b * H + h) * D + d, tot);
+    }
+}
+
+// out = round(round(silu(h)) * gate), (h, gate) = halves of a (rows, 2 hidden) matrix; 8 values per thread
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ In, T* __restrict__ Out, int hidden,
+                                                       int64_t ldin, int64_t ldo) {
+    const T* in = In + (int64_t)blockIdx.y * ldin;
+    T* o = Out + (int64_t)blockIdx.y * ldo;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= hidden) return;
+    float h[8], g[8], y[8];
+    load8<T>(in + i, h);
+    load8<T>(in + hidden + i, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = Act<T>::round(h[e] / (1.0f + __expf(-h[e]))) * g[e];
+    store8<T>(o + i, y);
+}
+
+#define QL_DT(dtype, CALL)                                        \
+    switch (dtype) {                                              \
+    case QL_DTYPE_F32: { typedef float T; CALL; break; }          \
+    case QL_DTYPE_F16: { typedef f16 T; CALL; break; }            \
+    case QL_DTYPE_BF16: { typedef __bf16 T; CALL; break; }        \
+    default: return QL_ERR_BAD_DTYPE;                             \
+    }
+
+template <typename T, bool FUSE_ADD>
+static int launch_rmsnorm(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows, int64_t dim,
+                          int64_t ldx, int64_t ldo, float eps, hipStream_t st) {
+    const int vpt = (int)((dim / 8 + 255) / 256);
+#define QL_RMS(V)                                                                                                  \
+    rmsnorm_kernel<T, V, FUSE_ADD><<<(unsigned)rows, 256, 0, st>>>((const T*)X, (const T*)Delta, (const T*)W, (T*)Hout, \
+                                                                   (T*)Out, (int)dim, ldx, ldo, eps)
+    if (vpt <= 1) QL_RMS(1);
+    else if (vpt <= 2) QL_RMS(2);
+    else if (vpt <= 4) QL_RMS(4);
+    else if (vpt <= 8) QL_RMS(8);
+    else return QL_ERR_UNSUPPORTED;
+#undef QL_RMS
+    return finish_launch();
+}
+
+int rmsnorm(int dtype, const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows, int64_t dim,
+            int64_t ldx, int64_t ldo, float eps, hipStream_t st) {
+    if (Delta) {
+        QL_DT(dtype, return (launch_rmsnorm<T, true>(X, Delta, W, Hout, Out, rows, dim, ldx, ldo, eps, st)))
+    } else {
+        QL_DT(dtype, return (launch_rmsnorm<T, false>(X, Delta, W, Hout, Out, rows, dim, ldx, ldo, eps, st)))
+    }
+    return QL_ERR_BAD_DTYPE;
+}
+
+int rope_kv_write(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Qout,
+                  void* Kc, void* Vc, int64_t B, int64_t S, int64_t H, int64_t G, int64_t D, int64_t capacity,
+                  int64_t ldqkv, hipStream_t st) {
+    QL_DT(dtype, (rope_kv_write_kernel<T><<<(unsigned)(B * S), 256, 0, st>>>((const T*)QKV, (const T*)table, pos, widx, (T*)Qout,
+                                                                              (T*)Kc, (T*)Vc, (int)S, (int)H, (int)G, (int)D,
+                                                                              (int)capacity, ldqkv)))
+    return finish_launch();
+}
+
+template <typename T>
+static int launch_attention(const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
+                            int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
+    const float sq = sqrtf((float)D);
+#define QL_ATT(DD)                                                                                                  \
+    {                                                                                                               \
+        const size_t lds = (size_t)(capacity + DD + 4 + (256 / (DD / 8)) * DD) * sizeof(float);                     \
+        decode_attention_kernel<T, DD><<<(unsigned)(B * H), 256, lds, st>>>((const T*)Q, (const T*)Kc, (const T*)Vc, mask, \
+                                                                            (T*)Out, (int)H, (int)G, (int)capacity, sq);  \
+    }
+    if (D == 128) QL_ATT(128)
+    else if (D == 64) QL_ATT(64)
+    else if (D == 32) QL_ATT(32)
+    else return QL_ERR_UNSUPPORTED;
+#undef QL_ATT
+    return finish_launch();
+}
+
+int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
+                     int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
+    QL_DT(dtype, return (launch_attention<T>(Q, Kc, Vc, mask, Out, B, H, G, D, capacity, st)))
+    return QL_ERR_BAD_DTYPE;
+}
+
+int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st) {
+    dim3 grid((unsigned)((hidden / 8 + 255) / 256), (unsigned)rows);
+    QL_DT(dtype, (silu_mul_kernel<T><<<grid, 256, 0, st>>>((const T*)In, (T*)Out, (int)hidden, ldin, ldo)))
+    return finish_launch();
+}
+
+}  // namespace ql

@@ -42,4 +42,14 @@ int qembedding_w4(int dtype, const int64_t* ids, const uint8_t* Wq, const void* 
 int qembedding_w8(int dtype, const int64_t* ids, const int8_t* W, const void* S, void* out, int64_t count,
                   int64_t V, int64_t D, hipStream_t st);
 
+// decode_ops.hip
+int rmsnorm(int dtype, const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows, int64_t dim,
+            int64_t ldx, int64_t ldo, float eps, hipStream_t st);
+int rope_kv_write(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Qout,
+                  void* Kc, void* Vc, int64_t B, int64_t S, int64_t H, int64_t G, int64_t D, int64_t capacity,
+                  int64_t ldqkv, hipStream_t st);
+int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
+                     int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st);
+int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st);
+
 }  // namespace ql

@@ -375,48 +375,115 @@ __global__ __launch_bounds__(256) void act_quant_rowwise_kernel(const T* __restr
 
 // =============================================================================================
 // W8A8: C = round(acc_i32 * (a_scale[m] * w_scale[n])) (+ bias), acc = Aq (M,K) . W (N,K)^T
-//   v_mfma_i32_32x32x32_i8: lane l supplies row (l & 31) of its operand and the 16 consecutive k
-//   bytes of half (l >> 5) of the 32-deep step - both operands are K-contiguous in memory, so each
-//   fragment is ONE 16-byte load.  Block = 4 waves = 64 x 64 outputs (wave = 32 x 32).
-//   Accumulator map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+//   A true int8 x int8 dense GEMM on v_mfma_i32_32x32x32_i8 (exact int32 accumulation).
+//   Both operands are K-contiguous int8.  Block = 4 waves side by side in N (128 output channels) x
+//   BM = 32 MT rows; K step = 128 bytes.  Both tiles are staged through LDS in full 128-byte lines
+//   (global -> registers one step ahead -> ds_write_b128 after the MFMAs, double buffered, one barrier per
+//   step); 16-byte chunk c of row r sits at chunk position 8 r + (c ^ ((r >> 1) & 7)) so the fragment
+//   reads (ds_read_b128, 128-byte pitch) are bank-conflict free.  Lane (j = lane & 31, kb = lane >> 5)
+//   feeds MFMA sub-step s with chunk 4 kb + s of its row for BOTH operands (a consistent K assignment).
+//   Accumulator map: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
 // =============================================================================================
-template <typename T>
+template <typename T, int MT>
 __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict__ Aq, const float* __restrict__ a_scale,
                                                         const int8_t* __restrict__ W, const T* __restrict__ S,
                                                         const T* __restrict__ bias, T* __restrict__ C, int M, int N,
                                                         int K, int64_t ldc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mt = blockIdx.y * 64 + (wave >> 1) * 32;
-    const int nt = blockIdx.x * 64 + (wave & 1) * 32;
-    if (mt >= M || nt >= N) return;
-    const int r = lane & 31, kh = lane >> 5;
-    const int am = (mt + r < M) ? (mt + r) : (M - 1);
-    const int bn = (nt + r < N) ? (nt + r) : (N - 1);
-    const int8_t* ap = Aq + (int64_t)am * K + kh * 16;
-    const int8_t* bp = W + (int64_t)bn * K + kh * 16;
+    constexpr int BM = 32 * MT;
+    constexpr int ACH = BM * 8 / 256;          // 16-byte A chunks staged per thread per K step
+    constexpr int WCH = 4;                     // 128 rows x 8 chunks / 256 threads
+    __shared__ __attribute__((aligned(16))) char smem_a[2][BM * 128];
+    __shared__ __attribute__((aligned(16))) char smem_w[2][128 * 128];
 
-    i32x16 acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kb = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 128;
+    const int ksteps = (K + 127) >> 7;
+
+    const int8_t* a_src[ACH];
+    int a_dst[ACH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
-
-#pragma unroll 4
-    for (int k = 0; k < K; k += 32) {
-        const i32x4 a = *reinterpret_cast<const i32x4*>(ap + k);
-        const i32x4 b = *reinterpret_cast<const i32x4*>(bp + k);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+    for (int u = 0; u < ACH; ++u) {
+        const int q = tid + u * 256, r = q >> 3, c = q & 7;
+        a_src[u] = Aq + (int64_t)((m0 + r < M) ? (m0 + r) : (M - 1)) * K + c * 16;
+        a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
     }
-
-    const int n = nt + r;
-    if (n < N) {
-        const float ws = Act<T>::load(S + n);
+    const int8_t* w_src[WCH];
+    int w_dst[WCH];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mt + (i & 3) + 8 * (i >> 2) + 4 * kh;
-            if (m < M) {
-                const float comb = a_scale[m] * ws;
-                store_out<T>(C + (int64_t)m * ldc + n, (float)acc[i] * comb, bias ? bias + n : nullptr);
+    for (int u = 0; u < WCH; ++u) {
+        const int q = tid + u * 256, r = q >> 3, c = q & 7;
+        w_src[u] = W + (int64_t)((n0 + r < N) ? (n0 + r) : (N - 1)) * K + c * 16;
+        w_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
+    }
+    const int c_mine = tid & 7;                // (tid + u * 256) & 7 is the same for every u
+    const int klast = K - 16;                  // last in-bounds 16-byte chunk start
+
+    i32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0;
+
+    i32x4 a_next[ACH], w_next[WCH];
+    auto load_tiles = [&](int kt) {
+        const int k = kt * 128 + c_mine * 16;
+        const bool inb = k <= klast;
+        const int off = inb ? kt * 128 : klast - c_mine * 16;      // clamped address for the K tail
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) a_next[u] = *reinterpret_cast<const i32x4*>(a_src[u] + off);
+#pragma unroll
+        for (int u = 0; u < WCH; ++u) w_next[u] = *reinterpret_cast<const i32x4*>(w_src[u] + off);
+        if (!inb) {                             // zero weights make the tail contribute exactly 0
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) w_next[u] = i32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) *reinterpret_cast<i32x4*>(smem_a[buf] + a_dst[u]) = a_next[u];
+#pragma unroll
+        for (int u = 0; u < WCH; ++u) *reinterpret_cast<i32x4*>(smem_w[buf] + w_dst[u]) = w_next[u];
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int wr = wave * 32 + j;              // this lane's weight row inside the block's W tile
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < ksteps;
+        if (more) load_tiles(kt + 1);          // in flight under this step's MFMAs
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int c = kb * 4 + sub;
+            const i32x4 b = *reinterpret_cast<const i32x4*>(smem_w[buf] + (wr * 8 + (c ^ ((wr >> 1) & 7))) * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = mt * 32 + j;
+                const i32x4 a = *reinterpret_cast<const i32x4*>(smem_a[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[mt], 0, 0, 0);
             }
         }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int n = n0 + wave * 32 + j;
+    if (n < N) {
+        const float ws = Act<T>::load(S + n);
+        const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) {
+                    const float comb = a_scale[m] * ws;
+                    store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][i] * comb, bn);
+                }
+            }
     }
 }
 
@@ -498,13 +565,23 @@ static int launch_act_quant(const void* A, int8_t* Aq, float* a_scale, int64_t M
     return finish_launch();
 }
 
+template <typename T, int MT>
+static int launch_w8a8_mt(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
+                          void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
+    w8a8_mfma_kernel<T, MT><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N,
+                                                  (int)K, ldc);
+    return finish_launch();
+}
+
 template <typename T>
 static int launch_w8a8(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
                        void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
-    w8a8_mfma_kernel<T><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N,
-                                              (int)K, ldc);
-    return finish_launch();
+    // rows per block: large tiles once they still give >= ~1 block per CU, smaller ones to fill the chip
+    const int64_t nb = (N + 127) / 128;
+    if (M > 64 && nb * ((M + 127) / 128) >= 256) return launch_w8a8_mt<T, 4>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
+    if (M > 32) return launch_w8a8_mt<T, 2>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
+    return launch_w8a8_mt<T, 1>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
 }
 
 #define QL_DISPATCH_DTYPE(dtype, fn, ...)                         \

@@ -1,0 +1,229 @@
+"""Token-by-token decode loop around the quantized model (harness for BASELINE configs 4 and 5).
+
+Counterpart of the reference's ``ChatGLMDecoder.generate`` and ``top_p_sampling``
+(chatglm_q/decoder.py:12-27,65-108): batch 1, same sampler, same timing definitions
+(``gen = (n - 1) / sum(t[1:])``, ``avg = n / sum(t)``, chatglm_q/decoder.py:99-106).
+
+MI355X-first differences (results unchanged):
+  * the key/value cache is preallocated and a decode step is shape-static, so ONE step - 113 QLinear
+    launches plus the small ops around them - is captured in a HIP graph and replayed per token; the
+    position counter, the cache write index, the attention mask and (for greedy decoding) the argmax and
+    the next input id are all updated on the device inside that graph, so the host only replays it;
+  * lm_head is evaluated for the last position only (the loop uses nothing else, decoder.py:85);
+  * prefill can be chunked (`prefill_chunk`), each chunk one forward over batch x chunk rows.
+Text handling (tokenizer, chat template, punctuation fix-ups) is out of scope: the loop works on token ids;
+a tokenizer object with ``encode`` / ``decode`` may be supplied and is used if present.
+"""
+from __future__ import annotations
+
+import time
+from typing import Iterable, Optional
+
+import torch
+from torch import Tensor
+
+from .model import ChatGLM2Model, KVCache
+
+
+def top_p_sampling(logits: Tensor, top_k: int = 100, top_p: float = 0.8, temperature: float = 1.0) -> Tensor:
+    """softmax(logits / T) -> keep the top_k most likely -> drop those whose preceding cumulative mass
+    exceeds top_p -> renormalise -> one multinomial draw (chatglm_q/decoder.py:12-27)."""
+    probs = torch.softmax(logits.float() / temperature, dim=-1)
+    probs, indices = torch.sort(probs, dim=-1, descending=True)
+    probs, indices = probs[..., :top_k], indices[..., :top_k]
+    before = torch.cumsum(probs, dim=-1) - probs
+    probs = torch.where(before > top_p, torch.zeros_like(probs), probs)
+    probs = probs / probs.sum(dim=-1, keepdim=True)
+    pick = torch.multinomial(probs, num_samples=1)
+    return torch.gather(indices, dim=-1, index=pick)[..., 0]
+
+
+def filtered_distribution(logits: Tensor, top_k: int = 100, top_p: float = 0.8, temperature: float = 1.0):
+    """The deterministic part of the sampler: (renormalised probabilities, token indices)."""
+    probs = torch.softmax(logits.float() / temperature, dim=-1)
+    probs, indices = torch.sort(probs, dim=-1, descending=True)
+    probs, indices = probs[..., :top_k], indices[..., :top_k]
+    before = torch.cumsum(probs, dim=-1) - probs
+    probs = torch.where(before > top_p, torch.zeros_like(probs), probs)
+    return probs / probs.sum(dim=-1, keepdim=True), indices
+
+
+class DecodeSession:
+    """One sequence batch on one device: preallocated cache, eager (chunked) prefill, graph-replayed decode."""
+
+    def __init__(self, model: ChatGLM2Model, batch: int, capacity: int, use_graph: Optional[bool] = None):
+        self.model = model
+        p = model.final_ln.weight
+        self.device, self.dtype = p.device, p.dtype
+        self.batch, self.capacity = batch, capacity
+        self.cache: KVCache = model.new_cache(batch, capacity)
+        self.use_graph = (self.device.type == "cuda") if use_graph is None else use_graph
+        dev = self.device
+        # device-resident step state (static addresses: the captured graph reads and updates them)
+        self.tok = torch.zeros(batch, 1, dtype=torch.long, device=dev)
+        self.write_index = torch.zeros(1, dtype=torch.long, device=dev)
+        self.pos = torch.zeros(batch, 1, dtype=torch.long, device=dev)
+        self.mask = torch.full((batch, 1, capacity), -1e10, dtype=torch.float32, device=dev)
+        self.logits: Optional[Tensor] = None
+        self.graph = None
+        self.length = 0
+
+    # -- prefill -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prefill(self, ids: Tensor, chunk: Optional[int] = None) -> Tensor:
+        """ids (batch, S).  Returns the last position's logits (batch, vocab)."""
+        B, S = ids.shape
+        if S + self.length > self.capacity:
+            raise ValueError(f"sequence {S + self.length} exceeds the cache capacity {self.capacity}")
+        ids = ids.to(self.device)
+        chunk = chunk or S
+        t = torch.arange(self.capacity, device=self.device)
+        logits = None
+        for s0 in range(0, S, chunk):
+            s1 = min(S, s0 + chunk)
+            rows = torch.arange(self.length + s0, self.length + s1, device=self.device)
+            mask = ((t[None, :] > rows[:, None]).float() * -1e10)[None].expand(B, -1, -1)
+            logits = self.model.step(ids[:, s0:s1], self.cache, rows, (rows + 1)[None].expand(B, -1), mask,
+                                     last_only=True)
+        self.length += S
+        self.cache.length = self.length
+        # arm the decode-step state
+        self.write_index.fill_(self.length)
+        self.pos.fill_(self.length + 1)                         # positions are 1-based (model.py:308)
+        self.mask.fill_(-1e10)
+        self.mask[:, :, : self.length] = 0.0
+        return logits[:, -1]
+
+    # -- one decode step -------------------------------------------------------------------------------
+    def _step_body(self, greedy: bool):
+        self.mask.index_fill_(2, self.write_index, 0.0)         # the new position may attend to itself
+        logits = self.model.step(self.tok, self.cache, self.write_index, self.pos, self.mask, last_only=True)
+        self.logits = logits[:, -1]
+        if greedy:
+            self.tok.copy_(self.logits.argmax(dim=-1, keepdim=True))
+        self.write_index.add_(1)
+        self.pos.add_(1)
+
+    @torch.no_grad()
+    def capture(self, greedy: bool = True):
+        """Capture one decode step.  Every weight's derived layout must already exist (module.prepare())."""
+        if not self.use_graph:
+            return
+        saved = (self.tok.clone(), self.write_index.clone(), self.pos.clone(), self.mask.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._step_body(greedy)                             # warm-up: allocations, lazy repacks
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step_body(greedy)
+        # capture ran the body twice on live state: restore (the cache rows it touched get rewritten)
+        for dst, src in zip((self.tok, self.write_index, self.pos, self.mask), saved):
+            dst.copy_(src)
+        self._captured_greedy = greedy
+
+    @torch.no_grad()
+    def decode_step(self, token: Optional[Tensor] = None, greedy: bool = True) -> Tensor:
+        """Advance by one token.  `token` (batch, 1) overrides the device-resident next id (needed when the
+        host samples).  Returns this step's last-position logits (batch, vocab)."""
+        if self.length + 1 > self.capacity:
+            raise ValueError("cache capacity exhausted")
+        if token is not None:
+            self.tok.copy_(token.to(self.device))
+        if self.graph is not None and self._captured_greedy == greedy:
+            self.graph.replay()
+        else:
+            self._step_body(greedy)
+        self.length += 1
+        self.cache.length = self.length
+        return self.logits
+
+
+class ChatGLMDecoder:
+    def __init__(self, config, model: ChatGLM2Model, tokenizer=None, eos_token_id: Optional[int] = None, device=None,
+                 max_sequence_length: Optional[int] = None, time_log: bool = False):
+        self.config = config
+        self.model = model
+        self.tokenizer = tokenizer
+        self.device = device
+        self.eos_token_id = eos_token_id
+        self.max_sequence_length = max_sequence_length or model.config.max_sequence_length
+        self.time_log = time_log
+        self.last_stats: dict = {}
+
+    @torch.no_grad()
+    def generate_ids(self, prefix_ids: Iterable[int], max_generated_tokens: int = 400, top_k: int = 100,
+                     top_p: float = 0.8, temperature: float = 1.0, greedy: bool = False, ignore_eos: bool = False,
+                     prefill_chunk: Optional[int] = None, use_graph: Optional[bool] = None, sync_every_token: bool = True):
+        """Yields generated token ids one by one (batch 1, like the reference, chatglm_q/decoder.py:70)."""
+        prefix = list(prefix_ids)
+        budget = min(max_generated_tokens, self.max_sequence_length - len(prefix))
+        if budget <= 0:
+            return
+        capacity = -(-(len(prefix) + budget) // 64) * 64
+        sess = DecodeSession(self.model, 1, capacity, use_graph)
+        times = []
+        sync = (lambda: torch.cuda.synchronize(sess.device)) if sess.device.type == "cuda" else (lambda: None)
+
+        t0 = time.perf_counter()
+        logits = sess.prefill(torch.tensor([prefix], dtype=torch.long), prefill_chunk)
+        nxt = logits.argmax(-1) if greedy else top_p_sampling(logits, top_k, top_p, temperature)
+        token = int(nxt.item())                                    # the sync that makes the timing valid
+        times.append(time.perf_counter() - t0)
+        generated = [token]
+        yield token
+
+        device_loop = greedy and not sync_every_token and (ignore_eos or self.eos_token_id is None)
+        if len(generated) < budget and (ignore_eos or token != self.eos_token_id):
+            sess.tok.fill_(token)
+            sess.capture(greedy=greedy)
+        pending = []
+        while len(generated) < budget and (ignore_eos or generated[-1] != self.eos_token_id):
+            t0 = time.perf_counter()
+            if device_loop:
+                # the graph feeds its own argmax back as the next input: the host only replays
+                sess.decode_step(greedy=True)
+                pending.append(sess.tok.clone())
+                generated.append(-1)
+                times.append(time.perf_counter() - t0)
+                continue
+            logits = sess.decode_step(None if greedy else torch.tensor([[generated[-1]]]), greedy=greedy)
+            nxt = sess.tok[:, 0] if greedy else top_p_sampling(logits, top_k, top_p, temperature)
+            token = int(nxt.item())
+            times.append(time.perf_counter() - t0)
+            generated.append(token)
+            yield token
+        if device_loop and pending:
+            t0 = time.perf_counter()
+            sync()
+            times[-1] += time.perf_counter() - t0
+            toks = [int(t.item()) for t in pending]
+            generated[-len(toks):] = toks
+            for t in toks:
+                yield t
+
+        n = len(times)
+        rest = sum(times[1:])
+        self.last_stats = {
+            "prefix": len(prefix), "generated": n, "init_s": times[0], "sum_s": sum(times),
+            "gen_tok_per_s": (n - 1) / rest if n > 1 and rest > 0 else float("nan"),
+            "avg_tok_per_s": n / sum(times),
+        }
+        if self.time_log:
+            s = self.last_stats
+            print("Decoder:")
+            print(f"  len: {s['prefix']}(prefix) + {s['generated']}(gen)")
+            print(f" init: {s['init_s']:.6f} s")
+            print(f"  sum: {s['sum_s']:.6f} s")
+            print(f"  gen: {s['gen_tok_per_s']:.6f} tok/s")
+            print(f"  avg: {s['avg_tok_per_s']:.6f} tok/s")
+
+    def generate(self, prefix_text: str, **kw):
+        """Text interface when a tokenizer (``encode`` / ``decode``) was supplied; yields the decoded text so far."""
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: use generate_ids() with token ids")
+        ids = []
+        for tok in self.generate_ids(self.tokenizer.encode(prefix_text), **kw):
+            ids.append(tok)
+            yield self.tokenizer.decode(ids)

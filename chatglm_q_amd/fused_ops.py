@@ -1,0 +1,83 @@
+"""Host wrappers for the fused decode-step neighbours of the QLinear calls (csrc/decode_ops.hip,
+SURVEY.md 8f row N1).  Each replaces a handful of tiny torch launches with one HIP launch and keeps the
+model graph's rounding sequence (chatglm_q/model.py, lines cited in include/qlinear_hip.h)."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def rmsnorm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    lib = _lib.get_lib()
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty((x2.shape[0], x2.shape[1]), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        st = lib.qlinear_rmsnorm(x2.data_ptr(), weight.data_ptr(), out.data_ptr(), x2.shape[0], x2.shape[1],
+                                 x2.stride(0) if x2.shape[0] > 1 else x2.shape[1], x2.shape[1], float(eps),
+                                 _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
+    _lib.check(st, "qlinear_rmsnorm")
+    return out.reshape(x.shape)
+
+
+def add_rmsnorm(x: Tensor, delta: Tensor, weight: Tensor, eps: float):
+    """h = x + delta (rounded), out = rmsnorm(h) * weight in ONE launch.  Returns (h, out)."""
+    lib = _lib.get_lib()
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1]).contiguous()
+    d2 = delta.reshape(-1, shape[-1]).contiguous()
+    h = torch.empty_like(x2)
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x.device):
+        st = lib.qlinear_add_rmsnorm(x2.data_ptr(), d2.data_ptr(), weight.data_ptr(), h.data_ptr(), out.data_ptr(),
+                                     x2.shape[0], x2.shape[1], x2.shape[1], float(eps), _lib.dtype_code(x.dtype),
+                                     _lib.stream_ptr(x.device))
+    _lib.check(st, "qlinear_add_rmsnorm")
+    return h.reshape(shape), out.reshape(shape)
+
+
+def rope_kv_write(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
+                  n_head: int, n_groups: int, d_head: int) -> Tensor:
+    """qkv (B, S, (H+2G) D) -> rotated q (B, S, H*D); rotated k and v are written into the caches in place."""
+    lib = _lib.get_lib()
+    B, S, W = qkv.shape
+    qkv = qkv.contiguous()
+    q = torch.empty((B, S, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
+    with torch.cuda.device(qkv.device):
+        st = lib.qlinear_rope_kv_write(qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(),
+                                       write_index.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                       B, S, n_head, n_groups, d_head, k_cache.shape[1], W,
+                                       _lib.dtype_code(qkv.dtype), _lib.stream_ptr(qkv.device))
+    _lib.check(st, "qlinear_rope_kv_write")
+    return q
+
+
+def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, n_head: int, n_groups: int,
+                     d_head: int) -> Tensor:
+    """q (B, 1, H*D), caches (B, capacity, G, D), mask (B, 1, capacity) additive fp32 -> (B, 1, H*D)."""
+    lib = _lib.get_lib()
+    B = q.shape[0]
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        st = lib.qlinear_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), mask.data_ptr(),
+                                          out.data_ptr(), B, n_head, n_groups, d_head, k_cache.shape[1],
+                                          _lib.dtype_code(q.dtype), _lib.stream_ptr(q.device))
+    _lib.check(st, "qlinear_decode_attention")
+    return out
+
+
+def silu_mul(x: Tensor, hidden: int) -> Tensor:
+    lib = _lib.get_lib()
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty((x2.shape[0], hidden), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        st = lib.qlinear_silu_mul(x2.data_ptr(), out.data_ptr(), x2.shape[0], hidden,
+                                  x2.stride(0) if x2.shape[0] > 1 else 2 * hidden, hidden,
+                                  _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
+    _lib.check(st, "qlinear_silu_mul")
+    return out.reshape(*x.shape[:-1], hidden)

@@ -1,0 +1,335 @@
+"""ChatGLM2 decoder graph - the CALLER of the quantized-linear path (harness for BASELINE configs 4 and 5).
+
+This is the build's own counterpart of the reference's model graph (chatglm_q/model.py:90-392); it exists so
+that the QLinear kernels can be measured where they are used: 28 x (qkv_proj, o_proj, w_in, w_out) +
+lm_head = 113 calls per decoded token.  Numerical semantics follow the reference (cited per block) and
+are pinned by tests/golden/tiny_model.npz; parameter / buffer names match it, so a reference checkpoint's
+state_dict loads key for key.
+
+Differences in structure (not in results): one preallocated key/value cache per layer that a decode step
+writes in place (the reference grows its cache with torch.cat every token, chatglm_q/model.py:151-155),
+which makes a decode step shape-static and HIP-graph capturable (`chatglm_q_amd/decoder.py`).
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+
+# QLINEAR_FUSED_DECODE=0 keeps every op around the QLinear calls in plain torch (A/B measurements)
+FUSED_DECODE_OPS = os.environ.get("QLINEAR_FUSED_DECODE", "1") not in ("0", "false", "False")
+
+
+@dataclass
+class ChatGLM2Config:
+    # field names and defaults as chatglm_q/model.py:9-22 (ChatGLM2-6B)
+    hidden_size: int = 4096
+    inner_hidden_size: int = 13696
+    head_hidden_size: int = 128
+    num_multi_query_groups: int = 2
+    num_attention_heads: int = 32
+    num_layers: int = 28
+    vocab_size: int = 65024
+    dropout_rate: float = 0.0
+    layernorm_epsilon: float = 1e-05
+    max_sequence_length: int = 8192
+
+
+# Patch points, as in the reference (chatglm_q/model.py:76-87): a loader rebinds these two names to the
+# quantized classes before constructing the model (chatglm_q/loader.py:41-66).
+class Linear(nn.Linear):
+    def forward(self, x: Tensor) -> Tensor:
+        return F.linear(x, self.weight.type_as(x), None if self.bias is None else self.bias.type_as(x))
+
+    def reset_parameters(self):
+        pass
+
+
+class Embedding(nn.Embedding):
+    def reset_parameters(self):
+        pass
+
+
+def rotary_table(d_head: int, length: int, theta: float = 10000.0) -> Tensor:
+    """(length, d_head/2, 2) table of (cos, sin): the first d_head/4 pairs rotate, the rest pass through
+    as (1, 0) - "half of the head_dim bypassed" (chatglm_q/model.py:35-44)."""
+    half = d_head // 2
+    inv = 1.0 / (theta ** (torch.arange(0, half, 2).float() / half))
+    ang = torch.outer(torch.arange(length).float(), inv)
+    rot = torch.stack((torch.cos(ang), torch.sin(ang)), dim=-1)
+    keep = torch.stack((torch.ones_like(ang), torch.zeros_like(ang)), dim=-1)
+    return torch.cat((rot, keep), dim=-2)
+
+
+def rotate_pairs(x: Tensor, cs: Tensor) -> Tensor:
+    """Complex multiply of interleaved (re, im) pairs by (cos, sin) (chatglm_q/model.py:48-59).
+    x: (..., d/2, 2); cs broadcastable (..., d/2, 2).  Evaluated in fp32, returned in x's dtype."""
+    xr, xi = x[..., 0].float(), x[..., 1].float()
+    c, s = cs[..., 0].float(), cs[..., 1].float()
+    return torch.stack((xr * c - xi * s, xr * s + xi * c), dim=-1).flatten(-2).to(x.dtype)
+
+
+class RMSNorm(nn.Module):
+    """x * rsqrt(mean(x^2) + eps) in fp32, cast back, times weight (chatglm_q/model.py:62-73)."""
+
+    def __init__(self, dim: int, eps: float = 1e-5, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, dtype=dtype))
+        self.eps = eps
+
+    def forward(self, x: Tensor) -> Tensor:
+        xf = x.float()
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)).type_as(x) * self.weight
+
+
+class KVCache:
+    """Preallocated per-layer key/value store: (batch, capacity, groups, d_head)."""
+
+    def __init__(self, n_layers: int, batch: int, capacity: int, groups: int, d_head: int, device, dtype):
+        self.k = [torch.zeros(batch, capacity, groups, d_head, device=device, dtype=dtype) for _ in range(n_layers)]
+        self.v = [torch.zeros(batch, capacity, groups, d_head, device=device, dtype=dtype) for _ in range(n_layers)]
+        self.capacity = capacity
+        self.length = 0            # host-side count of valid positions (not used inside captured graphs)
+
+    def as_tuples(self):
+        """Reference-shaped view: tuple of (k, v) each (batch, length, groups, 1, d_head)."""
+        n = self.length
+        return tuple((k[:, :n].unsqueeze(3), v[:, :n].unsqueeze(3)) for k, v in zip(self.k, self.v))
+
+
+class ChatGLM2Attention(nn.Module):
+    """Multi-query attention (chatglm_q/model.py:90-177)."""
+
+    def __init__(self, n_state: int, n_head: int, d_head: int, n_groups: int, layer_idx: int, dtype=None):
+        super().__init__()
+        self.n_head, self.d_head, self.n_groups, self.layer_idx = n_head, d_head, n_groups, layer_idx
+        self.qkv_proj = Linear(n_state, d_head * (n_head + 2 * n_groups), bias=True, dtype=dtype)
+        self.o_proj = Linear(d_head * n_head, n_state, bias=False, dtype=dtype)
+
+    def project(self, x: Tensor, cs: Tensor):
+        """qkv projection + rotary.  Returns q (B,S,G,H/G,D), k (B,S,G,D), v (B,S,G,D)."""
+        B, S, _ = x.shape
+        H, D, G = self.n_head, self.d_head, self.n_groups
+        q, k, v = torch.split(self.qkv_proj(x), [D * H, D * G, D * G], dim=-1)
+        q = rotate_pairs(q.view(B, S, G, H // G, D // 2, 2), cs[:, :, None, None])
+        k = rotate_pairs(k.view(B, S, G, D // 2, 2), cs[:, :, None])
+        return q, k, v.view(B, S, G, D)
+
+    def attend(self, x_dtype, q: Tensor, k_all: Tensor, v_all: Tensor, mask: Optional[Tensor]) -> Tensor:
+        return self.o_proj(self.core(x_dtype, q, k_all, v_all, mask))
+
+    def core(self, x_dtype, q: Tensor, k_all: Tensor, v_all: Tensor, mask: Optional[Tensor]) -> Tensor:
+        """softmax((q / sqrt(D)) k^T + mask) v with the softmax in fp32 (chatglm_q/model.py:157-175).
+        q (B,S,G,Hg,D); k_all, v_all (B,T,G,D); mask (B,S,T) additive.  Returns (B,S,H*D) (before o_proj)."""
+        B, S, G, Hg, D = q.shape
+        qh = (q / math.sqrt(D)).permute(0, 2, 3, 1, 4)                    # (B,G,Hg,S,D)
+        kh = k_all.permute(0, 2, 3, 1)[:, :, None]                        # (B,G,1,D,T)
+        vh = v_all.permute(0, 2, 1, 3)[:, :, None]                        # (B,G,1,T,D)
+        qk = torch.matmul(qh, kh)                                         # (B,G,Hg,S,T)
+        if mask is not None:
+            qk = qk + mask[:, None, None, :, :]
+        p = F.softmax(qk.float(), dim=-1).to(x_dtype)
+        out = torch.matmul(p, vh)                                         # (B,G,Hg,S,D)
+        return out.permute(0, 3, 1, 2, 4).reshape(B, S, G * Hg * D)
+
+
+class GatedFeedForward(nn.Module):
+    """w_out(silu(h) * gate), (h, gate) = split(w_in(x)) (chatglm_q/model.py:180-201)."""
+
+    def __init__(self, dim: int, hidden_dim: int, dtype=None):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.w_in = Linear(dim, hidden_dim * 2, bias=False, dtype=dtype)
+        self.w_out = Linear(hidden_dim, dim, bias=False, dtype=dtype)
+
+    def forward(self, x: Tensor) -> Tensor:
+        h, gate = torch.split(self.w_in(x), self.hidden_dim, dim=-1)
+        return self.w_out(F.silu(h) * gate)
+
+
+class ChatGLM2Block(nn.Module):
+    """Pre-norm residual block (chatglm_q/model.py:204-246)."""
+
+    def __init__(self, layer_idx: int, config: ChatGLM2Config, dtype=None):
+        super().__init__()
+        self.layer_idx = layer_idx
+        self.attn_ln = RMSNorm(config.hidden_size, config.layernorm_epsilon, dtype)
+        self.attn = ChatGLM2Attention(config.hidden_size, config.num_attention_heads, config.head_hidden_size,
+                                      config.num_multi_query_groups, layer_idx, dtype)
+        self.ffn_ln = RMSNorm(config.hidden_size, config.layernorm_epsilon, dtype)
+        self.ffn = GatedFeedForward(config.hidden_size, config.inner_hidden_size, dtype)
+
+
+class ChatGLM2Model(nn.Module):
+    def __init__(self, config: ChatGLM2Config, dtype=None):
+        super().__init__()
+        self.config = config
+        self.word_embedding = Embedding(config.vocab_size, config.hidden_size, dtype=dtype)
+        self.layers = nn.ModuleList([ChatGLM2Block(i, config, dtype) for i in range(config.num_layers)])
+        self.final_ln = RMSNorm(config.hidden_size, config.layernorm_epsilon, dtype)
+        self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False, dtype=dtype)
+        # the reference keeps the table in the model dtype (chatglm_q/model.py:268-270)
+        table = rotary_table(config.head_hidden_size, config.max_sequence_length).to(dtype=dtype)
+        self.register_buffer("freqs_cis_cache", table.view(config.max_sequence_length, -1), persistent=False)
+
+    # -- cache helpers ---------------------------------------------------------------------------
+    def new_cache(self, batch: int, capacity: int, device=None, dtype=None) -> KVCache:
+        c = self.config
+        p = self.final_ln.weight
+        return KVCache(c.num_layers, batch, capacity, c.num_multi_query_groups, c.head_hidden_size,
+                       device or p.device, dtype or p.dtype)
+
+    def _rotary(self, position_ids: Tensor) -> Tensor:
+        d2 = self.config.head_hidden_size // 2
+        return F.embedding(position_ids, self.freqs_cis_cache).view(*position_ids.shape, d2, 2)
+
+    # -- one pass over `n_new` positions against a preallocated cache ------------------------------
+    def step(self, input_ids: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
+             last_only: bool = False) -> Tensor:
+        """Shape-static forward: embeds input_ids (B, S), writes the new keys/values into the cache rows
+        `write_index` (S,), attends over the WHOLE cache capacity under the additive `mask` (B, S, capacity)
+        and returns logits.  Every argument is a device tensor, so the call can be captured in a HIP graph
+        and replayed with new contents.  `last_only` evaluates lm_head for the final position only (the
+        decode loop uses nothing else, chatglm_q/decoder.py:85)."""
+        h = self.word_embedding(input_ids)
+        if FUSED_DECODE_OPS and h.is_cuda:
+            return self._step_fused(h, cache, write_index, position_ids, mask, last_only)
+        cs = self._rotary(position_ids)
+        for i, layer in enumerate(self.layers):
+            q, k, v = layer.attn.project(layer.attn_ln(h), cs)
+            cache.k[i].index_copy_(1, write_index, k)
+            cache.v[i].index_copy_(1, write_index, v)
+            h = h + layer.attn.attend(h.dtype, q, cache.k[i], cache.v[i], mask)
+            h = h + layer.ffn(layer.ffn_ln(h))
+        h = self.final_ln(h[:, -1:] if last_only else h)
+        return self.lm_head(h)
+
+    def _step_fused(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
+                    last_only: bool) -> Tensor:
+        """Same graph with the small ops around the QLinear calls fused into single HIP launches
+        (csrc/decode_ops.hip): RMSNorm; split + rotary + cache write; single-position attention; SiLU * gate."""
+        from . import fused_ops as F_
+        c = self.config
+        H, G, D = c.num_attention_heads, c.num_multi_query_groups, c.head_hidden_size
+        B, S, _ = h.shape
+        mask = mask.contiguous()
+        delta = None                                   # pending residual contribution of the previous sub-block
+        for i, layer in enumerate(self.layers):
+            if delta is None:
+                x = F_.rmsnorm(h, layer.attn_ln.weight, layer.attn_ln.eps)
+            else:                                      # h += delta and the next norm in one launch
+                h, x = F_.add_rmsnorm(h, delta, layer.attn_ln.weight, layer.attn_ln.eps)
+            q = F_.rope_kv_write(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
+                                 cache.k[i], cache.v[i], H, G, D)
+            if S == 1:
+                att = F_.decode_attention(q, cache.k[i], cache.v[i], mask, H, G, D)
+            else:
+                att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i], cache.v[i], mask)
+            h, x = F_.add_rmsnorm(h, layer.attn.o_proj(att), layer.ffn_ln.weight, layer.ffn_ln.eps)
+            delta = layer.ffn.w_out(F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim))
+        if last_only:
+            h, delta = h[:, -1:], delta[:, -1:]
+        _, x = F_.add_rmsnorm(h, delta, self.final_ln.weight, self.final_ln.eps)
+        return self.lm_head(x)
+
+    # -- reference-shaped call ----------------------------------------------------------------------
+    def forward(self, input_ids: Optional[Tensor] = None, input_embeddings: Optional[Tensor] = None,
+                attention_mask: Optional[Tensor] = None, position_ids: Optional[Tensor] = None,
+                labels: Optional[Tensor] = None, past_key_values=None):
+        """Same contract as the reference forward (chatglm_q/model.py:329-392): returns
+        (loss, logits, current_key_values) with key/values shaped (B, T, groups, 1, d_head)."""
+        if input_embeddings is None:
+            if input_ids is None:
+                raise AssertionError("No input")
+            h = self.word_embedding(input_ids)
+        else:
+            if input_ids is not None:
+                raise AssertionError("Specify either 'input_ids' or 'input_embeddings'")
+            h = input_embeddings
+        B, S, _ = h.shape
+        device = h.device
+        past = 0 if past_key_values is None else past_key_values[0][0].shape[1]
+        T = past + S
+        if attention_mask is None:
+            attention_mask = torch.ones(B, T, dtype=torch.long, device=device)
+        if position_ids is None:
+            position_ids = torch.cumsum(attention_mask, dim=1)           # positions start at 1 (model.py:308)
+        t = torch.arange(T, device=device)
+        blocked = (t[:, None] < t[None, :])[None] | ~attention_mask[:, None, :].bool()
+        mask = (blocked.float() * -1e10)[:, -S:]                          # (B, S, T), model.py:311-317
+        cs = self._rotary(position_ids[:, -S:])
+
+        current = []
+        for i, layer in enumerate(self.layers):
+            q, k, v = layer.attn.project(layer.attn_ln(h), cs)
+            if past_key_values is not None:
+                k = torch.cat((past_key_values[i][0].squeeze(3), k), dim=1)
+                v = torch.cat((past_key_values[i][1].squeeze(3), v), dim=1)
+            current.append((k.detach().unsqueeze(3), v.detach().unsqueeze(3)))
+            h = h + layer.attn.attend(h.dtype, q, k, v, mask)
+            h = h + layer.ffn(layer.ffn_ln(h))
+        logits = self.lm_head(self.final_ln(h))
+
+        loss = None
+        if labels is not None:
+            n_classes = self.config.vocab_size
+            loss = F.cross_entropy(logits[..., :-1, :].contiguous().float().view(-1, n_classes),
+                                   labels[..., 1:].contiguous().view(-1))
+        return loss, logits, tuple(current)
+
+
+# ---- construction with quantized layers (chatglm_q/loader.py:41-66) ------------------------------
+def _build_with(linear_cls, embedding_cls, config: ChatGLM2Config, dtype):
+    import sys
+    this = sys.modules[__name__]
+    prev = this.Linear, this.Embedding
+    this.Linear, this.Embedding = linear_cls, embedding_cls
+    try:
+        return ChatGLM2Model(config, dtype)
+    finally:
+        this.Linear, this.Embedding = prev
+
+
+def create_quant_int4_model(config: ChatGLM2Config = ChatGLM2Config(), group_size: int = 32, dtype=None) -> ChatGLM2Model:
+    from .int4.qlinear import DynamicQuantizeLinear, QEmbedding
+    if group_size != 32:
+        raise AssertionError("the model graph constructs int4 layers with the default group of 32")
+    return _build_with(DynamicQuantizeLinear, QEmbedding, config, dtype)
+
+
+def create_quant_int8_model(config: ChatGLM2Config = ChatGLM2Config(), dtype=None) -> ChatGLM2Model:
+    from .int8.qlinear import DynamicQuantizeLinear, QEmbedding
+    return _build_with(DynamicQuantizeLinear, QEmbedding, config, dtype)
+
+
+@torch.no_grad()
+def fill_synthetic_(model: ChatGLM2Model, seed: int = 0) -> ChatGLM2Model:
+    """Random weights of the right format and scale (no checkpoint is available offline): uniform nibbles /
+    int8 codes, scales such that activations keep O(1) magnitude through 28 layers, unit norms."""
+    dev = model.final_ln.weight.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, buf in model.state_dict().items():
+        if buf.dtype == torch.uint8:
+            buf.copy_(torch.randint(0, 256, buf.shape, dtype=torch.uint8, device=dev, generator=g))
+        elif buf.dtype == torch.int8:
+            buf.copy_(torch.randint(-127, 128, buf.shape, dtype=torch.int8, device=dev, generator=g))
+        elif name.endswith("weight_scale"):
+            fan_in = buf.shape[0] * 32 if buf.dim() == 2 else model.config.hidden_size
+            if name.startswith("word_embedding"):
+                amp = 0.25                                             # embeddings ~ N(0, 1)
+            else:
+                amp = 1.0 / (4.6 * math.sqrt(fan_in)) if buf.dim() == 2 else 1.0 / (73.0 * math.sqrt(fan_in))
+            buf.copy_((torch.rand(buf.shape, device=dev, generator=g) * 0.5 + 0.75).to(buf.dtype) * amp)
+        elif name.endswith("bias"):
+            buf.copy_((torch.randn(buf.shape, device=dev, generator=g) * 0.02).to(buf.dtype))
+        elif name.endswith("ln.weight"):
+            buf.fill_(1.0)
+        else:
+            buf.copy_((torch.randn(buf.shape, device=dev, generator=g) * 0.02).to(buf.dtype))
+    return model

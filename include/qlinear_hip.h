@@ -137,6 +137,30 @@ int qlinear_qembedding_w4(const int64_t* ids, const uint8_t* Wq, const void* S, 
 int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, void* out,
                           int64_t count, int64_t V, int64_t D, int dtype, void* stream);
 
+/* ---- fused neighbours of the QLinear calls in one decode step ("next" row N1) ----------------------
+ * Same rounding sequence as the model graph (chatglm_q/model.py): every intermediate the reference
+ * materialises in the activation dtype is rounded to it.
+ * rmsnorm:           out[r,:] = round(round(x[r,:] * rsqrt(mean(x^2) + eps)) * w)            model.py:62-73
+ * add_rmsnorm:       h = round(x + delta) written to Hout (the block's residual add, model.py:243,245), then
+ *                    out = rmsnorm(h): one launch for both
+ * rope_kv_write:     qkv (B*S, (H+2G)*D) -> q (B*S, H*D) rotated; k (rotated), v written to the caches
+ *                    (B, capacity, G, D) at row widx[s]; table (max_pos, D/2, 2) = (cos, sin); pos (B*S)
+ *                                                                                              model.py:139-155
+ * decode_attention:  one query position: q (B, H*D), mask (B, capacity) additive fp32 -> out (B, H*D)
+ *                                                                                              model.py:157-175
+ * silu_mul:          in (rows, 2*hidden) -> out[r,i] = round(round(silu(in[r,i])) * in[r,hidden+i])   model.py:200-201 */
+int qlinear_rmsnorm(const void* X, const void* W, void* Out, int64_t rows, int64_t dim, int64_t ldx, int64_t ldo,
+                    float eps, int dtype, void* stream);
+int qlinear_add_rmsnorm(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows,
+                        int64_t dim, int64_t ld, float eps, int dtype, void* stream);
+int qlinear_rope_kv_write(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Qout,
+                          void* Kcache, void* Vcache, int64_t B, int64_t S, int64_t H, int64_t G, int64_t D,
+                          int64_t capacity, int64_t ldqkv, int dtype, void* stream);
+int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, void* Out,
+                             int64_t B, int64_t H, int64_t G, int64_t D, int64_t capacity, int dtype, void* stream);
+int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -299,7 +299,8 @@ def test_w8a8_integer_stage_exact_and_epilogue():
 
 
 @pytest.mark.parametrize("M,K,N,dt", [(512, 4096, 4096, "f16"), (70, 1024, 200, "f16"), (33, 512, 96, "bf16"),
-                                       (64, 256, 64, "f32")])
+                                       (64, 256, 64, "f32"), (1, 4096, 256, "f16"), (130, 13696, 136, "f16"),
+                                       (300, 208, 130, "f32"), (2048, 1024, 512, "bf16")])
 def test_w8a8_vs_oracle(M, K, N, dt):
     g = torch.Generator().manual_seed(M + K + N)
     w = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)
