@@ -299,17 +299,25 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
         }
     };
 
-    // ping-pong over two register tiles: a tile's registers are refilled (for two iterations later)
-    // right after its math, so one tile is always in flight under the other tile's math and no
-    // register copy ever touches a pending load
-    for (int it = 0; it < iters; it += 2) {
-        compute_tile(t0, it);
-        if (it + 2 < iters) t0 = load_tile(it + 2);
-        if (it + 1 < iters) {
-            compute_tile(t1, it + 1);
-            if (it + 3 < iters) t1 = load_tile(it + 3);
-        }
+    // ping-pong over two register tiles: a tile's registers are refilled (for two iterations later) right
+    // after its math, so one tile is always in flight under the other tile's math and no register copy ever
+    // touches a pending load.  The steady-state loop contains only UNCONDITIONAL loads of REAL tiles: a load
+    // under `if (more tiles)` leaves hipcc unable to count the loads issued after a given one (it then waits
+    // vmcnt(0), i.e. for the tile it just issued), and a dummy load past the end keeps the wave alive until
+    // it returns (measured +15 %).  The last round is peeled instead.
+    const int full = iters >> 1;
+    for (int r = 0; r + 1 < full; ++r) {
+        compute_tile(t0, 2 * r);
+        t0 = load_tile(2 * r + 2);
+        compute_tile(t1, 2 * r + 1);
+        t1 = load_tile(2 * r + 3);
     }
+    if (full > 0) {
+        compute_tile(t0, 2 * full - 2);
+        if (iters & 1) t0 = load_tile(2 * full);
+        compute_tile(t1, 2 * full - 1);
+    }
+    if (iters & 1) compute_tile(t0, iters - 1);
 
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -392,10 +400,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
 
-    PackedTileG<T> t0 = load_tile(0);
-    for (int it = 0; it < iters; ++it) {
-        PackedTileG<T> t1 = t0;
-        if (it + 1 < iters) t1 = load_tile(it + 1);
+    auto compute_tile = [&](PackedTileG<T>& t0, int it) {
         const int g = it * 64 + lane;
         const int gc = g < G ? g : G - 1;
         float m8s[4];
@@ -418,8 +423,24 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict
                     for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(a[m], wq, acc[m][c]);
                 }
             }
-        t0 = t1;
+    };
+    // two register tiles; steady-state loads unconditional and real, last round peeled
+    // (see w4_packed_gemv_16_kernel)
+    PackedTileG<T> ta = load_tile(0), tb;
+    if (iters > 1) tb = load_tile(1);
+    const int full = iters >> 1;
+    for (int r = 0; r + 1 < full; ++r) {
+        compute_tile(ta, 2 * r);
+        ta = load_tile(2 * r + 2);
+        compute_tile(tb, 2 * r + 1);
+        tb = load_tile(2 * r + 3);
     }
+    if (full > 0) {
+        compute_tile(ta, 2 * full - 2);
+        if (iters & 1) ta = load_tile(2 * full);
+        compute_tile(tb, 2 * full - 1);
+    }
+    if (iters & 1) compute_tile(ta, iters - 1);
 
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -476,12 +497,12 @@ static int env_int(const char* name, int dflt) {
 }
 
 // K slices per block: as many as keep every lane of a wave busy (>= 64 groups per slice) while the
-// grid is still small (fewer than ~8 blocks per CU); QLINEAR_W4_KSPLIT overrides for measurements.
+// grid is still small (fewer than ~4 blocks per CU); QLINEAR_W4_KSPLIT overrides for measurements.
 static int choose_ksplit(int64_t quads, int64_t G) {
     static const int forced = env_int("QLINEAR_W4_KSPLIT", 0);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     int ks = 1;
-    while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 2048) ks *= 2;
+    while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 1024) ks *= 2;
     return ks;
 }
 

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void act_quant_rowwise_kernel(const T* __restr
 //   feeds MFMA sub-step s with chunk 4 kb + s of its row for BOTH operands (a consistent K assignment).
 //   Accumulator map: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
 // =============================================================================================
-template <typename T, int MT>
+template <typename T, int MT, int DEPTH>
 __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict__ Aq, const float* __restrict__ a_scale,
                                                         const int8_t* __restrict__ W, const T* __restrict__ S,
                                                         const T* __restrict__ bias, T* __restrict__ C, int M, int N,
@@ -425,36 +425,29 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0;
 
-    i32x4 a_next[ACH], w_next[WCH];
-    auto load_tiles = [&](int kt) {
+    // register ring: the global loads of K step kt + DEPTH are issued when step kt starts, so DEPTH - 1 steps of
+    // MFMA work cover their latency.  DEPTH 4 when the grid gives ~1 block per CU (512 x 4096 x 4096: nothing
+    // else hides the latency), 2 for large grids where co-resident blocks do and registers buy occupancy.
+    i32x4 a_st[DEPTH][ACH], w_st[DEPTH][WCH];
+    auto load_tiles = [&](int kt, i32x4 (&ar)[ACH], i32x4 (&wr)[WCH]) {
         const int k = kt * 128 + c_mine * 16;
         const bool inb = k <= klast;
         const int off = inb ? kt * 128 : klast - c_mine * 16;      // clamped address for the K tail
 #pragma unroll
-        for (int u = 0; u < ACH; ++u) a_next[u] = *reinterpret_cast<const i32x4*>(a_src[u] + off);
+        for (int u = 0; u < ACH; ++u) ar[u] = *reinterpret_cast<const i32x4*>(a_src[u] + off);
 #pragma unroll
-        for (int u = 0; u < WCH; ++u) w_next[u] = *reinterpret_cast<const i32x4*>(w_src[u] + off);
-        if (!inb) {                             // zero weights make the tail contribute exactly 0
-#pragma unroll
-            for (int u = 0; u < WCH; ++u) w_next[u] = i32x4{0, 0, 0, 0};
-        }
+        for (int u = 0; u < WCH; ++u) wr[u] = *reinterpret_cast<const i32x4*>(w_src[u] + off);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt, const i32x4 (&ar)[ACH], const i32x4 (&wr)[WCH]) {
+        const bool inb = kt * 128 + c_mine * 16 <= klast;          // zero weights make the K tail contribute exactly 0
 #pragma unroll
-        for (int u = 0; u < ACH; ++u) *reinterpret_cast<i32x4*>(smem_a[buf] + a_dst[u]) = a_next[u];
+        for (int u = 0; u < ACH; ++u) *reinterpret_cast<i32x4*>(smem_a[buf] + a_dst[u]) = ar[u];
 #pragma unroll
-        for (int u = 0; u < WCH; ++u) *reinterpret_cast<i32x4*>(smem_w[buf] + w_dst[u]) = w_next[u];
+        for (int u = 0; u < WCH; ++u) *reinterpret_cast<i32x4*>(smem_w[buf] + w_dst[u]) = inb ? wr[u] : i32x4{0, 0, 0, 0};
     };
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
 
     const int wr = wave * 32 + j;              // this lane's weight row inside the block's W tile
-    for (int kt = 0; kt < ksteps; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ksteps;
-        if (more) load_tiles(kt + 1);          // in flight under this step's MFMAs
+    auto mma_step = [&](int buf) {
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const int c = kb * 4 + sub;
@@ -466,8 +459,40 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
                 acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[mt], 0, 0, 0);
             }
         }
-        if (more) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+
+    // prologue: DEPTH steps in flight (a step index past the end re-reads the last step: never stored)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_tiles(d < ksteps ? d : ksteps - 1, a_st[d], w_st[d]);
+    store_tiles(0, 0, a_st[0], w_st[0]);
+    __syncthreads();
+
+    // steady state: every load is unconditional and real (a load under `if (more)` makes hipcc wait
+    // vmcnt(0) - for the loads it just issued - before each ds_write; see w4_packed.hip)
+    int kt = 0;
+    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int buf = (kt + d) & 1;
+            if (kt + d + DEPTH < ksteps) {
+                load_tiles(kt + d + DEPTH, a_st[d], w_st[d]);      // slot d was stored to LDS last step
+            } else {
+                load_tiles(ksteps - 1, a_st[d], w_st[d]);          // harmless re-read, keeps the load count exact
+            }
+            mma_step(buf);
+            store_tiles(buf ^ 1, kt + d + 1, a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
+            __syncthreads();
+        }
+    }
+    // tail: at most DEPTH steps, no further loads
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if (kt + d < ksteps) {
+            const int buf = (kt + d) & 1;
+            mma_step(buf);
+            if (kt + d + 1 < ksteps) store_tiles(buf ^ 1, kt + d + 1, a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
+            __syncthreads();
+        }
     }
 
     const int n = n0 + wave * 32 + j;
@@ -569,8 +594,12 @@ template <typename T, int MT>
 static int launch_w8a8_mt(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
                           void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
-    w8a8_mfma_kernel<T, MT><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N,
-                                                  (int)K, ldc);
+    if ((int64_t)grid.x * grid.y <= 256)
+        w8a8_mfma_kernel<T, MT, 4><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
+                                                         (int)N, (int)K, ldc);
+    else
+        w8a8_mfma_kernel<T, MT, 2><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
+                                                         (int)N, (int)K, ldc);
     return finish_launch();
 }
 

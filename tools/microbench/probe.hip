@@ -35,6 +35,32 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ src
     if (lane == 0) out[wave] = x;
 }
 
+// strided read: each wave reads NCH chunks of 1 KiB, chunk c at byte offset wave_base + c * stride16*16;
+// wave bases tile the buffer so that all bytes are read exactly once when stride == NCH-th of a block
+template <int NCH>
+__global__ __launch_bounds__(256) void stride_read_kernel(const u32x4* __restrict__ src, uint32_t* __restrict__ out,
+                                                          size_t n16, int stride16, int chunks_per_stream) {
+    // stream layout: NCH streams of `chunks_per_stream` KiB each, streams `stride16` apart, forming one block
+    // of NCH * stride16 units; wave w handles chunk (w % chunks_per_stream) of block (w / chunks_per_stream)
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t block = wave / chunks_per_stream, chunk = wave % chunks_per_stream;
+    const size_t base = block * (size_t)NCH * stride16 + chunk * 64 + lane;
+    u32x4 v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        size_t idx = base + (size_t)c * stride16;
+        if (idx >= n16) idx = lane;
+        v[c] = __builtin_nontemporal_load(src + idx);
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) x ^= v[c][0] ^ v[c][1] ^ v[c][2] ^ v[c][3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (lane == 0) out[wave] = x;
+}
+
 __global__ void empty_kernel() {}
 
 struct Timer {
@@ -129,6 +155,15 @@ int main(int argc, char** argv) {
         report("pure read nt, 4x16B/thread", us, (double)pkb);
         us = T.run(STEPS, [&](int i) { read_kernel<9, true><<<blocks, 256, 0, T.st>>>((const u32x4*)pk[0], out, n16); });
         report("pure read nt, same buffer (cache-hot)", us, (double)pkb);
+        // 8 streams per wave, each stream G*16 bytes long (one column), streams one column apart: the GEMV's pattern
+        {
+            const int stride16 = G;                      // one column = G units of 16 B
+            const int cps = (G + 63) / 64;               // 1-KiB chunks per column (last one partial -> over-read)
+            const size_t nblocks = n16 / ((size_t)8 * stride16);
+            const int waves = (int)(nblocks * cps);
+            us = T.run(STEPS, [&](int i) { stride_read_kernel<8><<<(waves + 3) / 4, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16, stride16, cps); });
+            report("strided read nt: 8 cols x 1KiB per wave", us, (double)pkb);
+        }
     }
     us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
     report("w4 packed gemv (rotating)", us, alg);
