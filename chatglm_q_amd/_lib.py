@@ -23,6 +23,9 @@ FLAG_STRICT_ROUNDING = 1
 # QLINEAR_STRICT=1: reproduce the reference's per-weight rounding bit for bit in every kernel
 STRICT_DEFAULT = os.environ.get("QLINEAR_STRICT", "0") not in ("0", "", "false", "False")
 
+PRO_SILU = 1
+PRO_ADDNORM = 2
+
 OP_W4G32_FWD = 1
 OP_W4G32_FWD_PACKED = 2
 OP_W8_FWD = 3
@@ -40,6 +43,8 @@ EXPORTS = {
     "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                          c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_fwd_packed_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                               c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),

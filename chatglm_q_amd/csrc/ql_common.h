@@ -86,6 +86,35 @@ __device__ __forceinline__ float wave_sum(float v) {
             __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
+// 8 activation-dtype values held in one 16-byte register quad <-> fp32 (16-bit dtypes only)
+template <typename T>
+__device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {
+    static_assert(sizeof(T) == 2, "16-bit activation dtypes");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        T lo, hi;
+        const uint16_t l16 = (uint16_t)(r[e] & 0xFFFFu), h16 = (uint16_t)(r[e] >> 16);
+        __builtin_memcpy(&lo, &l16, 2);
+        __builtin_memcpy(&hi, &h16, 2);
+        v[2 * e] = (float)lo;
+        v[2 * e + 1] = (float)hi;
+    }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {   // rounds each value to T
+    static_assert(sizeof(T) == 2, "16-bit activation dtypes");
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const T lo = (T)v[2 * e], hi = (T)v[2 * e + 1];
+        uint16_t l16, h16;
+        __builtin_memcpy(&l16, &lo, 2);
+        __builtin_memcpy(&h16, &hi, 2);
+        r[e] = (u32)l16 | ((u32)h16 << 16);
+    }
+    return r;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace ql

@@ -114,11 +114,25 @@ struct PackedTile16 {
 // KS: the block's 4 waves cover 4/KS column quads x KS slices of K (combined through LDS at the end):
 // shapes with few columns but a long K (w_out: 13696 -> 4096) get 4x the workgroups and 4x the loads
 // in flight per column instead of one wave walking 7 tiles in sequence.
-template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
+// PRO: activation prologue applied while the row is staged (decode step, one row), so that the small ops in
+// front of a QLinear call cost no launch of their own.  Rounding sequence as the graph's:
+//   PRO_SILU     the input row is (h | gate), 2K wide: staged = round(round(silu(h)) * gate)      model.py:200-201
+//   PRO_ADDNORM  hnew = round(x + delta) (delta optional), written to pro.hout by block 0;
+//                staged = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)               model.py:62-73,243-245
+enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
+struct Prologue {
+    const void* delta;      // PRO_ADDNORM: residual contribution to add first (nullable)
+    const void* ln_weight;  // PRO_ADDNORM
+    void* hout;             // PRO_ADDNORM: updated residual stream
+    float eps;
+};
+
+template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
 __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
                                                                 const T* __restrict__ Sp, const T* __restrict__ bias,
                                                                 T* __restrict__ C, int M, int N, int K, int G,
-                                                                int64_t lda, int64_t ldc) {
+                                                                int64_t lda, int64_t ldc, Prologue pro) {
+    static_assert(PRO == PRO_NONE || (MB == 1 && ACH > 0), "prologues exist for the one-row LDS-staged kernel");
     static_assert(!STRICT || Act<T>::code == QL_DTYPE_F16, "strict rounding mode exists for fp16 only");
     constexpr bool A_LDS = ACH > 0;
     typedef Splice<T> SP;
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 
     // (1) activation staging loads first: oldest in the VM queue
     u32x4 areg[A_LDS ? ACH : 1];
+    u32x4 xreg[PRO != PRO_NONE ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // prologue operands
     if constexpr (A_LDS && VAR != 4) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
@@ -156,6 +171,11 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             const int c = min(tid + i * 256, MB * cpr - 1);
             const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
             areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
+            if constexpr (PRO == PRO_SILU) xreg[i] = *reinterpret_cast<const u32x4*>(arow[0] + K + cc * 8);
+            if constexpr (PRO == PRO_ADDNORM) {
+                xreg[i] = *reinterpret_cast<const u32x4*>((const T*)pro.ln_weight + cc * 8);
+                yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const T*)pro.delta : arow[0]) + cc * 8);
+            }
         }
     }
 
@@ -185,6 +205,50 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     if (iters > 1) t1 = load_tile(1);          // wave-uniform branch around the whole tile
 
     // (3) stage the activations (waits only for the staging loads, which are older than the tiles)
+    if constexpr (PRO == PRO_SILU) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            float h[8], g[8];
+            unpack8<T>(areg[i], h);
+            unpack8<T>(xreg[i], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = Act<T>::round(h[e] / (1.0f + __expf(-h[e]))) * g[e];
+            areg[i] = pack8<T>(h);
+        }
+    }
+    if constexpr (PRO == PRO_ADDNORM) {
+        float* nred = reinterpret_cast<float*>(smem + (((size_t)K * sizeof(T) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float));
+        float hv[ACH][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            float d[8];
+            unpack8<T>(areg[i], hv[i]);
+            unpack8<T>(yreg[i], d);
+            const int c = tid + i * 256;
+            if (pro.delta) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[i][e] = Act<T>::round(hv[i][e] + d[e]);
+            }
+            if (c < cpr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[i][e], hv[i][e], ss);
+                if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((T*)pro.hout + c * 8) = pack8<T>(hv[i]);
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) nred[wave] = ss;
+        __syncthreads();
+        const float r = rsqrtf(((nred[0] + nred[1]) + (nred[2] + nred[3])) / (float)K + pro.eps);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            float w[8];
+            unpack8<T>(xreg[i], w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[i][e] = Act<T>::round(hv[i][e] * r) * w[e];
+            areg[i] = pack8<T>(hv[i]);
+        }
+    }
     if constexpr (A_LDS && VAR != 4) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
@@ -519,21 +583,21 @@ static int launch_16(const PackedArgs& p) {
 #ifdef QL_DEV_VARIANTS
     if constexpr (MB == 1 && !STRICT) {
         if (dev_variant() == 1) {
-            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 1><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 1><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
             return finish_launch();
         }
         if (dev_variant() == 2) {
-            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 2><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 2><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
             return finish_launch();
         }
         if (dev_variant() == 4) {
-            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 4><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 4><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
             return finish_launch();
         }
     }
 #endif
     w4_packed_gemv_16_kernel<T, MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias,
-                                                                               (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc);
+                                                                               (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
     return finish_launch();
 }
 
@@ -577,6 +641,54 @@ static int launch_generic_mb(const PackedArgs& p) {
     w4_packed_gemv_kernel<T, MB><<<grid, 256, 0, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N,
                                                          p.K, (int)G, p.lda, p.ldc);
     return finish_launch();
+}
+
+// one-row forward with an activation prologue (decode step)
+template <typename T, int ACH, int KS, int PRO>
+static int launch_16_pro(const PackedArgs& p, const Prologue& pro) {
+    const int64_t G = p.K / 32, Npad = (p.N + 3) & ~(int64_t)3;
+    const u32x4* Wt = (const u32x4*)p.packed;
+    const T* Sp = (const T*)((const char*)p.packed + Npad * G * 16);
+    const int quads = (int)(Npad / 4);
+    constexpr int QW = 4 / KS;
+    dim3 grid((unsigned)((quads + QW - 1) / QW), 1);
+    const size_t lds = (((size_t)p.K * sizeof(T) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float) + 4 * sizeof(float);
+    w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 0, PRO><<<grid, 256, lds, p.st>>>(
+        (const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, 1, p.N, p.K, (int)G, p.lda, p.ldc, pro);
+    return finish_launch();
+}
+
+template <typename T, int PRO>
+static int launch_16_pro_any(const PackedArgs& p, const Prologue& pro) {
+    const int64_t chunks = p.K / 8, Npad = (p.N + 3) & ~(int64_t)3;
+    if ((size_t)p.K * sizeof(T) > 60 * 1024 || chunks > 8 * 256) return QL_ERR_UNSUPPORTED;
+    const int ks = choose_ksplit(Npad / 4, p.K / 32);
+#define QL_PRO(ACH_)                                                        \
+    switch (ks) {                                                           \
+    case 4: return launch_16_pro<T, ACH_, 4, PRO>(p, pro);                  \
+    case 2: return launch_16_pro<T, ACH_, 2, PRO>(p, pro);                  \
+    default: return launch_16_pro<T, ACH_, 1, PRO>(p, pro);                 \
+    }
+    if (chunks <= 2 * 256) { QL_PRO(2) }
+    if (chunks <= 4 * 256) { QL_PRO(4) }
+    QL_PRO(8)
+#undef QL_PRO
+}
+
+int w4_packed_fused(int dtype, int kind, const void* A, const void* packed, const void* bias, void* C, int64_t N,
+                    int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
+    const PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, false, st};
+    const Prologue pro{delta, ln_weight, hout, eps};
+    if (dtype == QL_DTYPE_F16) {
+        if (kind == PRO_SILU) return launch_16_pro_any<f16, PRO_SILU>(p, pro);
+        if (kind == PRO_ADDNORM) return launch_16_pro_any<f16, PRO_ADDNORM>(p, pro);
+    } else if (dtype == QL_DTYPE_BF16) {
+        if (kind == PRO_SILU) return launch_16_pro_any<__bf16, PRO_SILU>(p, pro);
+        if (kind == PRO_ADDNORM) return launch_16_pro_any<__bf16, PRO_ADDNORM>(p, pro);
+    } else {
+        return QL_ERR_BAD_DTYPE;
+    }
+    return QL_ERR_UNSUPPORTED;
 }
 
 int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {

@@ -116,6 +116,25 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     return c.reshape(out_shape)
 
 
+def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None = None,
+                     delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
+                     eps: float = 0.0) -> Tensor:
+    """One-row forward with an activation prologue (``_lib.PRO_SILU`` / ``_lib.PRO_ADDNORM``) on the derived layout.
+    ``a``: (..., K) for ADDNORM, (..., 2K) for SILU, exactly one row.  Returns (..., n_out)."""
+    lib = _lib.get_lib()
+    K = a.shape[-1] // 2 if kind == _lib.PRO_SILU else a.shape[-1]
+    if a.numel() != a.shape[-1]:
+        raise ValueError("fused prologues serve exactly one activation row")
+    a = a.contiguous()
+    c = torch.empty((*a.shape[:-1], n_out), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_packed_fused(kind, a.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                                n_out, K, _lib.ptr(delta), _lib.ptr(ln_weight), _lib.ptr(hout),
+                                                float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w4g32_fwd_packed_fused")
+    return c
+
+
 def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
     """Same contract as the reference wrapper (chatglm_q/int4/triton_ops.py:90-139).
 

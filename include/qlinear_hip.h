@@ -107,6 +107,18 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
                              int64_t ldc, int dtype, int flags, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* One-row (decode) forward on the derived layout with an activation PROLOGUE fused into the staging of the
+ * activation row, so that the small op in front of the QLinear call costs no launch of its own (SURVEY.md 8f
+ * N1).  fp16 / bf16, group 32, exact-dequant arithmetic.  Rounding sequence as the model graph's:
+ *   QL_PRO_SILU     A is (h | gate), 2K values: row = round(round(silu(h)) * gate)            chatglm_q/model.py:200-201
+ *   QL_PRO_ADDNORM  hnew = round(A + delta) (delta nullable), written to hout (nullable);
+ *                   row = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)          chatglm_q/model.py:62-73,243-245 */
+#define QL_PRO_SILU 1
+#define QL_PRO_ADDNORM 2
+int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* packed, const void* bias, void* C,
+                                   int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout,
+                                   float eps, int dtype, void* stream);
+
 /* ---- int8 per-output-channel weights -------------------------------------------------------
  * W  int8, logical (K, N) with element strides (ldw_k, ldw_n) - exactly what the reference
  *    wrapper receives: the module passes weight.t() of its (N, K) row-major buffer, i.e.

@@ -90,3 +90,43 @@ def test_fused_ops_unit_shapes():
     want = attn.core(torch.float16, q.view(B, 1, Gq, H // Gq, D), kc, vc, mask)
     got = F_.decode_attention(q, kc, vc, mask, H, Gq, D)
     assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_prologues_equal_separate_ops(dtype):
+    """qlinear_w4g32_fwd_packed_fused (add + RMSNorm / SiLU * gate inside the GEMV's activation staging) against
+    the separate launches, at ChatGLM2-6B layer shapes."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(21)
+    for K, N, bias in ((4096, 4608, True), (4096, 27392, False)):
+        layer = DynamicQuantizeLinear(K, N, bias=bias, dtype=dtype, device=DEV)
+        layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        if bias:
+            layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+        layer.prepare()
+        h = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        d = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        w = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+        for delta in (d, None):
+            hout = torch.empty_like(h)
+            got = H4.w4_forward_fused(_lib.PRO_ADDNORM, h, layer._packed, N, layer.bias, delta, w, hout, 1e-5)
+            if delta is None:
+                want_h, x = h, F_.rmsnorm(h, w, 1e-5)
+            else:
+                want_h, x = F_.add_rmsnorm(h, delta, w, 1e-5)
+            with torch.no_grad():
+                want = layer(x)
+            assert torch.equal(hout, want_h)
+            assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+    layer = DynamicQuantizeLinear(13696, 4096, bias=False, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    layer.prepare()
+    y = torch.randn(1, 1, 2 * 13696, device=DEV, generator=g).to(dtype)
+    got = H4.w4_forward_fused(_lib.PRO_SILU, y, layer._packed, 4096)
+    with torch.no_grad():
+        want = layer(F_.silu_mul(y, 13696))
+    assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
