@@ -345,12 +345,35 @@ def gen_model():
     np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **d)
 
 
+def gen_loader():
+    """config.json text, state_dict key order and the greedy shard plan of the reference for a tiny model
+    (chatglm_q/loader.py:16-38,139-150) - pins the build's checkpoint-folder writer/reader."""
+    import json
+    from chatglm_q.loader import ChatGLMLoadConfig, create_quant_int4_model
+    from chatglm_q.model import ChatGLM2Config
+    cfg = ChatGLM2Config(hidden_size=128, inner_hidden_size=224, head_hidden_size=32, num_multi_query_groups=2,
+                         num_attention_heads=4, num_layers=2, vocab_size=256, max_sequence_length=64)
+    lc = ChatGLMLoadConfig(model_config=cfg, quant_type="int4g32",
+                           weight_files=["model_weights_0.safetensors", "model_weights_1.safetensors"], torch_dtype="float16")
+    m = create_quant_int4_model(cfg, dtype=torch.float16)
+    mapping, idx, size = {}, 0, 0
+    for name, w in m.state_dict().items():           # the loop of save_model_and_tokenizer with a 40 kB shard limit
+        s = w.element_size() * w.numel()
+        if size + s > 40000:
+            idx += 1
+            size = 0
+        size += s
+        mapping[name] = f"model_weights_{idx}.safetensors"
+    json.dump({"config_json": lc.to_json(), "shard_mapping_40000": mapping, "state_keys": list(m.state_dict().keys())},
+              open(os.path.join(OUT, "loader_format.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "loader"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model}[w]()
+         "embedding": gen_embedding, "model": gen_model, "loader": gen_loader}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

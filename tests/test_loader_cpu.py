@@ -1,0 +1,40 @@
+"""Checkpoint folder format (config.json + safetensors shards) against the reference's own output."""
+import json
+import os
+
+import torch
+
+from chatglm_q_amd import loader as L
+from chatglm_q_amd import model as M
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "loader_format.json")))
+
+
+def tiny_cfg():
+    return M.ChatGLM2Config(hidden_size=128, inner_hidden_size=224, head_hidden_size=32, num_multi_query_groups=2,
+                            num_attention_heads=4, num_layers=2, vocab_size=256, max_sequence_length=64)
+
+
+def test_config_json_text_and_shard_plan_match_reference():
+    lc = L.ChatGLMLoadConfig(model_config=tiny_cfg(), quant_type="int4g32",
+                             weight_files=["model_weights_0.safetensors", "model_weights_1.safetensors"], torch_dtype="float16")
+    assert lc.to_json() == GOLD["config_json"]
+    back = L.ChatGLMLoadConfig.from_json(GOLD["config_json"])
+    assert back.model_config == tiny_cfg() and back.quant_type == "int4g32" and back.get_torch_dtype() == torch.float16
+    model = L.build_model(lc)
+    assert list(model.state_dict().keys()) == GOLD["state_keys"]
+    assert L.shard_plan(model.state_dict(), 40000) == GOLD["shard_mapping_40000"]
+
+
+def test_save_load_roundtrip(tmp_path):
+    lc = L.ChatGLMLoadConfig(model_config=tiny_cfg(), quant_type="int4g32", torch_dtype="float32")
+    model = M.fill_synthetic_(L.build_model(lc), seed=3)
+    L.save_model(tmp_path, lc, model, shard=True, max_shard_bytes=40000)
+    assert len(lc.weight_files) > 1 and (tmp_path / "config.json").exists()
+    lc2, model2 = L.load_model(tmp_path)
+    assert lc2.weight_files == lc.weight_files
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    ids = torch.randint(0, 256, (1, 6))
+    with torch.no_grad():
+        assert torch.equal(model(input_ids=ids)[1], model2(input_ids=ids)[1])
