@@ -124,7 +124,6 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, int flags,
                    void* workspace, size_t workspace_bytes, void* stream) {
-    (void)flags;
     (void)workspace;
     (void)workspace_bytes;
     if (!A || !W || !S || !C) return QL_ERR_NULL_POINTER;
@@ -134,7 +133,7 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     hipStream_t st = (hipStream_t)stream;
     const bool k_contig = ldw_k == 1 && ldw_n >= K;
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
-        return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, st);
+        return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, st);
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);
 }
 

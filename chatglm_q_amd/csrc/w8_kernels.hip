@@ -9,6 +9,8 @@
 //                            channels and streams their rows with 16-byte loads (decode shapes)
 //   act_quant_rowwise_kernel row-wise symmetric int8 activation quantisation (fp32 arithmetic)
 //   w8a8_mfma_kernel         i8 x i8 -> i32 on v_mfma_i32_32x32x32_i8, rank-1 scale epilogue
+#include <stdlib.h>
+
 #include "launch.h"
 #include "ql_common.h"
 
@@ -79,7 +81,13 @@ __device__ __forceinline__ u32x4 pair_even_odd(u32x4 x) {
     return y;
 }
 
-template <int MB, int ACH>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
+// STRICT: every weight b * s is rounded to fp16 before the dot (the reference's sequence, chatglm_q/int8/
+// triton_ops.py:70).  Otherwise ("exact-dequant", default) the spliced offset form 1152 + b feeds v_dot2c as is
+// and s * (sum a (1152 + b) - 1152 sum a) is applied once per output channel and 16-k chunk: 6 instead of 10
+// VALU ops per 4 weights, closer to real arithmetic, ~2e-4 relative from the reference (see w4_packed.hip).
+// KS: the block's 4 waves cover 4/KS channel quads x KS slices of K (combined through LDS at the end), so that a
+// 4096 x 4096 layer gives 2 blocks per CU instead of 1 (see w4_packed.hip).
+template <int MB, int ACH, int KS, bool STRICT>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
 __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict__ A, const int8_t* __restrict__ W,
                                                           const f16* __restrict__ S, const f16* __restrict__ bias,
                                                           f16* __restrict__ C, int M, int N, int K, int64_t ldw,
@@ -87,13 +95,18 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     constexpr bool A_LDS = ACH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb_raw = (blockIdx.x * 4 + wave) * 4;
+    constexpr int QW = 4 / KS;
+    const int ks = wave % KS;
+    const int nb_raw = (blockIdx.x * QW + wave / KS) * 4;
     const bool wave_active = nb_raw < N;
     const int nb = wave_active ? nb_raw : 0;
     const int m0 = blockIdx.y * MB;
     const int kvec = K & ~15;                  // part of K covered by 16-byte units
-    const int nchunks = kvec >> 4;             // lane-chunks (16 k each)
-    const int iters = (nchunks + 127) >> 7;    // tiles of 128 lane-chunks
+    const int nchunks_all = kvec >> 4;         // lane-chunks (16 k each) in a row
+    const int cps = (nchunks_all + KS - 1) / KS;                   // lane-chunks per K slice
+    const int c_begin = ks * cps;
+    const int nchunks = min(nchunks_all, c_begin + cps);           // end of this wave's slice
+    const int iters = nchunks > c_begin ? (nchunks - c_begin + 127) >> 7 : 0;    // tiles of 128 lane-chunks
     const int ppr = kvec >> 3;                 // 16-byte activation pieces per row
 
     const f16* arow[MB];
@@ -119,8 +132,8 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
         W8Tile<MB, A_LDS> tl;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int lc = it * 128 + u * 64 + lane;
-            const int lcc = lc < nchunks ? lc : (nchunks > 0 ? nchunks - 1 : 0);
+            const int lc = c_begin + it * 128 + u * 64 + lane;
+            const int lcc = lc < nchunks ? lc : (nchunks_all > 0 ? nchunks_all - 1 : 0);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 tl.w[c][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[c] + (int64_t)lcc * 16));
@@ -136,10 +149,8 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     };
 
     W8Tile<MB, A_LDS> t0, t1;
-    if (iters > 0) {
-        t0 = load_tile(0);
-        t1 = load_tile(iters > 1 ? 1 : 0);
-    }
+    if (iters > 0) t0 = load_tile(0);
+    if (iters > 1) t1 = load_tile(1);
 
     if constexpr (A_LDS) {
 #pragma unroll
@@ -160,6 +171,11 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
 
+    // splice constants in registers: (t & mask) | magic is then ONE v_and_or_b32
+    u32 k_mask, k_magic;
+    asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
+
     h2 s2[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -170,9 +186,9 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     auto compute_tile = [&](const W8Tile<MB, A_LDS>& tl, int it) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int lc = it * 128 + u * 64 + lane;
+            const int lc = c_begin + it * 128 + u * 64 + lane;
             const bool valid = lc < nchunks;
-            const int lcc = valid ? lc : (nchunks > 0 ? nchunks - 1 : 0);
+            const int lcc = valid ? lc : (nchunks_all > 0 ? nchunks_all - 1 : 0);
             h2 a02[MB][4], a13[MB][4];
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -188,41 +204,84 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
                     a02[m][2 * j + 1] = as_h2(y[2]);
                     a13[m][2 * j + 1] = as_h2(y[3]);
                 }
+            if constexpr (STRICT) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const h2 sc2 = valid ? s2[c] : h2{(f16)0.f, (f16)0.f};   // out-of-range lanes contribute 0
+                for (int c = 0; c < 4; ++c) {
+                    const h2 sc2 = valid ? s2[c] : h2{(f16)0.f, (f16)0.f};   // out-of-range lanes contribute 0
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const BytePairs b = byte_pairs_f16(tl.w[c][u][j]);
-                    const h2 w02 = b.p02 * sc2, w13 = b.p13 * sc2;       // rounded to fp16 (faithful)
+                    for (int j = 0; j < 4; ++j) {
+                        const BytePairs b = byte_pairs_f16(tl.w[c][u][j]);
+                        const h2 w02 = b.p02 * sc2, w13 = b.p13 * sc2;       // rounded to fp16 (faithful)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        float v = acc[m][c];
-                        v = __builtin_amdgcn_fdot2(w02, a02[m][j], v, false);
-                        v = __builtin_amdgcn_fdot2(w13, a13[m][j], v, false);
-                        acc[m][c] = v;
+                        for (int m = 0; m < MB; ++m) {
+                            float v = acc[m][c];
+                            v = __builtin_amdgcn_fdot2(w02, a02[m][j], v, false);
+                            v = __builtin_amdgcn_fdot2(w13, a13[m][j], v, false);
+                            acc[m][c] = v;
+                        }
                     }
+                }
+            } else {
+                const h2 ones = {(f16)1.0f, (f16)1.0f};
+                float corr[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    float e = 0.f, o = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e = __builtin_amdgcn_fdot2(ones, a02[m][j], e, false);
+                        o = __builtin_amdgcn_fdot2(ones, a13[m][j], o, false);
+                    }
+                    corr[m] = 1152.0f * (e + o);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float scf = valid ? (float)s2[c].x : 0.f;          // out-of-range lanes contribute 0
+                    float e[MB], o[MB];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) e[m] = o[m] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u32 t = tl.w[c][u][j] ^ 0x80808080u;
+                        const h2 x02 = as_h2((t & k_mask) | k_magic);         // (1152 + b0, 1152 + b2)
+                        const h2 x13 = as_h2(((t >> 8) & k_mask) | k_magic);  // (1152 + b1, 1152 + b3)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) {
+                            e[m] = __builtin_amdgcn_fdot2(x02, a02[m][j], e[m], false);
+                            o[m] = __builtin_amdgcn_fdot2(x13, a13[m][j], o[m], false);
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(scf, (e[m] + o[m]) - corr[m], acc[m][c]);
                 }
             }
         }
     };
 
-    for (int it = 0; it < iters; it += 2) {
-        compute_tile(t0, it);
-        if (it + 2 < iters) t0 = load_tile(it + 2);
-        if (it + 1 < iters) {
-            compute_tile(t1, it + 1);
-            if (it + 3 < iters) t1 = load_tile(it + 3);
-        }
+    // steady-state loads unconditional and real, last round peeled (see w4_packed.hip)
+    const int full = iters >> 1;
+    for (int r = 0; r + 1 < full; ++r) {
+        compute_tile(t0, 2 * r);
+        t0 = load_tile(2 * r + 2);
+        compute_tile(t1, 2 * r + 1);
+        t1 = load_tile(2 * r + 3);
     }
+    if (full > 0) {
+        compute_tile(t0, 2 * full - 2);
+        if (iters & 1) t0 = load_tile(2 * full);
+        compute_tile(t1, 2 * full - 1);
+    }
+    if (iters & 1) compute_tile(t0, iters - 1);
 
-    // K tail (K % 16): one element per lane
-    for (int k = kvec + lane; k < K; k += 64) {
+    // K tail (K % 16): one element per lane, done by slice 0
+    if (ks == 0) {
+        for (int k = kvec + lane; k < K; k += 64) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f16 wq = (f16)((float)wrow[c][k] * (float)s2[c].x);
+            for (int c = 0; c < 4; ++c) {
+                const f16 wq = (f16)((float)wrow[c][k] * (float)s2[c].x);
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf((float)arow[m][k], (float)wq, acc[m][c]);
+                for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf((float)arow[m][k], (float)wq, acc[m][c]);
+            }
         }
     }
 
@@ -231,7 +290,26 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[m][c] = wave_sum(acc[m][c]);
 
-    if (wave_active && lane == 0) {
+    if constexpr (KS > 1) {
+        float* red = reinterpret_cast<float*>(smem + (A_LDS ? (((size_t)MB * kvec * sizeof(f16) + 15) & ~(size_t)15) : 0));
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[(wave * MB + m) * 4 + c] = acc[m][c];
+        }
+        __syncthreads();
+        if (ks == 0 && lane == 0) {
+#pragma unroll
+            for (int p = 1; p < KS; ++p)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[m][c] += red[((wave + p) * MB + m) * 4 + c];
+        }
+    }
+
+    if (wave_active && ks == 0 && lane == 0) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m0 + m >= M) break;
@@ -526,6 +604,7 @@ static int launch_w8_generic(const void* A, const int8_t* W, const void* S, cons
 }
 
 struct W8Args {
+    bool strict;
     const void* A;
     const int8_t* W;
     const void* S;
@@ -545,24 +624,40 @@ static int launch_w8_gemv_generic(const W8Args& p) {
     return finish_launch();
 }
 
-template <int MB, int ACH>
+template <int MB, int ACH, int KS, bool STRICT>
 static int launch_w8_gemv_f16(const W8Args& p) {
     const int quads = (p.N + 3) / 4;
-    dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
-    const size_t lds = ACH > 0 ? (size_t)MB * (p.K & ~15) * sizeof(f16) : 0;
-    w8_gemv_f16_kernel<MB, ACH><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S, (const f16*)p.bias,
+    constexpr int QW = 4 / KS;
+    dim3 grid((unsigned)((quads + QW - 1) / QW), (unsigned)((p.M + MB - 1) / MB));
+    const size_t lds = (ACH > 0 ? (((size_t)MB * (p.K & ~15) * sizeof(f16) + 15) & ~(size_t)15) : 0) +
+                       (KS > 1 ? (size_t)4 * MB * 4 * sizeof(float) : 0);
+    w8_gemv_f16_kernel<MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S, (const f16*)p.bias,
                                                           (f16*)p.C, p.M, p.N, p.K, p.ldw, p.lda, p.ldc);
     return finish_launch();
 }
 
-template <int MB>
-static int launch_w8_gemv_f16_mb(const W8Args& p) {
+template <int MB, bool STRICT>
+static int launch_w8_gemv_f16_st(const W8Args& p) {
     const int64_t pieces = (int64_t)MB * ((p.K & ~15) / 8);
     const bool lds_ok = (size_t)MB * p.K * sizeof(f16) <= 64 * 1024 && pieces > 0;
-    if (lds_ok && pieces <= 2 * 256) return launch_w8_gemv_f16<MB, 2>(p);
-    if (lds_ok && pieces <= 4 * 256) return launch_w8_gemv_f16<MB, 4>(p);
-    if (lds_ok && pieces <= 8 * 256) return launch_w8_gemv_f16<MB, 8>(p);
-    return launch_w8_gemv_f16<MB, 0>(p);
+    // split K two ways inside the block while the plain grid is small and every lane keeps >= 1 chunk
+    static const int forced = [] { const char* e = getenv("QLINEAR_W8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int64_t quads = (p.N + 3) / 4;
+    const bool split = forced ? forced == 2 : ((p.K >> 4) >= 128 && quads / 2 < 1024);
+    if (split) {
+        if (lds_ok && pieces <= 2 * 256) return launch_w8_gemv_f16<MB, 2, 2, STRICT>(p);
+        if (lds_ok && pieces <= 4 * 256) return launch_w8_gemv_f16<MB, 4, 2, STRICT>(p);
+        if (lds_ok && pieces <= 8 * 256) return launch_w8_gemv_f16<MB, 8, 2, STRICT>(p);
+        return launch_w8_gemv_f16<MB, 0, 2, STRICT>(p);
+    }
+    if (lds_ok && pieces <= 2 * 256) return launch_w8_gemv_f16<MB, 2, 1, STRICT>(p);
+    if (lds_ok && pieces <= 4 * 256) return launch_w8_gemv_f16<MB, 4, 1, STRICT>(p);
+    if (lds_ok && pieces <= 8 * 256) return launch_w8_gemv_f16<MB, 8, 1, STRICT>(p);
+    return launch_w8_gemv_f16<MB, 0, 1, STRICT>(p);
+}
+template <int MB>
+static int launch_w8_gemv_f16_mb(const W8Args& p) {
+    return p.strict ? launch_w8_gemv_f16_st<MB, true>(p) : launch_w8_gemv_f16_st<MB, false>(p);
 }
 
 static int launch_w8_gemv_any(int dtype, const W8Args& p) {
@@ -626,8 +721,8 @@ int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const v
     QL_DISPATCH_DTYPE(dtype, launch_w8_generic, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st)
 }
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
-            int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    const W8Args p{A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st};
+            int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, bool strict, hipStream_t st) {
+    const W8Args p{strict, A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st};
     return launch_w8_gemv_any(dtype, p);
 }
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,

@@ -256,8 +256,9 @@ W8_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("strict", [False, True])
 @pytest.mark.parametrize("M,K,N,dt,has_bias", W8_SHAPES)
-def test_int8_vs_oracle(M, K, N, dt, has_bias):
+def test_int8_vs_oracle(M, K, N, dt, has_bias, strict):
     g = torch.Generator().manual_seed(K + N)
     w = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g)
     sc = ((torch.rand(N, generator=g) - 0.3) * 0.01).to(TDT[dt])       # some negative scales
@@ -268,8 +269,11 @@ def test_int8_vs_oracle(M, K, N, dt, has_bias):
     layer.apply_weights_(w, sc, bias)
     layer = layer.to(DEV)
     with torch.no_grad():
-        out = layer(a.to(DEV))
+        out = h8.w8_forward(a.to(DEV), layer.weight.t(), layer.weight_scale, layer.bias, strict=strict)
+        assert torch.equal(layer(a.to(DEV)), h8.w8_forward(a.to(DEV), layer.weight.t(), layer.weight_scale, layer.bias))
     assert_close(out, ref, dt, f"{M}x{K}x{N}")
+    if strict and dt == "f16":
+        assert O.rel_l2(t2n(out), ref) <= 1.5e-4
 
 
 def test_w8a8_integer_stage_exact_and_epilogue():
