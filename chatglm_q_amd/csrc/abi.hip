@@ -230,4 +230,12 @@ int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, in
     return silu_mul(dtype, In, Out, rows, hidden, ldin, ldo, (hipStream_t)stream);
 }
 
+int qlinear_greedy_advance(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
+                           int64_t* pos, float* mask, int64_t capacity, int dtype, void* stream) {
+    if (!logits || !tok || !write_index || !pos || !mask) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(B) || !fits_i32(N) || !fits_i32(capacity) || ldl < N) return QL_ERR_BAD_SHAPE;
+    return greedy_advance(dtype, logits, B, N, ldl, tok, write_index, pos, mask, capacity, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -267,6 +267,47 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ In,
     store8<T>(o + i, y);
 }
 
+// ---------------------------------------------------------------------------------------------
+// greedy step bookkeeping in ONE launch (block = batch row): tok = argmax(logits row) (lowest index wins
+// ties, as torch.argmax), pos += 1; block 0 also advances the shared cache write index and unmasks that
+// position in every row's mask (the next position may attend to itself).
+// Replaces torch's argmax (a 23 us single-block reduction at 65024 logits), a copy, an index_fill and two adds.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void greedy_advance_kernel(const T* __restrict__ logits, int N, int64_t ldl,
+                                                              int64_t* __restrict__ tok, int64_t* __restrict__ write_index,
+                                                              int64_t* __restrict__ pos, float* __restrict__ mask, int capacity) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const T* row = logits + (int64_t)blockIdx.x * ldl;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 1024) {
+        const float v = Act<T>::load(row + i);
+        if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        tok[blockIdx.x] = besti;
+        pos[blockIdx.x] += 1;
+        if (blockIdx.x == 0) {                       // the shared write index and every row's mask: one writer, no race
+            const int64_t nw = write_index[0] + 1;
+            write_index[0] = nw;
+            if (nw < capacity)
+                for (int b = 0; b < (int)gridDim.x; ++b) mask[(int64_t)b * capacity + nw] = 0.f;
+        }
+    }
+}
+
 #define QL_DT(dtype, CALL)                                        \
     switch (dtype) {                                              \
     case QL_DTYPE_F32: { typedef float T; CALL; break; }          \
@@ -332,6 +373,13 @@ int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, c
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
     QL_DT(dtype, return (launch_attention<T>(Q, Kc, Vc, mask, Out, B, H, G, D, capacity, st)))
     return QL_ERR_BAD_DTYPE;
+}
+
+int greedy_advance(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
+                   int64_t* pos, float* mask, int64_t capacity, hipStream_t st) {
+    QL_DT(dtype, (greedy_advance_kernel<T><<<(unsigned)B, 1024, 0, st>>>((const T*)logits, (int)N, ldl, tok, write_index, pos, mask,
+                                                                          (int)capacity)))
+    return finish_launch();
 }
 
 int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st) {

@@ -91,18 +91,23 @@ class DecodeSession:
         self.write_index.fill_(self.length)
         self.pos.fill_(self.length + 1)                         # positions are 1-based (model.py:308)
         self.mask.fill_(-1e10)
-        self.mask[:, :, : self.length] = 0.0
+        self.mask[:, :, : self.length + 1] = 0.0                # incl. the position the next step writes
         return logits[:, -1]
 
     # -- one decode step -------------------------------------------------------------------------------
     def _step_body(self, greedy: bool):
-        self.mask.index_fill_(2, self.write_index, 0.0)         # the new position may attend to itself
+        # invariant on entry: mask is 0 for positions <= write_index (the new position may attend to itself)
         logits = self.model.step(self.tok, self.cache, self.write_index, self.pos, self.mask, last_only=True)
         self.logits = logits[:, -1]
+        if greedy and self.logits.is_cuda and self.logits.stride(-1) == 1:
+            from . import fused_ops
+            fused_ops.greedy_advance(self.logits, self.tok, self.write_index, self.pos, self.mask)   # one launch
+            return
         if greedy:
             self.tok.copy_(self.logits.argmax(dim=-1, keepdim=True))
         self.write_index.add_(1)
         self.pos.add_(1)
+        self.mask.index_fill_(2, torch.clamp(self.write_index, max=self.capacity - 1), 0.0)
 
     @torch.no_grad()
     def capture(self, greedy: bool = True):

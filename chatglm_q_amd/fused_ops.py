@@ -81,3 +81,14 @@ def silu_mul(x: Tensor, hidden: int) -> Tensor:
                                   _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
     _lib.check(st, "qlinear_silu_mul")
     return out.reshape(*x.shape[:-1], hidden)
+
+
+def greedy_advance(logits: Tensor, tok: Tensor, write_index: Tensor, pos: Tensor, mask: Tensor):
+    """In place: tok = argmax(logits), pos += 1, write_index += 1, mask[..., new write_index] = 0 - one launch."""
+    lib = _lib.get_lib()
+    B, N = logits.shape
+    with torch.cuda.device(logits.device):
+        st = lib.qlinear_greedy_advance(logits.data_ptr(), B, N, logits.stride(0), tok.data_ptr(), write_index.data_ptr(),
+                                        pos.data_ptr(), mask.data_ptr(), mask.shape[-1], _lib.dtype_code(logits.dtype),
+                                        _lib.stream_ptr(logits.device))
+    _lib.check(st, "qlinear_greedy_advance")

@@ -172,6 +172,10 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
                              int64_t B, int64_t H, int64_t G, int64_t D, int64_t capacity, int dtype, void* stream);
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream);
+/* greedy decode bookkeeping in one launch (chatglm_q/decoder.py:85,97 with temperature -> 0): tok[b] = argmax of logits
+ * row b (lowest index on ties), pos[b] += 1, write_index[0] += 1, mask[b][new write_index] = 0 for every row. */
+int qlinear_greedy_advance(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
+                           int64_t* pos, float* mask, int64_t capacity, int dtype, void* stream);
 
 #ifdef __cplusplus
 }
