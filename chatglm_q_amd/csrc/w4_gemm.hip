@@ -119,57 +119,102 @@ __global__ __launch_bounds__(256) void w4_packed_gemm_kernel(const T* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
-    auto load_a = [&](int kt, u32x4 (&regs)[CH]) {
+    // Register ring, DEPTH K-steps deep: the global loads (A chunks, this lane's weight unit AND its scale) of
+    // step kt + DEPTH are issued when step kt starts, so DEPTH - 1 steps of MFMA work cover their latency.  In
+    // the steady-state loop every load is unconditional and real, so hipcc's vmcnt waits are exact (a load
+    // under `if (more)` made it drain the queue every step; the per-step scale load sat on the critical path).
+    constexpr int DEPTH = 3;
+    typedef decltype(MM::scale_pair(scol, true)) scale_t;
+    struct Stage {
+        u32x4 a[CH];
+        u32x4 w;
+        T s;
+    };
+    Stage st[DEPTH];
+    auto load_stage = [&](int kt, Stage& sg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int c = (tid + u * 256) & 7;
             const int k = kt * 64 + c * 8;
-            // a K tail (odd group count) reads a clamped chunk; its weights are zeroed below
-            regs[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c * 8));
-        }
-    };
-    auto store_a = [&](int buf, const u32x4 (&regs)[CH]) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = regs[u];
-    };
-
-    u32x4 a_next[CH];
-    u32x4 w_cur, w_next;
-    auto load_w = [&](int kt) {
-        const int g = 2 * kt + kb;
-        return __builtin_nontemporal_load(wcol + (g < G ? g : G - 1));
-    };
-
-    load_a(0, a_next);
-    w_cur = load_w(0);
-    store_a(0, a_next);
-    __syncthreads();
-
-    for (int kt = 0; kt < ksteps; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < ksteps;
-        if (more) {
-            load_a(kt + 1, a_next);            // in flight under this step's MFMAs
-            w_next = load_w(kt + 1);
+            // a K tail (odd group count) reads a clamped chunk; its weights are zeroed at use
+            sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c * 8));
         }
         const int g = 2 * kt + kb;
-        const auto s = MM::scale_pair(scol + (int64_t)(g < G ? g : G - 1) * 4, g < G);
+        const int gc = g < G ? g : G - 1;
+        sg.w = __builtin_nontemporal_load(wcol + gc);
+        sg.s = scol[(int64_t)gc * 4];
+    };
+    auto store_a = [&](int buf, const Stage& sg) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            const typename MM::frag b = MM::dequant(w_cur[sub], k_mask_lo, k_mask_hi, k_magic, s);
+        for (int u = 0; u < CH; ++u) *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = sg.a[u];
+    };
+    auto mma_step = [&](int buf, int kt, u32x4 w_cur, T s_raw) {
+        const int g = 2 * kt + kb;
+        const T s_eff = g < G ? s_raw : (T)0.f;              // the missing half of an odd last step contributes 0
+        const scale_t s = MM::scale_pair(&s_eff, true);
+        // A fragments are read ONE SUB-STEP AHEAD of the MFMAs that consume them: with the reads issued right in
+        // front of each MFMA (what the straightforward loop compiled to) every MFMA waited out a full LDS round
+        // trip (~100+ cycles against its own 32) and the matrix pipe idled 70 % of the time
+        auto read_a = [&](int sub, u32x4 (&fr)[MT]) {
             const int c = kb * 4 + sub;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = mt * 32 + j;
-                const u32x4 av = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
-                acc[mt] = MM::mma(__builtin_bit_cast(typename MM::frag, av), b, acc[mt]);
+                fr[mt] = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+            }
+        };
+        u32x4 fa[2][MT];
+        typename MM::frag fb[2];
+        read_a(0, fa[0]);
+        fb[0] = MM::dequant(w_cur[0], k_mask_lo, k_mask_hi, k_magic, s);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            // software pipeline inside the step: while the MFMAs of sub-step `sub` run, issue the A-fragment reads
+            // and build the B fragment of sub-step sub + 1 (VALU slots under the 32-cycle MFMA shadows)
+            if (sub < 3) {
+                read_a(sub + 1, fa[(sub + 1) & 1]);
+                fb[(sub + 1) & 1] = MM::dequant(w_cur[sub + 1], k_mask_lo, k_mask_hi, k_magic, s);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]), fb[sub & 1], acc[mt]);
+            // schedule shape per sub-step: the MT reads first, then each MFMA followed by a slice of the VALU work
+            __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);            // DS reads of the next sub-step
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, (16 + MT - 1) / MT, 0);   // its share of the dequant VALU
             }
         }
-        if (more) {
-            store_a(buf ^ 1, a_next);          // the other buffer was last read one barrier ago
-            w_cur = w_next;
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_stage(d < ksteps ? d : ksteps - 1, st[d]);
+    store_a(0, st[0]);
+    __syncthreads();
+
+    int kt = 0;
+    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int buf = (kt + d) & 1;
+            const u32x4 w_cur = st[d].w;
+            const T s_cur = st[d].s;
+            // slot d: its A chunks went to LDS last step, its weight unit / scale were just copied out
+            load_stage(kt + d + DEPTH < ksteps ? kt + d + DEPTH : ksteps - 1, st[d]);
+            mma_step(buf, kt + d, w_cur, s_cur);
+            store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            __syncthreads();
         }
-        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if (kt + d < ksteps) {
+            const int buf = (kt + d) & 1;
+            mma_step(buf, kt + d, st[d].w, st[d].s);
+            if (kt + d + 1 < ksteps) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            __syncthreads();
+        }
     }
 
     // C/D map of 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
