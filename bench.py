@@ -251,7 +251,7 @@ def main():
         },
     }
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         try:
             import bench_extras
             result["extras"] = bench_extras.run(torch, device)
@@ -262,7 +262,7 @@ def main():
         if isinstance(e2e.get("graph_sync_every_token"), dict):
             # second half of BASELINE.json's metric: ChatGLM2-6B int4g32 decode tok/s (reference timing definition)
             result["decode_tok_per_s"] = e2e["graph_sync_every_token"]["gen_tok_per_s"]
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))

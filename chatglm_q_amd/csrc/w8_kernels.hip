@@ -525,17 +525,28 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
     };
 
     const int wr = wave * 32 + j;              // this lane's weight row inside the block's W tile
+    // fragments are read ONE SUB-STEP AHEAD of the MFMAs that consume them (an LDS round trip is ~100+ cycles,
+    // an MFMA 32-64): reads of sub-step s + 1 are issued before the MFMAs of sub-step s
+    auto read_frags = [&](int buf, int sub, i32x4 (&fa)[MT], i32x4& fb) {
+        const int c = kb * 4 + sub;
+        fb = *reinterpret_cast<const i32x4*>(smem_w[buf] + (wr * 8 + (c ^ ((wr >> 1) & 7))) * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = mt * 32 + j;
+            fa[mt] = *reinterpret_cast<const i32x4*>(smem_a[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+        }
+    };
     auto mma_step = [&](int buf) {
+        i32x4 fa[2][MT], fb[2];
+        read_frags(buf, 0, fa[0], fb[0]);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
-            const int c = kb * 4 + sub;
-            const i32x4 b = *reinterpret_cast<const i32x4*>(smem_w[buf] + (wr * 8 + (c ^ ((wr >> 1) & 7))) * 16);
+            if (sub < 3) read_frags(buf, sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int r = mt * 32 + j;
-                const i32x4 a = *reinterpret_cast<const i32x4*>(smem_a[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
-                acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[mt], 0, 0, 0);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[sub & 1][mt], fb[sub & 1], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 1, 0);        // next sub-step's DS reads first
+            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);            // then this sub-step's MFMAs
         }
     };
 
