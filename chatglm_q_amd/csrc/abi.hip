@@ -132,6 +132,9 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
         return QL_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const bool k_contig = ldw_k == 1 && ldw_n >= K;
+    if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype) && M > 4 && K % 16 == 0 &&
+        (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
+        return w8_gemm(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, st);   // many rows: MFMA, reference rounding
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
         return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, st);
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);

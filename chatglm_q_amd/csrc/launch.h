@@ -34,6 +34,9 @@ int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const v
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
             int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, bool strict, hipStream_t st);
+// w8_gemm.hip (M > 4, fp16 / bf16, MFMA)
+int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st);
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,

@@ -1,0 +1,241 @@
+// int8 per-channel weight-only GEMM for many activation rows (prefill / batched decode), gfx950.
+//
+//   C[M,N] = A[M,K] . (W^T * s[n])     W (N, K) int8 row-major, fp16 / bf16 activations, fp32 accumulation
+//
+// Same structure as w4_gemm.hip and the same arithmetic as the reference kernel (chatglm_q/int8/triton_ops.py:
+// 62-73): every weight b * s is ROUNDED to the activation dtype in registers, products are exact inside
+// v_mfma_f32_32x32x16_{f16,bf16}, accumulation is fp32.  Block = 4 waves x 32 output channels = 128 channels,
+// BM = 32 MT rows, K step 64.  Lane (j = lane & 31, kb = lane >> 5) owns channel j and the 32 bytes
+// k = 64 kt + 32 kb .. +31 of its weight row per step (two 16-byte loads); MFMA sub-step s uses bytes 8s..8s+7.
+// fp16: byte -> half without cvt: (b ^ 0x80) spliced under 0x6400 = 1152 + b, minus 1152, times s; the splice
+// yields the byte PAIRS (b0,b2),(b1,b3), so the A tile is staged with every 4 halves regrouped the same way
+// (a0,a2,a1,a3) - a consistent K permutation of both operands leaves the sum unchanged.
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+
+typedef _Float16 w8_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 w8_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float w8_f32x16 __attribute__((ext_vector_type(16)));
+
+// regroup the 8 halves of a 16-byte chunk as (a0,a2),(a1,a3),(a4,a6),(a5,a7)
+__device__ __forceinline__ u32x4 w8g_pair_even_odd(u32x4 x) {
+    u32x4 y;
+    y[0] = (x[0] & 0xFFFFu) | (x[1] << 16);
+    y[1] = (x[0] >> 16) | (x[1] & 0xFFFF0000u);
+    y[2] = (x[2] & 0xFFFFu) | (x[3] << 16);
+    y[3] = (x[2] >> 16) | (x[3] & 0xFFFF0000u);
+    return y;
+}
+
+template <typename T> struct W8Mma;
+template <> struct W8Mma<f16> {
+    typedef w8_f16x8 frag;
+    static constexpr bool kPairedA = true;     // A staged as (a0,a2,a1,a3 | a4,a6,a5,a7)
+    static __device__ __forceinline__ w8_f32x16 mma(frag a, frag b, w8_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    // 8 bytes (two words) -> 8 halves b * s in the paired order
+    static __device__ __forceinline__ frag dequant(u32 w0, u32 w1, u32 k_mask, u32 k_magic, float s) {
+        const h2 k1152 = {(f16)1152.0f, (f16)1152.0f};
+        const f16 sh = (f16)s;
+        const h2 s2 = {sh, sh};
+        const u32 t0 = w0 ^ 0x80808080u, t1 = w1 ^ 0x80808080u;
+        const h2 e0 = (as_h2((t0 & k_mask) | k_magic) - k1152) * s2;              // (b0, b2): exact, ONE rounding in * s
+        const h2 e1 = (as_h2(((t0 >> 8) & k_mask) | k_magic) - k1152) * s2;       // (b1, b3)
+        const h2 e2 = (as_h2((t1 & k_mask) | k_magic) - k1152) * s2;              // (b4, b6)
+        const h2 e3 = (as_h2(((t1 >> 8) & k_mask) | k_magic) - k1152) * s2;       // (b5, b7)
+        u32x4 r = {as_u32(e0), as_u32(e1), as_u32(e2), as_u32(e3)};
+        return __builtin_bit_cast(frag, r);
+    }
+};
+template <> struct W8Mma<__bf16> {
+    typedef w8_bf16x8 frag;
+    static constexpr bool kPairedA = false;    // natural K order
+    static __device__ __forceinline__ w8_f32x16 mma(frag a, frag b, w8_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag dequant(u32 w0, u32 w1, u32, u32, float s) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 w = i < 2 ? w0 : w1;
+            const int sh = 16 * (i & 1);
+            const float lo = (float)((int)(w << (24 - sh)) >> 24) * s;            // byte (2i) of the octet
+            const float hi = (float)((int)(w << (16 - sh)) >> 24) * s;            // byte (2i + 1)
+            const bf2 p = {(__bf16)lo, (__bf16)hi};                               // one rounding each (v_cvt_pk_bf16_f32)
+            r[i] = __builtin_bit_cast(u32, p);
+        }
+        return __builtin_bit_cast(frag, r);
+    }
+};
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
+                                                      const T* __restrict__ S, const T* __restrict__ bias, T* __restrict__ C,
+                                                      int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc) {
+    constexpr int BM = 32 * MT;
+    constexpr int CH = BM * 8 / 256;           // 16-byte A chunks staged per thread per K step
+    constexpr int DEPTH = 3;
+    typedef W8Mma<T> MM;
+    __shared__ __attribute__((aligned(16))) char smem[2][BM * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kb = lane >> 5;
+    const int m0 = blockIdx.y * BM;
+    const int n_raw = blockIdx.x * 128 + wave * 32 + j;
+    const int n = n_raw < N ? n_raw : N - 1;
+    const int ksteps = (K + 63) >> 6;
+
+    u32 k_mask, k_magic;
+    asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
+
+    const int8_t* wrow = W + (int64_t)n * ldw + kb * 32;
+    const float sc = Act<T>::load(S + n);
+
+    const T* a_src[CH];
+    int a_dst[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const int q = tid + u * 256;
+        const int r = q >> 3, c = q & 7;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_src[u] = A + (int64_t)row * lda + c * 8;
+        a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
+    }
+    const int kmax_a = K - 8;                  // last in-bounds 8-half chunk start
+    const int kmax_w = K - 16;                 // last in-bounds 16-byte weight chunk start
+
+    w8_f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    struct Stage {
+        u32x4 a[CH];
+        u32x4 w[2];
+    };
+    Stage st[DEPTH];
+    auto load_stage = [&](int kt, Stage& sg) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int c = (tid + u * 256) & 7;
+            const int k = kt * 64 + c * 8;
+            sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax_a ? kt * 64 : kmax_a - c * 8));   // K tail: clamped
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = kt * 64 + kb * 32 + h * 16;
+            sg.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32)));
+        }
+    };
+    auto store_a = [&](int buf, const Stage& sg) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = MM::kPairedA ? w8g_pair_even_odd(sg.a[u]) : sg.a[u];
+    };
+    auto mma_step = [&](int buf, int kt, const u32x4 (&w_in)[2]) {
+        // bytes of a K tail (k >= K) are replaced by 0: b = 0 contributes nothing whatever the (clamped) activations are
+        u32x4 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) w[h] = (kt * 64 + kb * 32 + h * 16 <= kmax_w) ? w_in[h] : u32x4{0u, 0u, 0u, 0u};
+        auto read_a = [&](int sub, u32x4 (&fr)[MT]) {
+            const int c = kb * 4 + sub;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = mt * 32 + j;
+                fr[mt] = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+            }
+        };
+        u32x4 fa[2][MT];
+        typename MM::frag fb[2];
+        read_a(0, fa[0]);
+        fb[0] = MM::dequant(w[0][0], w[0][1], k_mask, k_magic, sc);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub < 3) {
+                read_a(sub + 1, fa[(sub + 1) & 1]);
+                const int s1 = sub + 1;
+                fb[s1 & 1] = MM::dequant(w[s1 >> 1][2 * (s1 & 1)], w[s1 >> 1][2 * (s1 & 1) + 1], k_mask, k_magic, sc);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]), fb[sub & 1], acc[mt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (16 + MT - 1) / MT, 0);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_stage(d < ksteps ? d : ksteps - 1, st[d]);
+    store_a(0, st[0]);
+    __syncthreads();
+
+    int kt = 0;
+    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int buf = (kt + d) & 1;
+            const u32x4 w_cur[2] = {st[d].w[0], st[d].w[1]};
+            load_stage(kt + d + DEPTH < ksteps ? kt + d + DEPTH : ksteps - 1, st[d]);
+            mma_step(buf, kt + d, w_cur);
+            store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        if (kt + d < ksteps) {
+            const int buf = (kt + d) & 1;
+            mma_step(buf, kt + d, st[d].w);
+            if (kt + d + 1 < ksteps) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            __syncthreads();
+        }
+    }
+
+    if (n_raw < N) {
+        const T* bn = bias ? bias + n_raw : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][i], bn);
+            }
+    }
+}
+
+template <typename T, int MT>
+static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int M, int N, int K,
+                          int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
+    w8_gemm_kernel<T, MT><<<grid, 256, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda, ldc);
+    return finish_launch();
+}
+
+template <typename T>
+static int launch_w8_gemm_any(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
+                              int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+    if (M > 64) return launch_w8_gemm<T, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
+    if (M > 32) return launch_w8_gemm<T, 2>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
+    return launch_w8_gemm<T, 1>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
+}
+
+int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_w8_gemm_any<f16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_w8_gemm_any<__bf16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql

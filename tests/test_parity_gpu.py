@@ -253,6 +253,12 @@ W8_SHAPES = [
     (5, 512, 96, "f32", True),
     (128, 4096, 256, "f32", True),      # BASELINE config 1 shape (N cut for test time)
     (40, 1024, 256, "f16", False),
+    (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
+    (200, 1024, 640, "f16", False),     # MT = 4, ragged M
+    (129, 208, 136, "f16", True),       # K % 64 != 0 (K tail), ragged N
+    (2048, 4096, 256, "f16", False),    # prefill-sized M
+    (70, 13696, 128, "bf16", True),     # bf16 MFMA
+    (33, 400, 96, "bf16", False),
 ]
 
 
