@@ -58,6 +58,10 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
     case QL_OP_W4G32_FWD:
         if (group == 32 && N % 8 == 0) return w4_canon_workspace_bytes(M, N, K);
         return 0;
+    case QL_OP_W4G32_FWD_PACKED:     // optional: without it the few-row MFMA GEMM runs unsplit (slower, same results)
+        return (M > 4 && group == 32 && K % 32 == 0) ? w4_packed_gemm_workspace_bytes(M, N, K) : 0;
+    case QL_OP_W8_FWD:
+        return (M > 4 && K % 16 == 0) ? w8_gemm_workspace_bytes(M, N, K) : 0;
     default: return 0;
     }
 }
@@ -96,15 +100,13 @@ int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                              int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, int flags,
                              void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace;
-    (void)workspace_bytes;
     if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
     if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
     if (!aligned(packed, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
-    return w4_packed(dtype, A, packed, bias, C, M, N, K, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0,
-                     (hipStream_t)stream);
+    return w4_packed(dtype, A, packed, bias, C, M, N, K, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, workspace,
+                     workspace_bytes, (hipStream_t)stream);
 }
 
 int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* packed, const void* bias, void* C,
@@ -124,8 +126,6 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, int flags,
                    void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace;
-    (void)workspace_bytes;
     if (!A || !W || !S || !C) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < N || ldw_k <= 0 || ldw_n <= 0)
@@ -134,7 +134,7 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     const bool k_contig = ldw_k == 1 && ldw_n >= K;
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype) && M > 4 && K % 16 == 0 &&
         (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
-        return w8_gemm(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, st);   // many rows: MFMA, reference rounding
+        return w8_gemm(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, workspace, workspace_bytes, st);   // many rows: MFMA, reference rounding
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
         return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, st);
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);

@@ -1,5 +1,6 @@
 // Internal launcher interface between abi.hip and the kernel translation units.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -20,23 +21,60 @@ int w4_canon(int dtype, const void* A, const uint8_t* Wq, const void* S, const v
              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
 int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st);
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-              int64_t K, int64_t lda, int64_t ldc, bool strict, hipStream_t st);
+              int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st);
 
 int w4_packed_fused(int dtype, int kind, const void* A, const void* packed, const void* bias, void* C, int64_t N,
                     int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 
 // w4_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                   int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
+                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
+size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 // w8_kernels.hip
 int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
             int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, bool strict, hipStream_t st);
+// MFMA GEMM launch plan (both weight formats).  mt: tile height in units of 32 rows - the tallest tile that
+// still leaves at least two blocks per CU.  ksplit: when even 32-row tiles give fewer than one block per CU
+// (few rows: the launch is bound by the weight stream and needs memory-level parallelism, not MFMA rate), K is
+// split over blockIdx.z into fp32 slabs in the workspace and a second launch sums them.  `per` = K steps
+// (64 k each) per slab.  No or too small a workspace degrades to ksplit = 1.
+// QLINEAR_GEMM_MT / QLINEAR_GEMM_KSPLIT override (tuning sweeps).
+struct GemmPlan {
+    int mt, ksplit, per;
+};
+inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t ksteps, size_t ws_bytes) {
+    static const int forced_mt = [] { const char* e = getenv("QLINEAR_GEMM_MT"); return e ? atoi(e) : 0; }();
+    static const int forced_ks = [] { const char* e = getenv("QLINEAR_GEMM_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int64_t nb = (N + 127) / 128;
+    int mt = 1;
+    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
+    else
+        for (int t = 4; t > 1; t >>= 1)
+            if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 512) { mt = t; break; }
+    const int64_t blocks = nb * ((M + 32 * mt - 1) / (32 * mt));
+    int64_t ks = 1;
+    if (forced_ks > 0) ks = forced_ks;
+    else if (blocks < 256) ks = (256 + blocks - 1) / blocks;   // measured optimum: about one block per CU
+    if (ks > 16) ks = 16;
+    if (ks > ksteps / 4) ks = ksteps / 4;                       // at least 4 K steps per slab
+    while (ks > 1 && (size_t)(ks * M * N) * sizeof(float) > ws_bytes) --ks;
+    if (ks < 1) ks = 1;
+    const int64_t per = (ksteps + ks - 1) / ks;
+    ks = (ksteps + per - 1) / per;                               // every slab non-empty
+    return {mt, (int)ks, (int)per};
+}
+inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
+    const GemmPlan p = gemm_plan(M, N, ksteps, (size_t)-1);
+    return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(float) : 0;
+}
+
 // w8_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
-            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
+            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
+size_t w8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st);
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,

@@ -64,6 +64,41 @@ __device__ __forceinline__ void store_out(T* c, float acc, const T* bias_n) {
     Act<T>::store(c, y);
 }
 
+// XCD-aware tile order for 1-D grids.  Workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD
+// with its own L2.  Block `id` of `total` becomes position P in a tile order such that XCD c works on one
+// contiguous range of P (bijective for any total): tiles that share an operand panel share an L2.
+// nbx > 0: P runs row-major (x fastest; an XCD owns whole row tiles, the A panel is fetched once);
+// nbx < 0: P runs column-major over |nbx| columns and `nby` rows (an XCD owns whole column tiles: few-row
+// shapes, where the weights are the large operand).
+struct TileXY {
+    int x, y;
+};
+__device__ __forceinline__ TileXY xcd_tile(unsigned id, unsigned total, int nbx) {
+    const unsigned c = id & 7u, i = id >> 3, q = total >> 3, r = total & 7u;
+    const unsigned p = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + i;
+    if (nbx > 0) return {(int)(p % (unsigned)nbx), (int)(p / (unsigned)nbx)};
+    const unsigned nby = total / (unsigned)(-nbx);
+    return {(int)(p / nby), (int)(p % nby)};
+}
+// which order moves fewer bytes into the L2s: a_bytes / w_bytes are the whole operands
+inline int xcd_order(int nbx, int nby, double a_bytes, double w_bytes) {
+    const double row_major = a_bytes + w_bytes * (nby < 8 ? nby : 8), col_major = a_bytes * (nbx < 8 ? nbx : 8) + w_bytes;
+    return row_major <= col_major ? nbx : -nbx;
+}
+
+// Split-K epilogue shared by the canonical-layout kernel and the MFMA GEMMs: sum the fp32 slabs
+// partial[s][m][n], round once, add bias, store.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
+                                                            T* __restrict__ C, int M, int N, int64_t ldc, int ksplit) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += partial[((int64_t)s * M + m) * N + n];
+    store_out<T>(C + (int64_t)m * ldc + n, v, bias ? bias + n : nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-level helpers (wave64).
 // ---------------------------------------------------------------------------------------------

@@ -20,6 +20,13 @@
 #include "launch.h"
 #include "w4_dequant.h"
 
+// Developer ablation switches (tools/microbench/gemm_ablate.hip compiles this file with -DQL_GEMM_ABLATE=bits to
+// attribute loop time; always 0 in the library): 1 no dequant, 2 no steady-state weight/scale loads, 4 no MFMA,
+// 8 no steady-state A loads / LDS stores, 16 no LDS fragment reads, 32 no barriers, 64 cached (not nt) weight loads.
+#ifndef QL_GEMM_ABLATE
+#define QL_GEMM_ABLATE 0
+#endif
+
 namespace ql {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -75,83 +82,116 @@ template <> struct Mma<__bf16> {
     static constexpr u32 kMagic = 0x43004300u;
 };
 
-template <typename T, int MT>
-__global__ __launch_bounds__(256) void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
-                                                             const T* __restrict__ Sp, const T* __restrict__ bias,
-                                                             T* __restrict__ C, int M, int N, int K, int G,
-                                                             int64_t lda, int64_t ldc) {
-    constexpr int BM = 32 * MT;
-    constexpr int CH = BM * 8 / 256;           // 16-byte A chunks staged per thread per K step
+template <typename T, int MT, int NT, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+                                                                 const T* __restrict__ Sp, const T* __restrict__ bias,
+                                                                 T* __restrict__ C, int M, int N, int K, int G,
+                                                                 int64_t lda, int64_t ldc, float* __restrict__ part,
+                                                                 int per, int nbx) {
+    constexpr int BM = 32 * MT;                // rows per block
+    constexpr int WN = 32 * NT;                // columns per wave
+    constexpr int NTHR = NW * 64;
+    constexpr int CH = (BM * 8 + NTHR - 1) / NTHR;   // 16-byte A chunks staged per thread per K step
+    constexpr bool kAllStage = (BM * 8) % NTHR == 0;
     typedef Mma<T> MM;
     __shared__ __attribute__((aligned(16))) char smem[2][BM * 128];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kb = lane >> 5;
-    const int m0 = blockIdx.y * BM;
-    const int n_raw = blockIdx.x * 128 + wave * 32 + j;
-    const int n = n_raw < N ? n_raw : N - 1;   // clamped column: loads stay in bounds, stores are masked
+    // 1-D grid over (row tile, column tile), remapped so that each XCD (hardware block id mod 8) owns a contiguous
+    // run of row-major tile indices: the column tiles that share an A row tile then hit ONE L2 instead of eight
+    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * BM;
+    const int n_base = tile.x * (NW * WN) + wave * WN + j;       // + 32 t for the wave's t-th column tile
     const int ksteps = (G + 1) >> 1;           // 64 k (two groups) per step
+    const int k0 = blockIdx.z * per;           // split-K: this block's K steps are [k0, k0 + nst)
+    const int nst = ksteps - k0 < per ? ksteps - k0 : per;
+    auto gstep = [&](int t) { return k0 + (t < nst ? t : nst - 1); };
 
     u32 k_mask_lo, k_mask_hi, k_magic;
     asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
     asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
 
-    const u32x4* wcol = Wt + (int64_t)n * G;
-    const T* scol = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+    const u32x4* wcol[NT];
+    const T* scol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nr = n_base + 32 * t;
+        const int n = nr < N ? nr : N - 1;     // clamped column: loads stay in bounds, stores are masked
+        wcol[t] = Wt + (int64_t)n * G;
+        scol[t] = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+    }
 
     // A staging: thread -> CH chunks; chunk q: row q / 8, 16-byte column q % 8
     const T* a_src[CH];
     int a_dst[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-        const int q = tid + u * 256;
-        const int r = q >> 3, c = q & 7;
+        const int q = tid + u * NTHR;
+        const int r = (q >> 3) % BM, c = q & 7;
         const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
         a_src[u] = A + (int64_t)row * lda + c * 8;
         a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
     }
     const int kmax = K - 8;                    // last in-bounds 8-half chunk start
 
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
 
-    // Register ring, DEPTH K-steps deep: the global loads (A chunks, this lane's weight unit AND its scale) of
+    // Register ring, DEPTH K-steps deep: the global loads (A chunks, this lane's weight units AND their scales) of
     // step kt + DEPTH are issued when step kt starts, so DEPTH - 1 steps of MFMA work cover their latency.  In
     // the steady-state loop every load is unconditional and real, so hipcc's vmcnt waits are exact (a load
     // under `if (more)` made it drain the queue every step; the per-step scale load sat on the critical path).
-    constexpr int DEPTH = 3;
-    typedef decltype(MM::scale_pair(scol, true)) scale_t;
+    typedef decltype(MM::scale_pair(scol[0], true)) scale_t;
     struct Stage {
         u32x4 a[CH];
-        u32x4 w;
-        T s;
+        u32x4 w[NT];
+        T s[NT];
     };
     Stage st[DEPTH];
-    auto load_stage = [&](int kt, Stage& sg) {
+    auto load_stage = [&](int kt, Stage& sg, bool steady = false) {
+        if (!(steady && (QL_GEMM_ABLATE & 8))) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int c = (tid + u * 256) & 7;
-            const int k = kt * 64 + c * 8;
-            // a K tail (odd group count) reads a clamped chunk; its weights are zeroed at use
-            sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c * 8));
+            for (int u = 0; u < CH; ++u) {
+                const int c = (tid + u * NTHR) & 7;
+                const int k = kt * 64 + c * 8;
+                // a K tail (odd group count) reads a clamped chunk; its weights are zeroed at use
+                sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c * 8));
+            }
         }
+        if (steady && (QL_GEMM_ABLATE & 2)) return;
         const int g = 2 * kt + kb;
         const int gc = g < G ? g : G - 1;
-        sg.w = __builtin_nontemporal_load(wcol + gc);
-        sg.s = scol[(int64_t)gc * 4];
-    };
-    auto store_a = [&](int buf, const Stage& sg) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = sg.a[u];
+        for (int t = 0; t < NT; ++t) {
+            // plain (cacheable) loads: other row blocks re-read the same units, and a 128-byte line serves 4 steps
+            sg.w[t] = wcol[t][gc];
+            sg.s[t] = scol[t][(int64_t)gc * 4];
+        }
     };
-    auto mma_step = [&](int buf, int kt, u32x4 w_cur, T s_raw) {
+    auto store_a = [&](int buf, const Stage& sg, bool steady = false) {
+        if (steady && (QL_GEMM_ABLATE & 8)) return;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (kAllStage || tid + u * NTHR < BM * 8) *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = sg.a[u];
+    };
+    auto block_sync = [&] {
+        if (!(QL_GEMM_ABLATE & 32)) __syncthreads();
+    };
+    auto mma_step = [&](int buf, int kt, const u32x4 (&w_cur)[NT], const T (&s_raw)[NT]) {
         const int g = 2 * kt + kb;
-        const T s_eff = g < G ? s_raw : (T)0.f;              // the missing half of an odd last step contributes 0
-        const scale_t s = MM::scale_pair(&s_eff, true);
+        scale_t s[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const T s_eff = g < G ? s_raw[t] : (T)0.f;       // the missing half of an odd last step contributes 0
+            s[t] = MM::scale_pair(&s_eff, true);
+        }
         // A fragments are read ONE SUB-STEP AHEAD of the MFMAs that consume them: with the reads issued right in
         // front of each MFMA (what the straightforward loop compiled to) every MFMA waited out a full LDS round
         // trip (~100+ cycles against its own 32) and the matrix pipe idled 70 % of the time
@@ -160,28 +200,43 @@ __global__ __launch_bounds__(256) void w4_packed_gemm_kernel(const T* __restrict
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = mt * 32 + j;
-                fr[mt] = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                if (QL_GEMM_ABLATE & 16) fr[mt] = u32x4{(u32)r, (u32)c, (u32)buf, 0x3c003c00u};
+                else fr[mt] = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
             }
         };
+        auto deq = [&](u32 w, scale_t sc) {
+            if (QL_GEMM_ABLATE & 1) return __builtin_bit_cast(typename MM::frag, u32x4{w, w ^ k_magic, w, w});
+            return MM::dequant(w, k_mask_lo, k_mask_hi, k_magic, sc);
+        };
         u32x4 fa[2][MT];
-        typename MM::frag fb[2];
+        typename MM::frag fb[2][NT];
         read_a(0, fa[0]);
-        fb[0] = MM::dequant(w_cur[0], k_mask_lo, k_mask_hi, k_magic, s);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fb[0][t] = deq(w_cur[t][0], s[t]);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             // software pipeline inside the step: while the MFMAs of sub-step `sub` run, issue the A-fragment reads
-            // and build the B fragment of sub-step sub + 1 (VALU slots under the 32-cycle MFMA shadows)
+            // and build the B fragments of sub-step sub + 1 (VALU slots under the MFMA shadows)
             if (sub < 3) {
                 read_a(sub + 1, fa[(sub + 1) & 1]);
-                fb[(sub + 1) & 1] = MM::dequant(w_cur[sub + 1], k_mask_lo, k_mask_hi, k_magic, s);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fb[(sub + 1) & 1][t] = deq(w_cur[t][sub + 1], s[t]);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]), fb[sub & 1], acc[mt]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (QL_GEMM_ABLATE & 4) {
+                        const u32x4 fbu = __builtin_bit_cast(u32x4, fb[sub & 1][t]);
+                        acc[mt][t][sub] += u32_as_f32(fa[sub & 1][mt][0] ^ fa[sub & 1][mt][1] ^ fa[sub & 1][mt][2] ^
+                                                      fa[sub & 1][mt][3] ^ fbu[0] ^ fbu[1] ^ fbu[2] ^ fbu[3]);
+                    } else
+                        acc[mt][t] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]), fb[sub & 1][t], acc[mt][t]);
+                }
             // schedule shape per sub-step: the MT reads first, then each MFMA followed by a slice of the VALU work
             __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);            // DS reads of the next sub-step
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int q = 0; q < MT * NT; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, (16 + MT - 1) / MT, 0);   // its share of the dequant VALU
             }
@@ -189,71 +244,100 @@ __global__ __launch_bounds__(256) void w4_packed_gemm_kernel(const T* __restrict
     };
 
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_stage(d < ksteps ? d : ksteps - 1, st[d]);
+    for (int d = 0; d < DEPTH; ++d) load_stage(gstep(d), st[d]);
     store_a(0, st[0]);
     __syncthreads();
 
     int kt = 0;
-    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+    for (; kt + DEPTH < nst; kt += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int buf = (kt + d) & 1;
-            const u32x4 w_cur = st[d].w;
-            const T s_cur = st[d].s;
-            // slot d: its A chunks went to LDS last step, its weight unit / scale were just copied out
-            load_stage(kt + d + DEPTH < ksteps ? kt + d + DEPTH : ksteps - 1, st[d]);
-            mma_step(buf, kt + d, w_cur, s_cur);
-            store_a(buf ^ 1, st[(d + 1) % DEPTH]);
-            __syncthreads();
+            u32x4 w_cur[NT];
+            T s_cur[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w_cur[t] = st[d].w[t];
+                s_cur[t] = st[d].s[t];
+            }
+            // slot d: its A chunks went to LDS last step, its weight units / scales were just copied out
+            load_stage(gstep(kt + d + DEPTH), st[d], true);
+            mma_step(buf, gstep(kt + d), w_cur, s_cur);
+            store_a(buf ^ 1, st[(d + 1) % DEPTH], true);
+            block_sync();
         }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        if (kt + d < ksteps) {
+        if (kt + d < nst) {
             const int buf = (kt + d) & 1;
-            mma_step(buf, kt + d, st[d].w, st[d].s);
-            if (kt + d + 1 < ksteps) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            mma_step(buf, gstep(kt + d), st[d].w, st[d].s);
+            if (kt + d + 1 < nst) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }
 
     // C/D map of 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
-    if (n_raw < N) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n_raw = n_base + 32 * t;
+        if (n_raw >= N) continue;
         const T* bn = bias ? bias + n_raw : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
-                if (m < M) store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][i], bn);
+                if (m >= M) continue;
+                if (part) part[((int64_t)blockIdx.z * M + m) * N + n_raw] = acc[mt][t][i];   // fp32 slab; summed by splitk_reduce_kernel
+                else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][t][i], bn);
             }
     }
 }
 
-template <typename T, int MT>
+template <typename T, int MT, int NT, int NW>
 static int launch_gemm(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                       int64_t ldc, hipStream_t st) {
+                       int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
     const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
     const u32x4* Wt = (const u32x4*)packed;
     const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
-    w4_packed_gemm_kernel<T, MT><<<grid, 256, 0, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G, lda, ldc);
+    float* part = plan.ksplit > 1 ? ws : nullptr;
+    constexpr int BN = NW * 32 * NT;
+    const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
+    dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
+    w4_packed_gemm_kernel<T, MT, NT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G,
+                                                                      lda, ldc, part, plan.per,
+        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5));
+    const int rc = finish_launch();
+    if (rc != 0 || !part) return rc;
+    const int64_t total = (int64_t)M * N;
+    splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
     return finish_launch();
 }
 
+
 template <typename T>
 static int launch_gemm_any(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                           int64_t K, int64_t lda, int64_t ldc, hipStream_t st) {
-    if (M > 64) return launch_gemm<T, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
-    if (M > 32) return launch_gemm<T, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
-    return launch_gemm<T, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+                           int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    switch (plan.mt) {
+    case 4:
+        // 8 waves (256 columns) per block halve the A-tile traffic per flop; worth it once that grid still fills the chip
+        if (((N + 255) / 256) * ((M + 127) / 128) >= 256)
+            return launch_gemm<T, 4, 1, 8>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+        return launch_gemm<T, 4, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    case 2: return launch_gemm<T, 2, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    default: return launch_gemm<T, 1, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    }
 }
 
+size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) { return gemm_workspace_bytes(M, N, (K / 32 + 1) / 2); }
+
 int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                   int64_t K, int64_t lda, int64_t ldc, hipStream_t st) {
+                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (dtype) {
-    case QL_DTYPE_F16: return launch_gemm_any<f16>(A, packed, bias, C, M, N, K, lda, ldc, st);
-    case QL_DTYPE_BF16: return launch_gemm_any<__bf16>(A, packed, bias, C, M, N, K, lda, ldc, st);
+    case QL_DTYPE_F16: return launch_gemm_any<f16>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_BF16: return launch_gemm_any<__bf16>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

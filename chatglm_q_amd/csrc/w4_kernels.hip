@@ -191,18 +191,6 @@ __global__ __launch_bounds__(256) void w4_canon_kernel(const T* __restrict__ A, 
     }
 }
 
-// sum the split-K slabs, round once, add bias, store
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
-                                                            T* __restrict__ C, int M, int N, int64_t ldc, int ksplit) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx % N);
-    float v = 0.f;
-    for (int s = 0; s < ksplit; ++s) v += partial[((int64_t)s * M + m) * N + n];
-    store_out<T>(C + (int64_t)m * ldc + n, v, bias ? bias + n : nullptr);
-}
-
 // =============================================================================================
 // host-side launchers (called from abi.hip)
 // =============================================================================================

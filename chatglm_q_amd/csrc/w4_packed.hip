@@ -701,10 +701,10 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
 }
 
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-              int64_t K, int64_t lda, int64_t ldc, bool strict, hipStream_t st) {
+              int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st) {
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
     if (M > 4 && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
-        return w4_packed_gemm(dtype, A, packed, bias, C, M, N, K, lda, ldc, st);
+        return w4_packed_gemm(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     const PackedArgs p{A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, strict, st};
     switch (dtype) {
     case QL_DTYPE_F16:

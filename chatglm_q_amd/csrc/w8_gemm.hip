@@ -72,22 +72,29 @@ template <> struct W8Mma<__bf16> {
     }
 };
 
-template <typename T, int MT>
-__global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
+template <typename T, int MT, int NW, int DEPTH>
+__global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
                                                       const T* __restrict__ S, const T* __restrict__ bias, T* __restrict__ C,
-                                                      int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc) {
+                                                      int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc,
+                                                      float* __restrict__ part, int per, int nbx) {
     constexpr int BM = 32 * MT;
-    constexpr int CH = BM * 8 / 256;           // 16-byte A chunks staged per thread per K step
-    constexpr int DEPTH = 3;
+    constexpr int NTHR = NW * 64;
+    constexpr int CH = (BM * 8 + NTHR - 1) / NTHR;   // 16-byte A chunks staged per thread per K step
+    constexpr bool kAllStage = (BM * 8) % NTHR == 0;
     typedef W8Mma<T> MM;
     __shared__ __attribute__((aligned(16))) char smem[2][BM * 128];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kb = lane >> 5;
-    const int m0 = blockIdx.y * BM;
-    const int n_raw = blockIdx.x * 128 + wave * 32 + j;
+    // 1-D grid, XCD-aware tile order (ql_common.h): tiles sharing an A row tile share an L2
+    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * BM;
+    const int n_raw = tile.x * (NW * 32) + wave * 32 + j;
     const int n = n_raw < N ? n_raw : N - 1;
     const int ksteps = (K + 63) >> 6;
+    const int k0 = blockIdx.z * per;           // split-K: this block's K steps are [k0, k0 + nst)
+    const int nst = ksteps - k0 < per ? ksteps - k0 : per;
+    auto gstep = [&](int t) { return k0 + (t < nst ? t : nst - 1); };
 
     u32 k_mask, k_magic;
     asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
@@ -100,8 +107,8 @@ __global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, c
     int a_dst[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-        const int q = tid + u * 256;
-        const int r = q >> 3, c = q & 7;
+        const int q = tid + u * NTHR;
+        const int r = (q >> 3) % BM, c = q & 7;
         const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
         a_src[u] = A + (int64_t)row * lda + c * 8;
         a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
@@ -123,20 +130,21 @@ __global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, c
     auto load_stage = [&](int kt, Stage& sg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int c = (tid + u * 256) & 7;
+            const int c = (tid + u * NTHR) & 7;
             const int k = kt * 64 + c * 8;
             sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax_a ? kt * 64 : kmax_a - c * 8));   // K tail: clamped
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kt * 64 + kb * 32 + h * 16;
-            sg.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32)));
+            sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32));   // cacheable: re-read by other row tiles
         }
     };
     auto store_a = [&](int buf, const Stage& sg) {
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = MM::kPairedA ? w8g_pair_even_odd(sg.a[u]) : sg.a[u];
+            if (kAllStage || tid + u * NTHR < BM * 8)
+                *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = MM::kPairedA ? w8g_pair_even_odd(sg.a[u]) : sg.a[u];
     };
     auto mma_step = [&](int buf, int kt, const u32x4 (&w_in)[2]) {
         // bytes of a K tail (k >= K) are replaced by 0: b = 0 contributes nothing whatever the (clamped) activations are
@@ -175,28 +183,28 @@ __global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, c
     };
 
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_stage(d < ksteps ? d : ksteps - 1, st[d]);
+    for (int d = 0; d < DEPTH; ++d) load_stage(gstep(d), st[d]);
     store_a(0, st[0]);
     __syncthreads();
 
     int kt = 0;
-    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+    for (; kt + DEPTH < nst; kt += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int buf = (kt + d) & 1;
             const u32x4 w_cur[2] = {st[d].w[0], st[d].w[1]};
-            load_stage(kt + d + DEPTH < ksteps ? kt + d + DEPTH : ksteps - 1, st[d]);
-            mma_step(buf, kt + d, w_cur);
+            load_stage(gstep(kt + d + DEPTH), st[d]);
+            mma_step(buf, gstep(kt + d), w_cur);
             store_a(buf ^ 1, st[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        if (kt + d < ksteps) {
+        if (kt + d < nst) {
             const int buf = (kt + d) & 1;
-            mma_step(buf, kt + d, st[d].w);
-            if (kt + d + 1 < ksteps) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
+            mma_step(buf, gstep(kt + d), st[d].w);
+            if (kt + d + 1 < nst) store_a(buf ^ 1, st[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }
@@ -208,32 +216,52 @@ __global__ __launch_bounds__(256) void w8_gemm_kernel(const T* __restrict__ A, c
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
-                if (m < M) store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][i], bn);
+                if (m >= M) continue;
+                if (part) part[((int64_t)blockIdx.z * M + m) * N + n_raw] = acc[mt][i];   // fp32 slab; summed by splitk_reduce_kernel
+                else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][i], bn);
             }
     }
 }
 
-template <typename T, int MT>
+template <typename T, int MT, int NW>
 static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int M, int N, int K,
-                          int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
-    w8_gemm_kernel<T, MT><<<grid, 256, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda, ldc);
+                          int64_t ldw, int64_t lda, int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
+    float* part = plan.ksplit > 1 ? ws : nullptr;
+    constexpr int BN = NW * 32;
+    const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
+    dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
+    w8_gemm_kernel<T, MT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
+                                                           ldc, part, plan.per,
+        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K));
+    const int rc = finish_launch();
+    if (rc != 0 || !part) return rc;
+    const int64_t total = (int64_t)M * N;
+    splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
     return finish_launch();
 }
 
 template <typename T>
 static int launch_w8_gemm_any(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
-                              int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
-    if (M > 64) return launch_w8_gemm<T, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
-    if (M > 32) return launch_w8_gemm<T, 2>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
-    return launch_w8_gemm<T, 1>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st);
+                              int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes,
+                              hipStream_t st) {
+    const GemmPlan plan = gemm_plan(M, N, (K + 63) / 64, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    switch (plan.mt) {
+    case 4:
+        if (((N + 255) / 256) * ((M + 127) / 128) >= 256)   // see w4_gemm.hip
+            return launch_w8_gemm<T, 4, 8>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
+        return launch_w8_gemm<T, 4, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
+    case 2: return launch_w8_gemm<T, 2, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
+    default: return launch_w8_gemm<T, 1, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
+    }
 }
 
+size_t w8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) { return gemm_workspace_bytes(M, N, (K + 63) / 64); }
+
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
-            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+            int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (dtype) {
-    case QL_DTYPE_F16: return launch_w8_gemm_any<f16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, st);
-    case QL_DTYPE_BF16: return launch_w8_gemm_any<__bf16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, st);
+    case QL_DTYPE_F16: return launch_w8_gemm_any<f16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_BF16: return launch_w8_gemm_any<__bf16>(A, W, S, bias, C, M, N, K, ldw, lda, ldc, ws, ws_bytes, st);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

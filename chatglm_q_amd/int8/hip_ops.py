@@ -61,10 +61,13 @@ def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     ldw_k = b.stride(0) if K > 1 else 1
     ldw_n = b.stride(1) if N > 1 else max(K, 1)
     with torch.cuda.device(a.device):
+        # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
+        ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8_FWD, M, N, K, 0)) if M > 4 and ldw_k == 1 else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
         st = lib.qlinear_w8_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
                                 ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, _lib.dtype_code(a.dtype),
                                 _lib.FLAG_STRICT_ROUNDING if (_lib.STRICT_DEFAULT if strict is None else strict) else 0,
-                                None, 0, _lib.stream_ptr(a.device))
+                                _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd")
     return c.reshape(out_shape)
 

@@ -78,8 +78,12 @@ const char* qlinear_status_string(int status);
  * Lets a caller prove that a result came from the HIP path and not from any fallback. */
 uint64_t qlinear_launch_count(void);
 
-/* Bytes of scratch the op needs for this shape (0 = none).  The caller allocates it (e.g. from
- * torch's caching allocator so stream semantics hold) and passes it to the op. */
+/* Bytes of scratch the op wants for this shape (0 = none).  The caller allocates it (e.g. from
+ * torch's caching allocator so stream semantics hold) and passes it to the op.  It is REQUIRED by
+ * QL_OP_W4G32_FWD (QL_ERR_WORKSPACE otherwise) and OPTIONAL for QL_OP_W4G32_FWD_PACKED / QL_OP_W8_FWD,
+ * where it lets a few-row (5 <= M < ~256) MFMA GEMM split K over workgroups into fp32 slabs that a
+ * second launch sums; without it (NULL / too small / not 16-byte aligned) those shapes run unsplit -
+ * same rounding sequence, several times slower. */
 size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t group);
 
 /* ---- int4 group-quantised weights, canonical (reference) layout ---------------------------
