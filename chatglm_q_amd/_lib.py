@@ -25,6 +25,7 @@ STRICT_DEFAULT = os.environ.get("QLINEAR_STRICT", "0") not in ("0", "", "false",
 
 PRO_SILU = 1
 PRO_ADDNORM = 2
+EPI_SILU_GATE = 0x100
 
 OP_W4G32_FWD = 1
 OP_W4G32_FWD_PACKED = 2

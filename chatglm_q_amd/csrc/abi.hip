@@ -113,14 +113,17 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
                                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout,
                                    float eps, int dtype, void* stream) {
     if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
+    const bool gate = (prologue & QL_EPI_SILU_GATE) != 0;
+    prologue &= ~QL_EPI_SILU_GATE;
     if (prologue == QL_PRO_ADDNORM && !ln_weight) return QL_ERR_NULL_POINTER;
     if (prologue != QL_PRO_SILU && prologue != QL_PRO_ADDNORM) return QL_ERR_UNSUPPORTED;
+    if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(N) || !fits_i32(K) || K % 32 != 0) return QL_ERR_BAD_SHAPE;
     if (!aligned(packed, 16) || !aligned(A, 16) || (delta && !aligned(delta, 16)) || (ln_weight && !aligned(ln_weight, 16)) ||
         (hout && !aligned(hout, 16)))
         return QL_ERR_MISALIGNED;
-    return w4_packed_fused(dtype, prologue, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
+    return w4_packed_fused(dtype, prologue, gate, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
 }
 
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,

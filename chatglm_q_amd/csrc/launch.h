@@ -23,8 +23,8 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st);
 
-int w4_packed_fused(int dtype, int kind, const void* A, const void* packed, const void* bias, void* C, int64_t N,
-                    int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
+int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,
+                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 
 // w4_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,

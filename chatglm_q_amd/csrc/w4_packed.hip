@@ -125,6 +125,8 @@ struct Prologue {
     const void* ln_weight;  // PRO_ADDNORM
     void* hout;             // PRO_ADDNORM: updated residual stream
     float eps;
+    int gate_epilogue;      // 1: columns come in quads (h0, h1, gate0, gate1); C gets N / 2 columns
+                            //    out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias)   model.py:200-201
 };
 
 template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
@@ -409,6 +411,19 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     }
 
     if (wave_active && ks == 0 && lane == 0) {
+        if (PRO != PRO_NONE && pro.gate_epilogue) {
+            // SiLU(h) * gate on the quad's (h0, h1, gate0, gate1) sums; N is a multiple of 4 here
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                y[c] = Act<T>::round(acc[0][c]);
+                if (bias) y[c] = Act<T>::round(y[c] + Act<T>::load(bias + t * 4 + c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                Act<T>::store(C + t * 2 + i, Act<T>::round(Act<T>::round(y[i] / (1.0f + __expf(-y[i]))) * y[i + 2]));
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m0 + m >= M) break;
@@ -675,10 +690,10 @@ static int launch_16_pro_any(const PackedArgs& p, const Prologue& pro) {
 #undef QL_PRO
 }
 
-int w4_packed_fused(int dtype, int kind, const void* A, const void* packed, const void* bias, void* C, int64_t N,
-                    int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
+int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,
+                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
     const PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, false, st};
-    const Prologue pro{delta, ln_weight, hout, eps};
+    const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
     if (dtype == QL_DTYPE_F16) {
         if (kind == PRO_SILU) return launch_16_pro_any<f16, PRO_SILU>(p, pro);
         if (kind == PRO_ADDNORM) return launch_16_pro_any<f16, PRO_ADDNORM>(p, pro);

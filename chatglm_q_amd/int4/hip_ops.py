@@ -120,17 +120,28 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     return c.reshape(out_shape)
 
 
+def gate_interleave(hidden: int, device=None) -> Tensor:
+    """Column order (h_0, h_1, gate_0, gate_1, h_2, h_3, gate_2, gate_3, ...) of a (K, 2 * hidden) first MLP
+    projection, as the SiLU * gate epilogue expects it (``hidden`` even)."""
+    if hidden % 2:
+        raise ValueError("gate interleave needs an even hidden size")
+    t = torch.arange(hidden // 2, device=device)
+    return torch.stack((2 * t, 2 * t + 1, hidden + 2 * t, hidden + 2 * t + 1), dim=1).reshape(-1)
+
+
 def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None = None,
                      delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
                      eps: float = 0.0) -> Tensor:
-    """One-row forward with an activation prologue (``_lib.PRO_SILU`` / ``_lib.PRO_ADDNORM``) on the derived layout.
-    ``a``: (..., K) for ADDNORM, (..., 2K) for SILU, exactly one row.  Returns (..., n_out)."""
+    """One-row forward with an activation prologue (``_lib.PRO_SILU`` / ``_lib.PRO_ADDNORM``, optionally OR-ed with
+    ``_lib.EPI_SILU_GATE``) on the derived layout.  ``a``: (..., K) for ADDNORM, (..., 2K) for SILU, exactly one
+    row; ``n_out`` = number of packed columns.  Returns (..., n_out), or (..., n_out / 2) with the gate epilogue
+    (``packed`` then holds the gate-interleaved column order, see ``gate_interleave``)."""
     lib = _lib.get_lib()
-    K = a.shape[-1] // 2 if kind == _lib.PRO_SILU else a.shape[-1]
+    K = a.shape[-1] // 2 if (kind & 0xFF) == _lib.PRO_SILU else a.shape[-1]
     if a.numel() != a.shape[-1]:
         raise ValueError("fused prologues serve exactly one activation row")
     a = a.contiguous()
-    c = torch.empty((*a.shape[:-1], n_out), device=a.device, dtype=a.dtype)
+    c = torch.empty((*a.shape[:-1], n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out), device=a.device, dtype=a.dtype)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w4g32_fwd_packed_fused(kind, a.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(),
                                                 n_out, K, _lib.ptr(delta), _lib.ptr(ln_weight), _lib.ptr(hout),

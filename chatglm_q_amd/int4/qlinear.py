@@ -128,6 +128,22 @@ class DynamicQuantizeLinear(nn.Module):
             self._packed_key = key
         return self
 
+    @torch.no_grad()
+    def gated_packed(self, hidden: int):
+        """Derived layout of a first MLP projection (out_features = 2 * hidden) with its columns reordered to
+        (h_2t, h_2t+1, gate_2t, gate_2t+1) quads for the fused SiLU * gate epilogue
+        (qlinear_w4g32_fwd_packed_fused | QL_EPI_SILU_GATE).  Returns (packed, bias_or_None); cached like
+        ``_packed`` and never part of the state_dict."""
+        if self.out_features != 2 * hidden or not self._packed_supported():
+            raise ValueError("gated layout needs a supported (K, 2 * hidden) int4g32 weight")
+        key = self._canonical_key()
+        if getattr(self, "_gated", None) is None or self._gated_key != key:
+            perm = hip_ops.gate_interleave(hidden, self.weight.device)
+            packed = hip_ops.repack_w4g32(self.weight.index_select(1, perm), self.weight_scale.index_select(1, perm))
+            bias = self.bias.index_select(0, perm) if self.bias is not None else None
+            self._gated, self._gated_key = (packed, bias), key
+        return self._gated
+
     def forward(self, input: Tensor):
         if check_input(input):
             if input.requires_grad and torch.is_grad_enabled():

@@ -251,9 +251,9 @@ class ChatGLM2Model(nn.Module):
         return ok
 
     def _step_one_row(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor) -> Tensor:
-        """Decode step of ONE row: 7 launches per layer.  The residual add + RMSNorm in front of qkv_proj / w_in /
+        """Decode step of ONE row: 6 launches per layer.  The residual add + RMSNorm in front of qkv_proj / w_in /
         lm_head run inside those QLinear kernels' activation staging (qlinear_w4g32_fwd_packed_fused); rotary +
-        cache write, the attention and SiLU * gate are one launch each."""
+        cache write and the attention are one launch each; SiLU * gate is w_in's epilogue."""
         from . import _lib, fused_ops as F_
         from .int4 import hip_ops as H4
         c = self.config
@@ -268,12 +268,14 @@ class ChatGLM2Model(nn.Module):
             q = F_.rope_kv_write(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i], H, G, D)
             o = at.o_proj(F_.decode_attention(q, cache.k[i], cache.v[i], mask, H, G, D))
             hn = torch.empty_like(h)
-            y = H4.w4_forward_fused(_lib.PRO_ADDNORM, h, ff.w_in.prepare()._packed, ff.w_in.out_features, None, o,
+            # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its derived layout (each wave owns
+            # (h, h, gate, gate) column quads), so the (1, 2 * hidden) intermediate is never written.  (As a
+            # PROLOGUE of w_out it measured +6 us: every one of w_out's ~1000 blocks redid the 13696 exponentials.)
+            gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
+            y = H4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gp, ff.w_in.out_features, gb, o,
                                     layer.ffn_ln.weight, hn, layer.ffn_ln.eps)
             h = hn
-            # SiLU * gate stays its own launch: fused into w_out's staging every one of its ~1000 blocks would
-            # redo the 13696 exponentials (measured +6 us per call, against ~3 us for the separate launch)
-            delta = ff.w_out(F_.silu_mul(y, ff.hidden_dim))
+            delta = ff.w_out(y)
         return H4.w4_forward_fused(_lib.PRO_ADDNORM, h, self.lm_head.prepare()._packed, self.lm_head.out_features, None,
                                    delta, self.final_ln.weight, None, self.final_ln.eps)
 

@@ -116,9 +116,15 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * N1).  fp16 / bf16, group 32, exact-dequant arithmetic.  Rounding sequence as the model graph's:
  *   QL_PRO_SILU     A is (h | gate), 2K values: row = round(round(silu(h)) * gate)            chatglm_q/model.py:200-201
  *   QL_PRO_ADDNORM  hnew = round(A + delta) (delta nullable), written to hout (nullable);
- *                   row = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)          chatglm_q/model.py:62-73,243-245 */
+ *                   row = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)          chatglm_q/model.py:62-73,243-245
+ * and optionally the gated-activation EPILOGUE of the MLP's first projection (OR the flag into `prologue`):
+ *   QL_EPI_SILU_GATE  the N packed columns come in quads (h_2t, h_2t+1, gate_2t, gate_2t+1) - i.e. the module's
+ *                   (K, 2H) weight was column-permuted before qlinear_w4g32_repack (bias likewise) - and C
+ *                   receives N / 2 values: C[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = round(sum) (+ bias,
+ *                   rounded): the (.., 2H) intermediate of chatglm_q/model.py:200-201 never exists. */
 #define QL_PRO_SILU 1
 #define QL_PRO_ADDNORM 2
+#define QL_EPI_SILU_GATE 0x100
 int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* packed, const void* bias, void* C,
                                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout,
                                    float eps, int dtype, void* stream);

@@ -130,3 +130,38 @@ def test_fused_prologues_equal_separate_ops(dtype):
     with torch.no_grad():
         want = layer(F_.silu_mul(y, 13696))
     assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gate_epilogue_equals_separate_ops(dtype, bias):
+    """QL_EPI_SILU_GATE: add + RMSNorm prologue, w_in on the gate-interleaved layout, SiLU * gate epilogue - against
+    the separate launches (w_in on the plain layout, then silu_mul).  The kernels add the same products in the
+    same order, so the two paths agree exactly."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(33)
+    for K, hidden in ((4096, 13696), (256, 96)):
+        layer = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+        layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        if bias:
+            layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+        gp, gb = layer.gated_packed(hidden)
+        assert (gb is None) == (not bias)
+        h = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        d = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        w = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+        hout = torch.empty_like(h)
+        got = H4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gp, 2 * hidden, gb, d, w, hout, 1e-5)
+        want_h, x = F_.add_rmsnorm(h, d, w, 1e-5)
+        with torch.no_grad():
+            want = F_.silu_mul(layer(x), hidden)
+        assert got.shape == (1, 1, hidden)
+        assert torch.equal(hout, want_h)
+        assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+        # cached, and refreshed when the canonical buffers change
+        assert layer.gated_packed(hidden)[0] is gp
+        layer.weight.add_(1)
+        assert layer.gated_packed(hidden)[0] is not gp
