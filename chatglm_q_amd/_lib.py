@@ -60,6 +60,7 @@ EXPORTS = {
     "qlinear_add_rmsnorm": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int64, c_float, c_int, c_void_p]),
     "qlinear_rope_kv_write": (c_int, [c_void_p] * 7 + [c_int64] * 7 + [c_int, c_void_p]),
     "qlinear_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_void_p]),
+    "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p]),
     "qlinear_greedy_advance": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_int, c_void_p]),
     "qlinear_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),

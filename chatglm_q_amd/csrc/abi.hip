@@ -220,9 +220,23 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(B) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) || H % G != 0)
         return QL_ERR_BAD_SHAPE;
-    if ((D != 128 && D != 64 && D != 32) || (capacity + 33 * D + 8) * 4 > 64 * 1024) return QL_ERR_UNSUPPORTED;
+    if ((D != 128 && D != 64 && D != 32) || (capacity + 35 * D + 8) * 4 > 64 * 1024) return QL_ERR_UNSUPPORTED;
     if (!aligned(Kcache, 16) || !aligned(Vcache, 16)) return QL_ERR_MISALIGNED;
     return decode_attention(dtype, Q, Kcache, Vcache, mask, Out, B, H, G, D, capacity, (hipStream_t)stream);
+}
+
+int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
+                                  void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
+                                  int64_t capacity, int64_t ldqkv, int dtype, void* stream) {
+    if (!QKV || !table || !pos || !widx || !Kcache || !Vcache || !mask || !Out) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(B) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) || H % G != 0 ||
+        ldqkv < (H + 2 * G) * D)
+        return QL_ERR_BAD_SHAPE;
+    if ((D != 128 && D != 64 && D != 32) || (capacity + 35 * D + 8) * 4 > 64 * 1024) return QL_ERR_UNSUPPORTED;
+    if (!aligned(Kcache, 16) || !aligned(Vcache, 16)) return QL_ERR_MISALIGNED;
+    return decode_attention_rope(dtype, QKV, table, pos, widx, Kcache, Vcache, mask, Out, B, H, G, D, capacity, ldqkv,
+                                 (hipStream_t)stream);
 }
 
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,

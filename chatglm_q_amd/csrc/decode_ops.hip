@@ -127,6 +127,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
 //   table: (max_pos, D/2, 2) in the activation dtype (second half of the pairs = (1, 0) pass-through)
 // rows = B * S, row = b * S + s.  caches: (B, capacity, G, D).  One thread = 4 pairs = 8 values.
 // ---------------------------------------------------------------------------------------------
+// (x0 + i x1) (c + i s), one explicit contraction so that every kernel rotates bit-identically
+__device__ __forceinline__ void rope_pair(float x0, float x1, float c, float s, float& y0, float& y1) {
+    y0 = __builtin_fmaf(x0, c, -(x1 * s));
+    y1 = __builtin_fmaf(x0, s, x1 * c);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict__ QKV, const T* __restrict__ table,
                                                             const int64_t* __restrict__ pos, const int64_t* __restrict__ widx,
@@ -153,10 +159,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict_
             float c[8], y[8];
             load8<T>(cs + u * 8, c);                         // (cos, sin) x 4 pairs
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                y[2 * p] = x[2 * p] * c[2 * p] - x[2 * p + 1] * c[2 * p + 1];
-                y[2 * p + 1] = x[2 * p] * c[2 * p + 1] + x[2 * p + 1] * c[2 * p];
-            }
+            for (int p = 0; p < 4; ++p) rope_pair(x[2 * p], x[2 * p + 1], c[2 * p], c[2 * p + 1], y[2 * p], y[2 * p + 1]);
             store8<T>(dst + u * 8, y);
         } else {
             store8<T>(dst + u * 8, x);
@@ -172,23 +175,63 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict_
 // QK: thread = position, the key row read with 16-byte loads, all issued before the first use.
 // PV: thread = (8-wide d chunk, position slice): 16-byte loads of V, slices combined through LDS.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kc,
-                                                               const T* __restrict__ Vc, const float* __restrict__ mask,
-                                                               T* __restrict__ Out, int H, int G, int capacity,
-                                                               float sqrt_d) {
+template <typename T, int D, bool ROPE>
+__global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ Q, T* Kc, T* Vc,
+                                                               const float* __restrict__ mask, T* __restrict__ Out, int H,
+                                                               int G, int capacity, float sqrt_d,
+                                                               const T* __restrict__ table, const int64_t* __restrict__ pos,
+                                                               const int64_t* __restrict__ widx, int64_t ldq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(2 * D <= 256, "one thread per q pair, k pair and v value");
     constexpr int CH = D / 8;                                 // 8-wide chunks per head row
     constexpr int SL = 256 / CH;                              // position slices in the PV phase
     float* sc = reinterpret_cast<float*>(smem);               // capacity scores / probabilities
     float* qs = sc + capacity;                                // D scaled query values
     float* red = qs + D;                                      // 4
     float* part = red + 4;                                    // SL x D partial outputs
+    float* knew = part + SL * D;                              // ROPE: this step's rotated key / value of the head's group
+    float* vnew = knew + D;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int g = h / (H / G);
-    const T* q = Q + ((int64_t)b * H + h) * D;
-    for (int d = threadIdx.x; d < D; d += 256) qs[d] = Act<T>::round(Act<T>::load(q + d) / sqrt_d);
-    __syncthreads();
+    int wrow = -1;
+    if constexpr (ROPE) {
+        // Q is the fused projection row (H q heads | G k heads | G v heads); rotate q and k exactly as
+        // rope_kv_write_kernel does (rounded to T), keep k / v of the new position in LDS - the group's other
+        // blocks must not read that cache row while block (h % (H/G) == 0) writes it
+        wrow = (int)widx[0];
+        const T* row = Q + (int64_t)b * ldq;
+        const T* cs = table + pos[b] * D;
+        const int d = threadIdx.x;
+        if (d < D) {
+            const int p = d < D / 2 ? d : d - D / 2;
+            const T* x = d < D / 2 ? row + h * D : row + (H + g) * D;
+            const float x0 = Act<T>::load(x + 2 * p), x1 = Act<T>::load(x + 2 * p + 1);
+            const float c0 = Act<T>::load(cs + 2 * p), c1 = Act<T>::load(cs + 2 * p + 1);
+            float y0, y1;
+            rope_pair(x0, x1, c0, c1, y0, y1);
+            y0 = Act<T>::round(y0);
+            y1 = Act<T>::round(y1);
+            if (d < D / 2) {
+                qs[2 * p] = Act<T>::round(y0 / sqrt_d);
+                qs[2 * p + 1] = Act<T>::round(y1 / sqrt_d);
+            } else {
+                knew[2 * p] = y0;
+                knew[2 * p + 1] = y1;
+            }
+        } else if (d < 2 * D) {
+            vnew[d - D] = Act<T>::load(row + (H + G + g) * D + (d - D));
+        }
+        __syncthreads();
+        if (h % (H / G) == 0 && d < 2 * D) {
+            const int64_t at = (((int64_t)b * capacity + wrow) * G + g) * D;
+            if (d < D) Act<T>::store(Kc + at + d, knew[d]);
+            else Act<T>::store(Vc + at + d - D, vnew[d - D]);
+        }
+    } else {
+        const T* q = Q + ((int64_t)b * H + h) * D;
+        for (int d = threadIdx.x; d < D; d += 256) qs[d] = Act<T>::round(Act<T>::load(q + d) / sqrt_d);
+        __syncthreads();
+    }
     const T* kb = Kc + ((int64_t)b * capacity * G + g) * D;
     const T* vb = Vc + ((int64_t)b * capacity * G + g) * D;
     const float* mk = mask + (int64_t)b * capacity;
@@ -196,8 +239,15 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     for (int t = threadIdx.x; t < capacity; t += 256) {
         const T* k = kb + (int64_t)t * G * D;
         float kv[CH][8];
+        if (ROPE && t == wrow) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) load8<T>(k + c * 8, kv[c]);
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kv[c][e] = knew[c * 8 + e];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) load8<T>(k + c * 8, kv[c]);
+        }
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -218,6 +268,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     const float inv = 1.0f / sum;
     for (int t = threadIdx.x; t < capacity; t += 256) sc[t] = Act<T>::round(sc[t] * inv);
     __syncthreads();
+    float pw = 0.f;
+    if constexpr (ROPE) {
+        // the new position's value comes from LDS: take its probability out of the table (0 x the cache row = 0)
+        pw = sc[wrow];
+        __syncthreads();
+        if (threadIdx.x == 0) sc[wrow] = 0.f;
+        __syncthreads();
+    }
     const int c = threadIdx.x % CH, sl = threadIdx.x / CH;
     float o[8];
 #pragma unroll
@@ -240,6 +298,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         const float p0 = sc[t];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p0, v0[e], o[e]);
+    }
+    if (ROPE && sl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pw, vnew[c * 8 + e], o[e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[sl * D + c * 8 + e] = o[e];
@@ -351,15 +413,16 @@ int rope_kv_write(int dtype, const void* QKV, const void* table, const int64_t* 
     return finish_launch();
 }
 
-template <typename T>
-static int launch_attention(const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
-                            int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
+template <typename T, bool ROPE>
+static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G,
+                            int64_t D, int64_t capacity, const void* table, const int64_t* pos, const int64_t* widx,
+                            int64_t ldq, hipStream_t st) {
     const float sq = sqrtf((float)D);
 #define QL_ATT(DD)                                                                                                  \
     {                                                                                                               \
-        const size_t lds = (size_t)(capacity + DD + 4 + (256 / (DD / 8)) * DD) * sizeof(float);                     \
-        decode_attention_kernel<T, DD><<<(unsigned)(B * H), 256, lds, st>>>((const T*)Q, (const T*)Kc, (const T*)Vc, mask, \
-                                                                            (T*)Out, (int)H, (int)G, (int)capacity, sq);  \
+        const size_t lds = (size_t)(capacity + DD + 4 + (256 / (DD / 8)) * DD + 2 * DD) * sizeof(float);           \
+        decode_attention_kernel<T, DD, ROPE><<<(unsigned)(B * H), 256, lds, st>>>(                                  \
+            (const T*)Q, (T*)Kc, (T*)Vc, mask, (T*)Out, (int)H, (int)G, (int)capacity, sq, (const T*)table, pos, widx, ldq); \
     }
     if (D == 128) QL_ATT(128)
     else if (D == 64) QL_ATT(64)
@@ -371,7 +434,15 @@ static int launch_attention(const void* Q, const void* Kc, const void* Vc, const
 
 int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
-    QL_DT(dtype, return (launch_attention<T>(Q, Kc, Vc, mask, Out, B, H, G, D, capacity, st)))
+    QL_DT(dtype, return (launch_attention<T, false>(Q, (void*)Kc, (void*)Vc, mask, Out, B, H, G, D, capacity, nullptr, nullptr,
+                                                    nullptr, 0, st)))
+    return QL_ERR_BAD_DTYPE;
+}
+
+int decode_attention_rope(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kc,
+                          void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
+                          int64_t capacity, int64_t ldqkv, hipStream_t st) {
+    QL_DT(dtype, return (launch_attention<T, true>(QKV, Kc, Vc, mask, Out, B, H, G, D, capacity, table, pos, widx, ldqkv, st)))
     return QL_ERR_BAD_DTYPE;
 }
 

@@ -69,6 +69,27 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
     return out
 
 
+def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
+                          mask: Tensor, n_head: int, n_groups: int, d_head: int) -> Tensor:
+    """``decode_attention(rope_kv_write(qkv, ...), ...)`` for one position per sequence in a single launch:
+    qkv (B, 1, (H+2G) D) -> (B, 1, H*D); the rotated key and the value are written into the caches at
+    ``write_index[0]``."""
+    lib = _lib.get_lib()
+    B, S, W = qkv.shape
+    if S != 1:
+        raise ValueError("decode_attention_rope serves one position per sequence")
+    qkv = qkv.contiguous()
+    out = torch.empty((B, 1, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
+    with torch.cuda.device(qkv.device):
+        st = lib.qlinear_decode_attention_rope(qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(),
+                                               write_index.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                               mask.data_ptr(), out.data_ptr(), B, n_head, n_groups, d_head,
+                                               k_cache.shape[1], W, _lib.dtype_code(qkv.dtype),
+                                               _lib.stream_ptr(qkv.device))
+    _lib.check(st, "qlinear_decode_attention_rope")
+    return out
+
+
 def silu_mul(x: Tensor, hidden: int) -> Tensor:
     lib = _lib.get_lib()
     x2 = x.reshape(-1, x.shape[-1])

@@ -227,11 +227,12 @@ class ChatGLM2Model(nn.Module):
                 x = F_.rmsnorm(h, layer.attn_ln.weight, layer.attn_ln.eps)
             else:                                      # h += delta and the next norm in one launch
                 h, x = F_.add_rmsnorm(h, delta, layer.attn_ln.weight, layer.attn_ln.eps)
-            q = F_.rope_kv_write(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
-                                 cache.k[i], cache.v[i], H, G, D)
-            if S == 1:
-                att = F_.decode_attention(q, cache.k[i], cache.v[i], mask, H, G, D)
+            if S == 1:                                 # rotary + cache write + attention: one launch
+                att = F_.decode_attention_rope(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
+                                               cache.k[i], cache.v[i], mask, H, G, D)
             else:
+                q = F_.rope_kv_write(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
+                                     cache.k[i], cache.v[i], H, G, D)
                 att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i], cache.v[i], mask)
             h, x = F_.add_rmsnorm(h, layer.attn.o_proj(att), layer.ffn_ln.weight, layer.ffn_ln.eps)
             delta = layer.ffn.w_out(F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim))
@@ -251,9 +252,9 @@ class ChatGLM2Model(nn.Module):
         return ok
 
     def _step_one_row(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor) -> Tensor:
-        """Decode step of ONE row: 6 launches per layer.  The residual add + RMSNorm in front of qkv_proj / w_in /
+        """Decode step of ONE row: 5 launches per layer.  The residual add + RMSNorm in front of qkv_proj / w_in /
         lm_head run inside those QLinear kernels' activation staging (qlinear_w4g32_fwd_packed_fused); rotary +
-        cache write and the attention are one launch each; SiLU * gate is w_in's epilogue."""
+        cache write + attention are one launch; SiLU * gate is w_in's epilogue."""
         from . import _lib, fused_ops as F_
         from .int4 import hip_ops as H4
         c = self.config
@@ -265,8 +266,8 @@ class ChatGLM2Model(nn.Module):
             qkv = H4.w4_forward_fused(_lib.PRO_ADDNORM, h, at.qkv_proj.prepare()._packed, at.qkv_proj.out_features,
                                       at.qkv_proj.bias, delta, layer.attn_ln.weight, hn, layer.attn_ln.eps)
             h = hn
-            q = F_.rope_kv_write(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i], H, G, D)
-            o = at.o_proj(F_.decode_attention(q, cache.k[i], cache.v[i], mask, H, G, D))
+            o = at.o_proj(F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i],
+                                                   cache.v[i], mask, H, G, D))
             hn = torch.empty_like(h)
             # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its derived layout (each wave owns
             # (h, h, gate, gate) column quads), so the (1, 2 * hidden) intermediate is never written.  (As a

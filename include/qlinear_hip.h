@@ -170,6 +170,8 @@ int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, vo
  *                                                                                              model.py:139-155
  * decode_attention:  one query position: q (B, H*D), mask (B, capacity) additive fp32 -> out (B, H*D)
  *                                                                                              model.py:157-175
+ * decode_attention_rope: rope_kv_write (S = 1) and decode_attention in ONE launch: qkv (B, (H+2G)*D) in, the
+ *                    cache row widx[0] written by one block per (b, group), out (B, H*D)
  * silu_mul:          in (rows, 2*hidden) -> out[r,i] = round(round(silu(in[r,i])) * in[r,hidden+i])   model.py:200-201 */
 int qlinear_rmsnorm(const void* X, const void* W, void* Out, int64_t rows, int64_t dim, int64_t ldx, int64_t ldo,
                     float eps, int dtype, void* stream);
@@ -180,6 +182,9 @@ int qlinear_rope_kv_write(const void* QKV, const void* table, const int64_t* pos
                           int64_t capacity, int64_t ldqkv, int dtype, void* stream);
 int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, void* Out,
                              int64_t B, int64_t H, int64_t G, int64_t D, int64_t capacity, int dtype, void* stream);
+int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
+                                  void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
+                                  int64_t capacity, int64_t ldqkv, int dtype, void* stream);
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream);
 /* greedy decode bookkeeping in one launch (chatglm_q/decoder.py:85,97 with temperature -> 0): tok[b] = argmax of logits

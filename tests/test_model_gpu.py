@@ -165,3 +165,31 @@ def test_gate_epilogue_equals_separate_ops(dtype, bias):
         assert layer.gated_packed(hidden)[0] is gp
         layer.weight.add_(1)
         assert layer.gated_packed(hidden)[0] is not gp
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("geom", [(2, 32, 2, 128, 192, 70), (3, 8, 4, 64, 64, 0), (1, 4, 1, 32, 40, 39)])
+def test_rope_attention_single_launch_equals_two(dtype, geom):
+    """decode_attention_rope against rope_kv_write followed by decode_attention: same cache rows bit for bit,
+    same attention output up to the position of the new value in the PV sum."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd import model as M
+    B, H, Gq, D, cap, n = geom                               # n = positions already cached; the step writes row n
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(B, 1, (H + 2 * Gq) * D, device=DEV, generator=g).to(dtype)
+    table = M.rotary_table(D, cap + 8).to(DEV).to(dtype).reshape(cap + 8, -1).contiguous()
+    pos = torch.full((B, 1), n + 1, dtype=torch.long, device=DEV)
+    widx = torch.tensor([n], dtype=torch.long, device=DEV)
+    mask = torch.full((B, 1, cap), -1e10, device=DEV)
+    mask[:, :, : n + 1] = 0
+    caches = []
+    for _ in range(2):
+        g2 = torch.Generator(device=DEV).manual_seed(6)
+        caches.append((torch.randn(B, cap, Gq, D, device=DEV, generator=g2).to(dtype),
+                       torch.randn(B, cap, Gq, D, device=DEV, generator=g2).to(dtype)))
+    (k1, v1), (k2, v2) = caches
+    q = F_.rope_kv_write(qkv, table, pos, widx, k1, v1, H, Gq, D)
+    want = F_.decode_attention(q, k1, v1, mask, H, Gq, D)
+    got = F_.decode_attention_rope(qkv, table, pos, widx, k2, v2, mask, H, Gq, D)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert O.rel_l2(t2n(got), t2n(want)) < (1e-5 if dtype == torch.float32 else 2e-3)
