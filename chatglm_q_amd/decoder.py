@@ -84,7 +84,7 @@ class DecodeSession:
             rows = torch.arange(self.length + s0, self.length + s1, device=self.device)
             mask = ((t[None, :] > rows[:, None]).float() * -1e10)[None].expand(B, -1, -1)
             logits = self.model.step(ids[:, s0:s1], self.cache, rows, (rows + 1)[None].expand(B, -1), mask,
-                                     last_only=True)
+                                     last_only=True, kv_len=self.length + s1)
         self.length += S
         self.cache.length = self.length
         # arm the decode-step state

@@ -191,33 +191,39 @@ class ChatGLM2Model(nn.Module):
 
     # -- one pass over `n_new` positions against a preallocated cache ------------------------------
     def step(self, input_ids: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
-             last_only: bool = False) -> Tensor:
+             last_only: bool = False, kv_len: Optional[int] = None) -> Tensor:
         """Shape-static forward: embeds input_ids (B, S), writes the new keys/values into the cache rows
         `write_index` (S,), attends over the WHOLE cache capacity under the additive `mask` (B, S, capacity)
         and returns logits.  Every argument is a device tensor, so the call can be captured in a HIP graph
         and replayed with new contents.  `last_only` evaluates lm_head for the final position only (the
-        decode loop uses nothing else, chatglm_q/decoder.py:85)."""
+        decode loop uses nothing else, chatglm_q/decoder.py:85).  `kv_len` (a HOST integer, so not for captured
+        steps) promises that every cache row >= kv_len is masked: attention then reads only the first kv_len
+        rows - the same sums, since a masked column's probability is exactly 0 (prefill uses this)."""
         h = self.word_embedding(input_ids)
+        if kv_len is not None:
+            mask = mask[..., :kv_len]
         if FUSED_DECODE_OPS and h.is_cuda:
-            return self._step_fused(h, cache, write_index, position_ids, mask, last_only)
+            return self._step_fused(h, cache, write_index, position_ids, mask, last_only, kv_len)
         cs = self._rotary(position_ids)
         for i, layer in enumerate(self.layers):
             q, k, v = layer.attn.project(layer.attn_ln(h), cs)
             cache.k[i].index_copy_(1, write_index, k)
             cache.v[i].index_copy_(1, write_index, v)
-            h = h + layer.attn.attend(h.dtype, q, cache.k[i], cache.v[i], mask)
+            h = h + layer.attn.attend(h.dtype, q, cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
             h = h + layer.ffn(layer.ffn_ln(h))
         h = self.final_ln(h[:, -1:] if last_only else h)
         return self.lm_head(h)
 
     def _step_fused(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
-                    last_only: bool) -> Tensor:
+                    last_only: bool, kv_len: Optional[int] = None) -> Tensor:
         """Same graph with the small ops around the QLinear calls fused into single HIP launches
         (csrc/decode_ops.hip): RMSNorm; split + rotary + cache write; single-position attention; SiLU * gate."""
         from . import fused_ops as F_
         c = self.config
         H, G, D = c.num_attention_heads, c.num_multi_query_groups, c.head_hidden_size
         B, S, _ = h.shape
+        if S == 1:
+            kv_len = None                              # the one-position kernels take the whole cache + mask
         mask = mask.contiguous()
         if B * S == 1 and h.dtype in (torch.float16, torch.bfloat16) and self._int4_packed_ready():
             return self._step_one_row(h, cache, write_index, position_ids, mask)
@@ -233,7 +239,7 @@ class ChatGLM2Model(nn.Module):
             else:
                 q = F_.rope_kv_write(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
                                      cache.k[i], cache.v[i], H, G, D)
-                att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i], cache.v[i], mask)
+                att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
             h, x = F_.add_rmsnorm(h, layer.attn.o_proj(att), layer.ffn_ln.weight, layer.ffn_ln.eps)
             delta = layer.ffn.w_out(F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim))
         if last_only:
