@@ -40,6 +40,8 @@ EXPORTS = {
     "qlinear_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "qlinear_w4g32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_bwd_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                        c_int64, c_int, c_void_p]),
     "qlinear_w4g32_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
@@ -48,9 +50,11 @@ EXPORTS = {
                                                c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w8_bwd_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                     c_int, c_void_p]),
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                 c_int64, c_int64, c_int, c_void_p]),
+                                 c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_qembedding_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                       c_int, c_void_p]),
     "qlinear_qembedding_w8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,

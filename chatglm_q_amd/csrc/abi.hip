@@ -62,6 +62,8 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
         return (M > 4 && group == 32 && K % 32 == 0) ? w4_packed_gemm_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8_FWD:
         return (M > 4 && K % 16 == 0) ? w8_gemm_workspace_bytes(M, N, K) : 0;
+    case QL_OP_W8A8_FWD:             // optional too: int32 split-K slabs for shapes with few row tiles
+        return K % 16 == 0 ? w8a8_workspace_bytes(M, N, K) : 0;
     default: return 0;
     }
 }
@@ -79,6 +81,17 @@ int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const voi
     const size_t need = w4_canon_workspace_bytes(M, N, K);
     if (need && (!workspace || workspace_bytes < need || !aligned(workspace, 16))) return QL_ERR_WORKSPACE;
     return w4_canon(dtype, A, Wq, S, bias, C, workspace, M, N, K, lda, ldc, st);
+}
+
+int qlinear_w4g32_bwd_input(const void* Gout, const uint8_t* Wq, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
+                            int64_t group, int64_t ldg, int64_t ldda, int dtype, void* stream) {
+    if (!Gout || !Wq || !S || !dA) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || ldg < N || ldda < K) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (N % 16 != 0 || N < 16 || (ldda & 1)) return QL_ERR_UNSUPPORTED;    /* 16-byte loads along the contraction */
+    if (!aligned(Wq, 16) || !aligned(S, 16) || !act_vec_ok(Gout, ldg, dtype) || !aligned(dA, 4)) return QL_ERR_MISALIGNED;
+    return w4_tgemm(dtype, Gout, Wq, S, dA, M, K, N, ldg, N, N, ldda, (hipStream_t)stream);
 }
 
 size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
@@ -143,6 +156,17 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);
 }
 
+int qlinear_w8_bwd_input(const void* Gout, const int8_t* Wkn, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
+                         int64_t ldg, int64_t ldda, int dtype, void* stream) {
+    if (!Gout || !Wkn || !S || !dA) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldg < N || ldda < K) return QL_ERR_BAD_SHAPE;
+    if (N % 16 != 0 || N < 16) return QL_ERR_UNSUPPORTED;                  /* 16-byte loads along the contraction */
+    if (!aligned(Wkn, 16) || !aligned(S, 16) || !act_vec_ok(Gout, ldg, dtype)) return QL_ERR_MISALIGNED;
+    /* the forward GEMM with the roles renamed: rows = K outputs, contraction = N, scale on the contraction */
+    return w8_gemm_scale_k(dtype, Gout, Wkn, S, dA, M, K, N, N, ldg, ldda, (hipStream_t)stream);
+}
+
 int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                                  int dtype, void* stream) {
     if (!A || !Aq || !a_scale) return QL_ERR_NULL_POINTER;
@@ -152,13 +176,14 @@ int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int6
 }
 
 int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
-                     void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+                     void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     if (!Aq || !a_scale || !W || !S || !C) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
     if (K % 16 != 0) return QL_ERR_UNSUPPORTED;     /* rows are read in 16-byte units */
     if (!aligned(Aq, 16) || !aligned(W, 16)) return QL_ERR_MISALIGNED;
-    return w8a8_gemm(dtype, Aq, a_scale, W, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
+    return w8a8_gemm(dtype, Aq, a_scale, W, S, bias, C, M, N, K, ldc, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int qlinear_qembedding_w4(const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count, int64_t V,

@@ -31,6 +31,10 @@ int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bia
                    int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+// w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
+int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,
+             int64_t lda, int64_t ldw, int64_t lds, int64_t ldc, hipStream_t st);
+
 // w8_kernels.hip
 int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
@@ -75,10 +79,13 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
             int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int w8_gemm_scale_k(int dtype, const void* A, const int8_t* W, const void* S, void* C, int64_t M, int64_t N, int64_t K,
+                    int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st);
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
-              void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st);
+              void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
+size_t w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 // embed_kernels.hip
 int qembedding_w4(int dtype, const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count,

@@ -50,6 +50,33 @@ template <> struct W8Mma<f16> {
         return __builtin_bit_cast(frag, r);
     }
 };
+// the same with one scale PER contraction element (backward: the scale belongs to the contraction index);
+// sc holds the octet's 8 scales in the operand's own element order
+__device__ __forceinline__ w8_f16x8 w8_dequant_sk(u32 w0, u32 w1, u32 k_mask, u32 k_magic, u32x4 sc, f16) {
+    const h2 k1152 = {(f16)1152.0f, (f16)1152.0f};
+    const u32 t0 = w0 ^ 0x80808080u, t1 = w1 ^ 0x80808080u;
+    u32x4 r;
+    r[0] = as_u32((as_h2((t0 & k_mask) | k_magic) - k1152) * as_h2(sc[0]));
+    r[1] = as_u32((as_h2(((t0 >> 8) & k_mask) | k_magic) - k1152) * as_h2(sc[1]));
+    r[2] = as_u32((as_h2((t1 & k_mask) | k_magic) - k1152) * as_h2(sc[2]));
+    r[3] = as_u32((as_h2(((t1 >> 8) & k_mask) | k_magic) - k1152) * as_h2(sc[3]));
+    return __builtin_bit_cast(w8_f16x8, r);
+}
+__device__ __forceinline__ w8_bf16x8 w8_dequant_sk(u32 w0, u32 w1, u32, u32, u32x4 sc, __bf16) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 w = i < 2 ? w0 : w1;
+        const int sh = 16 * (i & 1);
+        const float lo = (float)((int)(w << (24 - sh)) >> 24) * u32_as_f32(sc[i] << 16);
+        const float hi = (float)((int)(w << (16 - sh)) >> 24) * u32_as_f32(sc[i] & 0xFFFF0000u);
+        const bf2 p = {(__bf16)lo, (__bf16)hi};
+        r[i] = __builtin_bit_cast(u32, p);
+    }
+    return __builtin_bit_cast(w8_bf16x8, r);
+}
+
 template <> struct W8Mma<__bf16> {
     typedef w8_bf16x8 frag;
     static constexpr bool kPairedA = false;    // natural K order
@@ -72,7 +99,10 @@ template <> struct W8Mma<__bf16> {
     }
 };
 
-template <typename T, int MT, int NW, int DEPTH>
+// SK = false: S[n] scales the output channel (forward).  SK = true: S[k] scales the CONTRACTION index (the backward
+// product grad_A = grad_out . (W * s[:, None]) on a (K_out, N) row-major copy of the weights): the step's 64 scales go
+// through LDS (128 bytes per block) and are read back as broadcast fragments.
+template <typename T, int MT, int NW, int DEPTH, bool SK = false>
 __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
                                                       const T* __restrict__ S, const T* __restrict__ bias, T* __restrict__ C,
                                                       int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc,
@@ -83,6 +113,7 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     constexpr bool kAllStage = (BM * 8) % NTHR == 0;
     typedef W8Mma<T> MM;
     __shared__ __attribute__((aligned(16))) char smem[2][BM * 128];
+    __shared__ __attribute__((aligned(16))) char ssk[2][SK ? 128 : 16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kb = lane >> 5;
@@ -101,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
 
     const int8_t* wrow = W + (int64_t)n * ldw + kb * 32;
-    const float sc = Act<T>::load(S + n);
+    const float sc = SK ? 0.f : Act<T>::load(S + n);
 
     const T* a_src[CH];
     int a_dst[CH];
@@ -125,9 +156,14 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     struct Stage {
         u32x4 a[CH];
         u32x4 w[2];
+        u32x4 s;                               // SK: chunk (tid & 7) of the step's 64 scales
     };
     Stage st[DEPTH];
     auto load_stage = [&](int kt, Stage& sg) {
+        if constexpr (SK) {
+            const int c = tid & 7, k = kt * 64 + c * 8;
+            sg.s = *reinterpret_cast<const u32x4*>(S + (k <= kmax_a ? k : kmax_a));
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int c = (tid + u * NTHR) & 7;
@@ -145,6 +181,9 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
         for (int u = 0; u < CH; ++u)
             if (kAllStage || tid + u * NTHR < BM * 8)
                 *reinterpret_cast<u32x4*>(smem[buf] + a_dst[u]) = MM::kPairedA ? w8g_pair_even_odd(sg.a[u]) : sg.a[u];
+        if constexpr (SK) {
+            if (tid < 8) *reinterpret_cast<u32x4*>(ssk[buf] + tid * 16) = MM::kPairedA ? w8g_pair_even_odd(sg.s) : sg.s;
+        }
     };
     auto mma_step = [&](int buf, int kt, const u32x4 (&w_in)[2]) {
         // bytes of a K tail (k >= K) are replaced by 0: b = 0 contributes nothing whatever the (clamped) activations are
@@ -159,16 +198,23 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
                 fr[mt] = *reinterpret_cast<const u32x4*>(smem[buf] + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
             }
         };
+        auto deq = [&](int sub) {
+            if constexpr (SK) {
+                const u32x4 fs = *reinterpret_cast<const u32x4*>(ssk[buf] + (kb * 4 + sub) * 16);   // broadcast read
+                return w8_dequant_sk(w[sub >> 1][2 * (sub & 1)], w[sub >> 1][2 * (sub & 1) + 1], k_mask, k_magic, fs, T());
+            } else {
+                return MM::dequant(w[sub >> 1][2 * (sub & 1)], w[sub >> 1][2 * (sub & 1) + 1], k_mask, k_magic, sc);
+            }
+        };
         u32x4 fa[2][MT];
         typename MM::frag fb[2];
         read_a(0, fa[0]);
-        fb[0] = MM::dequant(w[0][0], w[0][1], k_mask, k_magic, sc);
+        fb[0] = deq(0);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             if (sub < 3) {
                 read_a(sub + 1, fa[(sub + 1) & 1]);
-                const int s1 = sub + 1;
-                fb[s1 & 1] = MM::dequant(w[s1 >> 1][2 * (s1 & 1)], w[s1 >> 1][2 * (s1 & 1) + 1], k_mask, k_magic, sc);
+                fb[(sub + 1) & 1] = deq(sub + 1);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -223,14 +269,14 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, bool SK = false>
 static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int M, int N, int K,
                           int64_t ldw, int64_t lda, int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
     float* part = plan.ksplit > 1 ? ws : nullptr;
     constexpr int BN = NW * 32;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
-    w8_gemm_kernel<T, MT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
+    w8_gemm_kernel<T, MT, NW, 3, SK><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
                                                            ldc, part, plan.per,
         xcd_order(nbx, nby, (double)M * K * 2, (double)N * K));
     const int rc = finish_launch();
@@ -252,6 +298,26 @@ static int launch_w8_gemm_any(const void* A, const int8_t* W, const void* S, con
         return launch_w8_gemm<T, 4, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
     case 2: return launch_w8_gemm<T, 2, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
     default: return launch_w8_gemm<T, 1, 4>(A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, (float*)ws, st);
+    }
+}
+
+// backward: C (M, N) = A (M, K) . (W (N, K) with S[k] on the contraction)^T ; no bias, no split-K
+template <typename T>
+static int launch_w8_gemm_sk(const void* A, const int8_t* W, const void* S, void* C, int64_t M, int64_t N, int64_t K,
+                             int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+    const GemmPlan plan{0, 1, (int)((K + 63) / 64)};
+    if (M > 64 && ((N + 127) / 128) * ((M + 127) / 128) >= 256)
+        return launch_w8_gemm<T, 4, 4, true>(A, W, S, nullptr, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, nullptr, st);
+    if (M > 32) return launch_w8_gemm<T, 2, 4, true>(A, W, S, nullptr, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, nullptr, st);
+    return launch_w8_gemm<T, 1, 4, true>(A, W, S, nullptr, C, (int)M, (int)N, (int)K, ldw, lda, ldc, plan, nullptr, st);
+}
+
+int w8_gemm_scale_k(int dtype, const void* A, const int8_t* W, const void* S, void* C, int64_t M, int64_t N, int64_t K,
+                    int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_w8_gemm_sk<f16>(A, W, S, C, M, N, K, ldw, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_w8_gemm_sk<__bf16>(A, W, S, C, M, N, K, ldw, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
     }
 }
 

@@ -466,7 +466,7 @@ template <typename T, int MT, int DEPTH>
 __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict__ Aq, const float* __restrict__ a_scale,
                                                         const int8_t* __restrict__ W, const T* __restrict__ S,
                                                         const T* __restrict__ bias, T* __restrict__ C, int M, int N,
-                                                        int K, int64_t ldc) {
+                                                        int K, int64_t ldc, int* __restrict__ part, int per) {
     constexpr int BM = 32 * MT;
     constexpr int ACH = BM * 8 / 256;          // 16-byte A chunks staged per thread per K step
     constexpr int WCH = 4;                     // 128 rows x 8 chunks / 256 threads
@@ -477,6 +477,10 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
     const int j = lane & 31, kb = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 128;
     const int ksteps = (K + 127) >> 7;
+    // split-K (few row tiles): this block's K steps are [k0, k0 + nst); the int32 slabs add up exactly
+    const int k0 = blockIdx.z * per;
+    const int nst = ksteps - k0 < per ? ksteps - k0 : per;
+    auto gstep = [&](int t) { return k0 + (t < nst ? t : nst - 1); };
 
     const int8_t* a_src[ACH];
     int a_dst[ACH];
@@ -552,34 +556,32 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
 
     // prologue: DEPTH steps in flight (a step index past the end re-reads the last step: never stored)
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) load_tiles(d < ksteps ? d : ksteps - 1, a_st[d], w_st[d]);
-    store_tiles(0, 0, a_st[0], w_st[0]);
+    for (int d = 0; d < DEPTH; ++d) load_tiles(gstep(d), a_st[d], w_st[d]);
+    store_tiles(0, gstep(0), a_st[0], w_st[0]);
     __syncthreads();
 
     // steady state: every load is unconditional and real (a load under `if (more)` makes hipcc wait
     // vmcnt(0) - for the loads it just issued - before each ds_write; see w4_packed.hip)
     int kt = 0;
-    for (; kt + DEPTH < ksteps; kt += DEPTH) {
+    for (; kt + DEPTH < nst; kt += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int buf = (kt + d) & 1;
-            if (kt + d + DEPTH < ksteps) {
-                load_tiles(kt + d + DEPTH, a_st[d], w_st[d]);      // slot d was stored to LDS last step
-            } else {
-                load_tiles(ksteps - 1, a_st[d], w_st[d]);          // harmless re-read, keeps the load count exact
-            }
+            // slot d was stored to LDS last step; past the end this is a harmless re-read of the last step
+            // (keeps the load count exact)
+            load_tiles(gstep(kt + d + DEPTH), a_st[d], w_st[d]);
             mma_step(buf);
-            store_tiles(buf ^ 1, kt + d + 1, a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
+            store_tiles(buf ^ 1, gstep(kt + d + 1), a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }
     // tail: at most DEPTH steps, no further loads
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        if (kt + d < ksteps) {
+        if (kt + d < nst) {
             const int buf = (kt + d) & 1;
             mma_step(buf);
-            if (kt + d + 1 < ksteps) store_tiles(buf ^ 1, kt + d + 1, a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
+            if (kt + d + 1 < nst) store_tiles(buf ^ 1, gstep(kt + d + 1), a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
             __syncthreads();
         }
     }
@@ -593,7 +595,10 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
-                if (m < M) {
+                if (m >= M) continue;
+                if (part) {
+                    part[((int64_t)blockIdx.z * M + m) * N + n] = acc[mt][i];
+                } else {
                     const float comb = a_scale[m] * ws;
                     store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][i] * comb, bn);
                 }
@@ -696,27 +701,77 @@ static int launch_act_quant(const void* A, int8_t* Aq, float* a_scale, int64_t M
     return finish_launch();
 }
 
+// split-K epilogue of the W8A8 GEMM: exact int32 sum of the slabs, then the rank-1 scale, one rounding, bias
+template <typename T>
+__global__ __launch_bounds__(256) void w8a8_splitk_reduce_kernel(const int* __restrict__ part, const float* __restrict__ a_scale,
+                                                                 const T* __restrict__ S, const T* __restrict__ bias,
+                                                                 T* __restrict__ C, int M, int N, int64_t ldc, int ksplit) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    int v = 0;
+    for (int s = 0; s < ksplit; ++s) v += part[((int64_t)s * M + m) * N + n];
+    store_out<T>(C + (int64_t)m * ldc + n, (float)v * (a_scale[m] * Act<T>::load(S + n)), bias ? bias + n : nullptr);
+}
+
+struct W8A8Plan {
+    int mt, ksplit, per;
+};
+// rows per block: large tiles once they still give >= ~1 block per CU, smaller ones to fill the chip; when even
+// those leave most CUs idle, split K (exact: the slabs are int32)
+static W8A8Plan w8a8_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
+    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W8A8_MT"); return e ? atoi(e) : 0; }();
+    static const int forced_ks = [] { const char* e = getenv("QLINEAR_W8A8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int64_t nb = (N + 127) / 128, ksteps = (K + 127) / 128;
+    int mt = (M > 64 && nb * ((M + 127) / 128) >= 256) ? 4 : M > 32 ? 2 : 1;
+    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
+    const int64_t blocks = nb * ((M + 32 * mt - 1) / (32 * mt));
+    // measured: splitting pays only while fewer than half of the CUs have a block (M <= 128 at N = 4096: 27.8 -> 22 us);
+    // at 512 x 4096 x 4096 (256 blocks) the launch is bound by operand traffic L2 -> CU, not by the K chain
+    int64_t ks = forced_ks > 0 ? forced_ks : (blocks < 128 ? 256 / blocks : 1);
+    if (ks > 4 && forced_ks <= 0) ks = 4;
+    if (ks > 8) ks = 8;
+    if (ks > ksteps / 4) ks = ksteps / 4;
+    while (ks > 1 && (size_t)(ks * M * N) * sizeof(int) > ws_bytes) --ks;
+    if (ks < 1) ks = 1;
+    const int64_t per = (ksteps + ks - 1) / ks;
+    ks = (ksteps + per - 1) / per;
+    return {mt, (int)ks, (int)per};
+}
+
 template <typename T, int MT>
 static int launch_w8a8_mt(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
-                          void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)));
-    if ((int64_t)grid.x * grid.y <= 256)
+                          void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, const W8A8Plan& plan, int* ws,
+                          hipStream_t st) {
+    int* part = plan.ksplit > 1 ? ws : nullptr;
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)), (unsigned)plan.ksplit);
+    static const int forced_depth = [] { const char* e = getenv("QLINEAR_W8A8_DEPTH"); return e ? atoi(e) : 0; }();
+    if (forced_depth ? forced_depth == 4 : (int64_t)grid.x * grid.y * grid.z <= 256)
         w8a8_mfma_kernel<T, MT, 4><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
-                                                         (int)N, (int)K, ldc);
+                                                         (int)N, (int)K, ldc, part, plan.per);
     else
         w8a8_mfma_kernel<T, MT, 2><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
-                                                         (int)N, (int)K, ldc);
+                                                         (int)N, (int)K, ldc, part, plan.per);
+    const int rc = finish_launch();
+    if (rc != 0 || !part) return rc;
+    const int64_t total = M * N;
+    w8a8_splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, a_scale, (const T*)S, (const T*)bias,
+                                                                                 (T*)C, (int)M, (int)N, ldc, plan.ksplit);
     return finish_launch();
 }
 
 template <typename T>
 static int launch_w8a8(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
-                       void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    // rows per block: large tiles once they still give >= ~1 block per CU, smaller ones to fill the chip
-    const int64_t nb = (N + 127) / 128;
-    if (M > 64 && nb * ((M + 127) / 128) >= 256) return launch_w8a8_mt<T, 4>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
-    if (M > 32) return launch_w8a8_mt<T, 2>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
-    return launch_w8a8_mt<T, 1>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, st);
+                       void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    const W8A8Plan plan = w8a8_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    if (plan.mt == 4) return launch_w8a8_mt<T, 4>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, plan, (int*)ws, st);
+    if (plan.mt == 2) return launch_w8a8_mt<T, 2>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, plan, (int*)ws, st);
+    return launch_w8a8_mt<T, 1>(Aq, a_scale, W, S, bias, C, M, N, K, ldc, plan, (int*)ws, st);
+}
+
+size_t w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const W8A8Plan p = w8a8_plan(M, N, K, (size_t)-1);
+    return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(int) : 0;
 }
 
 #define QL_DISPATCH_DTYPE(dtype, fn, ...)                         \
@@ -741,8 +796,8 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
     QL_DISPATCH_DTYPE(dtype, launch_act_quant, A, Aq, a_scale, M, K, lda, st)
 }
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
-              void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    QL_DISPATCH_DTYPE(dtype, launch_w8a8, Aq, a_scale, W, S, bias, C, M, N, K, ldc, st)
+              void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    QL_DISPATCH_DTYPE(dtype, launch_w8a8, Aq, a_scale, W, S, bias, C, M, N, K, ldc, ws, ws_bytes, st)
 }
 
 }  // namespace ql

@@ -120,6 +120,50 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     return c.reshape(out_shape)
 
 
+def w4_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
+    """Shapes / dtypes served by qlinear_w4g32_bwd_input (everything else takes the dense torch formula)."""
+    K, N = b.shape[0] * 2, b.shape[1]
+    return (grad_out.is_cuda and grad_out.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == grad_out.dtype
+            and b.dtype == torch.uint8 and b_scale.shape[0] * 32 == K and N % 16 == 0 and N >= 16
+            and b.is_contiguous() and b_scale.is_contiguous() and _lib.available())
+
+
+def w4_grad_input(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> Tensor:
+    """``grad_out @ dequant(b, b_scale).T`` on the canonical layout (reference:
+    dynamic_quant_matmul_transposed_s4, chatglm_q/int4/triton_ops.py:212-264)."""
+    lib = _lib.get_lib()
+    K, N = b.shape[0] * 2, b.shape[1]
+    g2 = _rows(grad_out)
+    M = g2.shape[0]
+    out = torch.empty((M, K), device=grad_out.device, dtype=grad_out.dtype)
+    if M:
+        with torch.cuda.device(grad_out.device):
+            st = lib.qlinear_w4g32_bwd_input(g2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), out.data_ptr(), M, N, K, 32,
+                                             g2.stride(0) if M > 1 else N, K, _lib.dtype_code(grad_out.dtype),
+                                             _lib.stream_ptr(grad_out.device))
+        _lib.check(st, "qlinear_w4g32_bwd_input")
+    return out.reshape(*grad_out.shape[:-1], K)
+
+
+def dynamic_quant_matmul_transposed_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
+    """Same contract as the reference wrapper (chatglm_q/int4/triton_ops.py:212-264): A (..., K), B (N//2, K) uint8,
+    B_scale (N//32, K) -> (..., N).  Unlike the reference kernel it needs no power-of-two sizes (K % 16 == 0)."""
+    del allow_tf32
+    _check_w4_t_args(a, b, b_scale)
+    return w4_grad_input(a, b, b_scale)
+
+
+def _check_w4_t_args(a: Tensor, b: Tensor, b_scale: Tensor) -> None:
+    if b.dim() != 2 or b_scale.dim() != 2:
+        raise AssertionError("B and B_scale must be 2-D")
+    if a.shape[-1] != b.shape[1] or b.shape[1] != b_scale.shape[1]:
+        raise AssertionError(f"K mismatch: {a.shape[-1]}, {b.shape[1]}, {b_scale.shape[1]}")
+    if b.dtype != torch.uint8 or a.dtype != b_scale.dtype:
+        raise AssertionError("B must be uint8 and A / B_scale share a dtype")
+    if not w4_grad_input_supported(a, b, b_scale):
+        raise AssertionError("transposed int4 product: fp16 / bf16 GPU tensors, group 32, K % 16 == 0, contiguous B")
+
+
 def gate_interleave(hidden: int, device=None) -> Tensor:
     """Column order (h_0, h_1, gate_0, gate_1, h_2, h_3, gate_2, gate_3, ...) of a (K, 2 * hidden) first MLP
     projection, as the SiLU * gate epilogue expects it (``hidden`` even)."""

@@ -58,8 +58,9 @@ def unpack_int4(x: Tensor, x_scale: Tensor) -> Tensor:
 class DynamicQuantizeMatMul(torch.autograd.Function):
     """A: (m, k) float; B: (k//2, n) uint8; b_scale: (g, n) float (chatglm_q/int4/qlinear.py:36-68).
 
-    Forward runs the HIP kernel for GPU tensors.  Backward (the reference's transposed Triton kernels,
-    out of this build's scope - SURVEY.md 8f N4) is the dense formula on whatever device A lives on.
+    Forward runs the HIP kernel for GPU tensors.  Backward: ``grad_A = grad_out @ dequant(B).T`` through
+    qlinear_w4g32_bwd_input (fp16 / bf16 GPU tensors, group 32; the reference's transposed Triton kernel,
+    chatglm_q/int4/triton_ops.py:142-264), the dense formula otherwise.
     """
 
     @staticmethod
@@ -74,7 +75,10 @@ class DynamicQuantizeMatMul(torch.autograd.Function):
         A, B, b_scale = ctx.saved_tensors
         grad_A = None
         if ctx.needs_input_grad[0]:
-            grad_A = grad_out.matmul(unpack_int4(B, b_scale).t())
+            if check_input(A) and hip_ops.w4_grad_input_supported(grad_out, B, b_scale):
+                grad_A = hip_ops.w4_grad_input(grad_out, B, b_scale)
+            else:
+                grad_A = grad_out.matmul(unpack_int4(B, b_scale).t())
         return grad_A, None, None
 
     @staticmethod
@@ -149,7 +153,7 @@ class DynamicQuantizeLinear(nn.Module):
             if input.requires_grad and torch.is_grad_enabled():
                 out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
                 if self.bias is not None:
-                    out += self.bias
+                    out = out + self.bias      # not in place: the Function's output may be a view
                 return out
             rows = input.numel() // max(input.shape[-1], 1)
             packed = None

@@ -79,6 +79,44 @@ def dynamic_quant_matmul(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool
     return w8_forward(a, b, b_scale)
 
 
+def w8_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
+    """Shapes / dtypes served by qlinear_w8_bwd_input (everything else takes the dense torch formula)."""
+    return (grad_out.is_cuda and grad_out.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == grad_out.dtype
+            and b.dtype == torch.int8 and b.dim() == 2 and b.shape[1] % 16 == 0 and b.shape[1] >= 16 and _lib.available())
+
+
+def w8_grad_input(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> Tensor:
+    """``grad_out @ (b.t() * b_scale[:, None])``; ``b`` is the logical (K, N) int8 matrix (chatglm_q/int8/qlinear.py:
+    41-52).  The kernel wants the contraction index N contiguous: the module's ``weight.t()`` view (strides (1, K)) is
+    materialised as a (K, N) row-major copy first - one pass over the int8 weights per backward call."""
+    lib = _lib.get_lib()
+    K, N = b.shape
+    b_kn = b.contiguous()
+    g2 = _rows(grad_out)
+    M = g2.shape[0]
+    out = torch.empty((M, K), device=grad_out.device, dtype=grad_out.dtype)
+    if M:
+        with torch.cuda.device(grad_out.device):
+            st = lib.qlinear_w8_bwd_input(g2.data_ptr(), b_kn.data_ptr(), b_scale.contiguous().data_ptr(), out.data_ptr(), M, N, K,
+                                          g2.stride(0) if M > 1 else N, K, _lib.dtype_code(grad_out.dtype),
+                                          _lib.stream_ptr(grad_out.device))
+        _lib.check(st, "qlinear_w8_bwd_input")
+    return out.reshape(*grad_out.shape[:-1], K)
+
+
+def dynamic_quant_matmul_transposed(a: Tensor, b_T: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
+    """Same contract as the reference wrapper (chatglm_q/int8/triton_ops.py:205-245): A (..., K), B_T (N, K) int8,
+    B_scale (K) -> (..., N)."""
+    del allow_tf32
+    if a.shape[-1] != b_T.shape[1] or b_T.shape[1] != b_scale.shape[0]:
+        raise AssertionError(f"K mismatch: {a.shape[-1]}, {b_T.shape[1]}, {b_scale.shape[0]}")
+    if b_T.dtype != torch.int8 or a.dtype != b_scale.dtype:
+        raise AssertionError("B_T must be int8 and A / B_scale share a dtype")
+    if not w8_grad_input_supported(a, b_T, b_scale):
+        raise AssertionError("transposed int8 product: fp16 / bf16 GPU tensors, K % 16 == 0")
+    return w8_grad_input(a, b_T, b_scale)
+
+
 def act_quant_rowwise(a: Tensor):
     """Row-wise symmetric int8 quantisation of activations in fp32 arithmetic.
     Returns (a_q (M, K) int8, a_scale (M,) float32)."""
@@ -116,9 +154,11 @@ def w8a8_forward(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | N
         if bias is not None:
             bias = bias.contiguous()
         with torch.cuda.device(a.device):
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8A8_FWD, M, N, K, 0))    # int32 split-K slabs, few row tiles
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
             st = lib.qlinear_w8a8_fwd(a_q.data_ptr(), a_s.data_ptr(), weight_nk.data_ptr(), w_scale.contiguous().data_ptr(),
                                       _lib.ptr(bias), c.data_ptr(), M, N, K, N, _lib.dtype_code(a.dtype),
-                                      _lib.stream_ptr(a.device))
+                                      _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a.device))
         _lib.check(st, "qlinear_w8a8_fwd")
     return c.reshape(out_shape)
 

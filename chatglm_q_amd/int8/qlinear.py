@@ -38,7 +38,10 @@ class DynamicQuantizeMatMul(torch.autograd.Function):
         A, B, b_scale = ctx.saved_tensors
         grad_A = None
         if ctx.needs_input_grad[0]:
-            grad_A = grad_out.matmul(B.t() * b_scale[:, None])
+            if check_input(A) and hip_ops.w8_grad_input_supported(grad_out, B, b_scale):
+                grad_A = hip_ops.w8_grad_input(grad_out, B, b_scale)      # qlinear_w8_bwd_input
+            else:
+                grad_A = grad_out.matmul(B.t() * b_scale[:, None])
         return grad_A, None, None
 
 
@@ -74,7 +77,7 @@ class DynamicQuantizeLinear(nn.Module):
             return hip_ops.w8_forward(input, self.weight.t(), self.weight_scale, self.bias)
         out = dynamic_quant_matmul(input, self.weight.t(), self.weight_scale)
         if self.bias is not None:
-            out += self.bias
+            out = out + self.bias              # not in place: the Function's output may be a view
         return out
 
     @torch.no_grad()

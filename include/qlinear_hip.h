@@ -80,7 +80,7 @@ uint64_t qlinear_launch_count(void);
 
 /* Bytes of scratch the op wants for this shape (0 = none).  The caller allocates it (e.g. from
  * torch's caching allocator so stream semantics hold) and passes it to the op.  It is REQUIRED by
- * QL_OP_W4G32_FWD (QL_ERR_WORKSPACE otherwise) and OPTIONAL for QL_OP_W4G32_FWD_PACKED / QL_OP_W8_FWD,
+ * QL_OP_W4G32_FWD (QL_ERR_WORKSPACE otherwise) and OPTIONAL for QL_OP_W4G32_FWD_PACKED / QL_OP_W8_FWD / QL_OP_W8A8_FWD,
  * where it lets a few-row (5 <= M < ~256) MFMA GEMM split K over workgroups into fp32 slabs that a
  * second launch sums; without it (NULL / too small / not 16-byte aligned) those shapes run unsplit -
  * same rounding sequence, several times slower. */
@@ -103,6 +103,15 @@ int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const voi
  * per 4 columns) so that one wave owns whole output columns and no cross-workgroup reduction is
  * needed.  Built once per weight by qlinear_w4g32_repack from the canonical buffers; canonical
  * buffers remain the source of truth (state_dict).  group must be 32. */
+/* Backward of the int4g32 product w.r.t. the activations (the weights are frozen integers):
+ *   dA (M, K) = Gout (M, N) . dequant(Wq, S)^T      canonical layout, group 32, fp16 / bf16, N % 16 == 0
+ * Same arithmetic as the reference's transposed kernel (every weight rounded to the activation dtype, fp32
+ * accumulation, one output rounding).  Replaces dynamic_quant_matmul_transposed_s4
+ * (chatglm_q/int4/triton_ops.py:142-264) behind DynamicQuantizeMatMul.backward (chatglm_q/int4/qlinear.py:53-64);
+ * unlike the reference's kernel it does not need power-of-two sizes (triton_ops.py:246). */
+int qlinear_w4g32_bwd_input(const void* Gout, const uint8_t* Wq, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
+                            int64_t group, int64_t ldg, int64_t ldda, int dtype, void* stream);
+
 size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K,
                          int64_t group, int dtype, void* stream);
@@ -140,6 +149,15 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
                    int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* Backward of the int8 product w.r.t. the activations:
+ *   dA (M, K) = Gout (M, N) . (Wkn * S[None, :])^T     Wkn = the logical (K, N) matrix, CONTIGUOUS (row stride N),
+ *                                                      i.e. module.weight.t().contiguous(); S (N); fp16 / bf16
+ * every weight rounded to the activation dtype, fp32 accumulation, one output rounding - the arithmetic of
+ * dynamic_quant_matmul_transposed (chatglm_q/int8/triton_ops.py:130-245) behind DynamicQuantizeMatMul.backward
+ * (chatglm_q/int8/qlinear.py:41-52). */
+int qlinear_w8_bwd_input(const void* Gout, const int8_t* Wkn, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
+                         int64_t ldg, int64_t ldda, int dtype, void* stream);
+
 /* ---- int8 activations x int8 weights (true i8 x i8 -> i32 MFMA contraction) ---------------
  * Row-wise symmetric activation quantisation in fp32 arithmetic:
  *   a_scale[m] = max(max_k |A[m,k]| / 127, 1e-10);  Aq = clamp(rint(A / a_scale), -127, 127)
@@ -147,9 +165,9 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
 int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K,
                                  int64_t lda, int dtype, void* stream);
 /* C[m,n] = round(acc_i32[m,n] * (a_scale[m] * w_scale[n])) (+ bias); W is (N, K) row-major. */
-int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S,
-                     const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t ldc,
-                     int dtype, void* stream);
+int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
+                     void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---- quantised embedding gathers ("next" row N3) -------------------------------------------
  * ids: (count) int64 token ids.  int4: Wq (V/2, D) packs along the vocabulary axis, S (V/group, D).

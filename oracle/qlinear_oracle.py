@@ -153,6 +153,21 @@ def w4_matmul(a: np.ndarray, qweight: np.ndarray, scale: np.ndarray,
     return out.reshape(*lead, w.shape[1])
 
 
+def w4_matmul_grad_input(grad_out: np.ndarray, qweight: np.ndarray, scale: np.ndarray,
+                         dtype: str | None = None) -> np.ndarray:
+    """Backward of the int4g32 product w.r.t. the activations: ``grad_A = grad_out @ dequant(qweight, scale).T``.
+
+    Restates DynamicQuantizeMatMul.backward (chatglm_q/int4/qlinear.py:53-64): the dense weight is rounded to the
+    activation dtype first (unpack_int4), one rounding of the result; the transposed Triton kernel does the same
+    per tile (chatglm_q/int4/triton_ops.py:191-197)."""
+    dt = dtype_of(scale, dtype)
+    w = as_f64(unpack_int4(qweight, scale, dt))
+    lead = grad_out.shape[:-1]
+    g2 = as_f64(grad_out).reshape(-1, grad_out.shape[-1])
+    assert g2.shape[1] == w.shape[1], (grad_out.shape, w.shape)
+    return round_to(g2 @ w.T, dt).reshape(*lead, w.shape[0])
+
+
 def quantize_int4(x: np.ndarray, group_k: int = DEFAULT_GROUP_SIZE, dtype: str = "f32"):
     """RTN int4 group quantiser; x is (K, N) in the act dtype.
 
@@ -203,6 +218,16 @@ def w8_matmul(a: np.ndarray, w_kn: np.ndarray, scale: np.ndarray,
     if bias is not None:
         out = round_to(as_f64(out) + as_f64(bias)[None, :], dt)
     return out.reshape(*lead, w.shape[1])
+
+
+def w8_matmul_grad_input(grad_out: np.ndarray, w_kn: np.ndarray, scale: np.ndarray,
+                         dtype: str | None = None) -> np.ndarray:
+    """``grad_A = grad_out @ (B.t() * b_scale[:, None])`` (chatglm_q/int8/qlinear.py:41-52); B is the (K, N) view."""
+    dt = dtype_of(scale, dtype)
+    w = as_f64(w8_dequant(w_kn, scale, dt))
+    lead = grad_out.shape[:-1]
+    g2 = as_f64(grad_out).reshape(-1, grad_out.shape[-1])
+    return round_to(g2 @ w.T, dt).reshape(*lead, w.shape[0])
 
 
 def quantize_int8(x: np.ndarray, dtype: str = "f32"):

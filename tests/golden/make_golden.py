@@ -345,6 +345,37 @@ def gen_model():
     np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **d)
 
 
+def gen_backward():
+    """grad_A of both quantized matmuls through the reference's own autograd functions (CPU route:
+    chatglm_q/int4/qlinear.py:53-64, chatglm_q/int8/qlinear.py:41-52)."""
+    d = {}
+    names = []
+    cases = [("i4_f16_m5", 4, (5, 256), 256, 192, "f16"), ("i4_bf16_m3", 4, (3, 128), 128, 64, "bf16"),
+             ("i4_f32_m4", 4, (4, 128), 128, 96, "f32"), ("i4_f16_rank3", 4, (2, 3, 192), 192, 128, "f16"),
+             ("i8_f16_m5", 8, (5, 256), 256, 192, "f16"), ("i8_bf16_m3", 8, (3, 128), 128, 64, "bf16"),
+             ("i8_f32_m4", 8, (4, 96), 96, 80, "f32")]
+    for i, (name, bits, ashape, K, N, dt) in enumerate(cases):
+        torch.manual_seed(7000 + i)
+        tdt = DT[dt]
+        a = torch.randn(ashape).to(tdt).requires_grad_(True)
+        w = (torch.randn((K, N)) / math.sqrt(K)).to(tdt)
+        go = torch.randn((*ashape[:-1], N)).to(tdt)
+        p = f"{name}/"
+        if bits == 4:
+            bq, bs = refq4.quantize_int4(w)
+            out = ref4.dynamic_quant_matmul(a, bq, bs)
+            d[p + "qweight"] = to_np(bq)
+        else:
+            wq, bs = refq8.quantize_int8(w.t().contiguous())          # (N, K) int8, (N) scales: the module's buffers
+            out = ref8.dynamic_quant_matmul(a, wq.t(), bs)
+            d[p + "weight_nk"] = to_np(wq)
+        out.backward(go)
+        put(d, p + "a", a.detach()); put(d, p + "scale", bs); put(d, p + "grad_out", go); put(d, p + "grad_a", a.grad)
+        names.append(f"{name}:{bits}:{dt}")
+    d["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "backward.npz"), **d)
+
+
 def gen_loader():
     """config.json text, state_dict key order and the greedy shard plan of the reference for a tiny model
     (chatglm_q/loader.py:16-38,139-150) - pins the build's checkpoint-folder writer/reader."""
@@ -369,11 +400,11 @@ def gen_loader():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "loader"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "backward", "loader"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model, "loader": gen_loader}[w]()
+         "embedding": gen_embedding, "model": gen_model, "backward": gen_backward, "loader": gen_loader}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -66,7 +66,7 @@ def test_argument_errors_come_back_as_status_codes_without_a_gpu():
     assert lib.qlinear_w4g32_fwd(p, p, p, None, p, 1, 8, 64, 32, 64, 8, 7, None, 0, None) == -3
     assert lib.qlinear_w4g32_fwd(p, p, p, None, p, 1, 8, 64, 24, 64, 8, 1, None, 0, None) == -4
     assert lib.qlinear_w4g32_fwd_packed(p, p, None, p, 1, 8, 64, 64, 64, 8, 1, 0, None, 0, None) == -4
-    assert lib.qlinear_w8a8_fwd(p, p, p, p, None, p, 1, 8, 40, 8, 1, None) == -7      # K % 16 != 0
+    assert lib.qlinear_w8a8_fwd(p, p, p, p, None, p, 1, 8, 40, 8, 1, None, 0, None) == -7      # K % 16 != 0
     with pytest.raises(ValueError, match="group"):
         _lib.check(-4, "x")
 

@@ -100,3 +100,19 @@ def test_bf16_rounding_helper():
     import torch
     ref = torch.tensor(x, dtype=torch.float64).to(torch.bfloat16).float().numpy()
     assert np.array_equal(O.round_to(x, "bf16"), ref)
+
+
+BWD = G.load("backward.npz")
+
+
+@pytest.mark.parametrize("entry", [str(e) for e in BWD["names"]])
+def test_grad_input_matches_reference_autograd(entry):
+    """grad_A from the reference's own autograd functions (CPU route) pins the oracle's backward restatement."""
+    name, bits, dt = entry.split(":")
+    c = G.case(BWD, name, dt)
+    if bits == "4":
+        got = O.w4_matmul_grad_input(c["grad_out"], c["qweight"], c["scale"], dtype=dt)
+    else:
+        got = O.w8_matmul_grad_input(c["grad_out"], c["weight_nk"].T, c["scale"], dtype=dt)
+    assert got.shape == c["grad_a"].shape
+    _close(got, c["grad_a"], dt)

@@ -303,7 +303,7 @@ def test_w8a8_integer_stage_exact_and_epilogue():
     c = torch.empty((a_q.shape[0], w.shape[0]), device=DEV, dtype=torch.float32)
     one_m = torch.ones(a_q.shape[0], device=DEV)
     st = lib.qlinear_w8a8_fwd(a_q.data_ptr(), one_m.data_ptr(), w.data_ptr(), ones.data_ptr(), None, c.data_ptr(),
-                              a_q.shape[0], w.shape[0], w.shape[1], w.shape[0], 0, _lib.stream_ptr(a.device))
+                              a_q.shape[0], w.shape[0], w.shape[1], w.shape[0], 0, None, 0, _lib.stream_ptr(a.device))
     assert st == 0
     assert np.array_equal(c.cpu().numpy().astype(np.int64), z["acc_i32"].astype(np.int64))
 
@@ -388,3 +388,95 @@ def test_error_reporting_no_exceptions_cross_the_abi():
         h4.dynamic_quant_matmul_s4(a, qw, sc.float())        # dtype mismatch, as the reference asserts
     with pytest.raises(AssertionError):
         h4.dynamic_quant_matmul_s4(a.cpu(), qw, sc)          # CPU tensor handed to the GPU wrapper
+
+
+# ---------------------------------------------------------------------------------------------
+# backward w.r.t. the activations
+# ---------------------------------------------------------------------------------------------
+W4_BWD_SHAPES = [(5, 256, 192, "f16"), (1, 4096, 4096, "f16"), (70, 1024, 208, "f16"), (129, 160, 4608, "bf16"),
+                 (300, 4096, 1024, "bf16"), (2048, 512, 4096, "f16"), (33, 64, 16, "f16")]
+
+
+@pytest.mark.parametrize("M,K,N,dt", W4_BWD_SHAPES)
+def test_w4_grad_input_vs_oracle(M, K, N, dt):
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    q = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8, generator=g)
+    sc = (torch.rand((K // 32, N), generator=g) * 0.01 + 0.001).to(TDT[dt])
+    go = torch.randn((M, N), generator=g).to(TDT[dt])
+    ref = O.w4_matmul_grad_input(t2n(go), q.numpy(), t2n(sc), dtype=dt)
+    out = h4.dynamic_quant_matmul_transposed_s4(go.to(DEV), q.to(DEV), sc.to(DEV))
+    assert out.shape == (M, K)
+    assert O.rel_l2(t2n(out), ref) < REL[dt]
+
+
+def test_w4_backward_golden_and_autograd():
+    """The reference's own grad_A (golden, CPU autograd route) through our autograd function on the GPU, and the
+    module path: a requires_grad input takes the HIP forward AND the HIP backward."""
+    from chatglm_q_amd.int4 import qlinear as q4
+    z = G.load("backward.npz")
+    for entry in z["names"]:
+        name, bits, dt = str(entry).split(":")
+        if bits != "4" or dt == "f32":
+            continue
+        c = G.case(z, name, dt)
+        a = G.to_torch(c["a"], dt).to(DEV).requires_grad_(True)
+        q = G.to_torch(c["qweight"], dt).to(DEV)
+        sc = G.to_torch(c["scale"], dt).to(DEV)
+        before = _lib.get_lib().qlinear_launch_count()
+        out = q4.dynamic_quant_matmul(a, q, sc)
+        out.backward(G.to_torch(c["grad_out"], dt).to(DEV))
+        assert _lib.get_lib().qlinear_launch_count() >= before + 2        # forward and backward both launched HIP kernels
+        assert O.rel_l2(t2n(a.grad), c["grad_a"]) < REL[dt]
+    layer = q4.DynamicQuantizeLinear(256, 192, bias=True, dtype=torch.float16, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV) * 0.01 + 0.001).half())
+    x = torch.randn(3, 7, 256, device=DEV).half().requires_grad_(True)
+    y = layer(x)
+    go = torch.randn_like(y)
+    y.backward(go)
+    ref = O.w4_matmul_grad_input(t2n(go), layer.weight.cpu().numpy(), t2n(layer.weight_scale), dtype="f16")
+    assert O.rel_l2(t2n(x.grad), ref) < REL["f16"]
+
+
+W8_BWD_SHAPES = [(5, 256, 192, "f16"), (1, 4096, 4096, "f16"), (70, 1000, 208, "f16"), (129, 160, 4608, "bf16"),
+                 (300, 4096, 1024, "bf16"), (2048, 512, 4096, "f16"), (33, 64, 16, "f16")]
+
+
+@pytest.mark.parametrize("M,K,N,dt", W8_BWD_SHAPES)
+def test_w8_grad_input_vs_oracle(M, K, N, dt):
+    g = torch.Generator().manual_seed(M * 5 + K + N)
+    w_nk = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)          # the module's buffer
+    sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(TDT[dt])
+    go = torch.randn((M, N), generator=g).to(TDT[dt])
+    ref = O.w8_matmul_grad_input(t2n(go), w_nk.numpy().T, t2n(sc), dtype=dt)
+    out = h8.dynamic_quant_matmul_transposed(go.to(DEV), w_nk.to(DEV).t(), sc.to(DEV))   # B_T = (K, N) view, strides (1, K)
+    assert out.shape == (M, K)
+    assert O.rel_l2(t2n(out), ref) < REL[dt]
+
+
+def test_w8_backward_golden_and_autograd():
+    from chatglm_q_amd.int8 import qlinear as q8m
+    z = G.load("backward.npz")
+    for entry in z["names"]:
+        name, bits, dt = str(entry).split(":")
+        if bits != "8" or dt == "f32":
+            continue
+        c = G.case(z, name, dt)
+        a = G.to_torch(c["a"], dt).to(DEV).requires_grad_(True)
+        w = G.to_torch(c["weight_nk"], dt).to(DEV)
+        sc = G.to_torch(c["scale"], dt).to(DEV)
+        before = _lib.get_lib().qlinear_launch_count()
+        out = q8m.dynamic_quant_matmul(a, w.t(), sc)
+        out.backward(G.to_torch(c["grad_out"], dt).to(DEV))
+        assert _lib.get_lib().qlinear_launch_count() >= before + 2
+        assert O.rel_l2(t2n(a.grad), c["grad_a"]) < REL[dt]
+    layer = q8m.DynamicQuantizeLinear(256, 192, bias=True, dtype=torch.float16, device=DEV)
+    layer.weight.copy_(torch.randint(-127, 128, layer.weight.shape, dtype=torch.int8, device=DEV))
+    layer.weight_scale.copy_((torch.rand(192, device=DEV) * 0.01 + 0.001).half())
+    layer.bias.zero_()
+    x = torch.randn(3, 7, 256, device=DEV).half().requires_grad_(True)
+    y = layer(x)
+    go = torch.randn_like(y)
+    y.backward(go)
+    ref = O.w8_matmul_grad_input(t2n(go), layer.weight.cpu().numpy().T, t2n(layer.weight_scale), dtype="f16")
+    assert O.rel_l2(t2n(x.grad), ref) < REL["f16"]
