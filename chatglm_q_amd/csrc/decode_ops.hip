@@ -13,6 +13,11 @@
 #include "launch.h"
 #include "ql_common.h"
 
+// developer ablation switches for tools/microbench/attn_ablate.hip (always 0 in the library)
+#ifndef QL_ATT_ABLATE
+#define QL_ATT_ABLATE 0
+#endif
+
 namespace ql {
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
@@ -23,11 +28,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ float block_max_256(float v, float* red) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -193,6 +194,32 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     float* vnew = knew + D;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int g = h / (H / G);
+    const T* kb = Kc + ((int64_t)b * capacity * G + g) * D;
+    const T* vb = Vc + ((int64_t)b * capacity * G + g) * D;
+    const float* mk = mask + (int64_t)b * capacity;
+    // Thread (c, r) owns 16-byte chunk c of rows r, r + RP, r + 2 RP, ... in BOTH phases (Q.K and P.V).  A decode step
+    // gives this kernel ~32 blocks, so its time is a chain of global round trips, not bandwidth: for the 16-bit
+    // dtypes the key chunks, value chunks and mask entries of the first NP rows per thread (256 positions) are
+    // requested before anything else - the rotary phase and the softmax then run under those loads.
+    constexpr int RP = 256 / CH;
+    constexpr bool kPre = sizeof(T) == 2 && !(QL_ATT_ABLATE & 32);
+    constexpr int NP = kPre ? 256 / RP : 1;
+    const int c = threadIdx.x % CH, r = threadIdx.x / CH;
+    u32x4 kr[NP], vr[NP];
+    float mr[NP];
+    if constexpr (kPre) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int t = r + RP * i, tc = t < capacity ? t : capacity - 1;
+            kr[i] = *reinterpret_cast<const u32x4*>(kb + (int64_t)tc * G * D + c * 8);
+            mr[i] = mk[tc];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int t = r + RP * i, tc = t < capacity ? t : capacity - 1;
+            vr[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)tc * G * D + c * 8);
+        }
+    }
     int wrow = -1;
     if constexpr (ROPE) {
         // Q is the fused projection row (H q heads | G k heads | G v heads); rotate q and k exactly as
@@ -205,8 +232,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         if (d < D) {
             const int p = d < D / 2 ? d : d - D / 2;
             const T* x = d < D / 2 ? row + h * D : row + (H + g) * D;
-            const float x0 = Act<T>::load(x + 2 * p), x1 = Act<T>::load(x + 2 * p + 1);
-            const float c0 = Act<T>::load(cs + 2 * p), c1 = Act<T>::load(cs + 2 * p + 1);
+            const float x0 = (QL_ATT_ABLATE & 1) ? 0.5f : Act<T>::load(x + 2 * p), x1 = (QL_ATT_ABLATE & 1) ? 0.25f : Act<T>::load(x + 2 * p + 1);
+            const float c0 = (QL_ATT_ABLATE & 1) ? 0.6f : Act<T>::load(cs + 2 * p), c1 = (QL_ATT_ABLATE & 1) ? 0.8f : Act<T>::load(cs + 2 * p + 1);
             float y0, y1;
             rope_pair(x0, x1, c0, c1, y0, y1);
             y0 = Act<T>::round(y0);
@@ -232,39 +259,85 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         for (int d = threadIdx.x; d < D; d += 256) qs[d] = Act<T>::round(Act<T>::load(q + d) / sqrt_d);
         __syncthreads();
     }
-    const T* kb = Kc + ((int64_t)b * capacity * G + g) * D;
-    const T* vb = Vc + ((int64_t)b * capacity * G + g) * D;
-    const float* mk = mask + (int64_t)b * capacity;
+    // Q.K: lane = 16-byte chunk c of key row t (a row = CH adjacent lanes: coalesced 2*D-byte reads; with one
+    // thread per POSITION every load instruction touched 64 different cache lines and the loads alone cost 2 us),
+    // 4 rows in flight per thread, partial dots combined across the CH lanes by DPP
     float mx = -INFINITY;
-    for (int t = threadIdx.x; t < capacity; t += 256) {
-        const T* k = kb + (int64_t)t * G * D;
-        float kv[CH][8];
-        if (ROPE && t == wrow) {
+    {
+        float qv[8];
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
+        for (int e = 0; e < 8; ++e) qv[e] = qs[c * 8 + e];
+        auto chunk_dot = [&](int t, const float (&kv)[8], float mt) {
+            float acc = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) kv[c][e] = knew[c * 8 + e];
-        } else {
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qv[e], kv[e], acc);
+            acc = group_sum<CH>(acc);
+            const float sv = Act<T>::round(acc) + mt;
+            mx = fmaxf(mx, sv);                               // every lane of the group holds the same score
+            if (c == 0) sc[t] = sv;
+        };
+        // loads are unconditional (a load under `if (t == wrow)` makes hipcc wait for it on the spot, serialising
+        // the round trips); the row being written by this step is replaced AFTER the load by the LDS copy
+        auto load_chunk = [&](int t, float (&kv)[8]) {
+            if (QL_ATT_ABLATE & 2) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c) load8<T>(k + c * 8, kv[c]);
+                for (int e = 0; e < 8; ++e) kv[e] = 0.01f * (float)(c + e + t);
+            } else {
+                load8<T>(kb + (int64_t)t * G * D + c * 8, kv);
+            }
+        };
+        auto fix_new = [&](int t, float (&kv)[8]) {
+            if (ROPE && t == wrow) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kv[e] = knew[c * 8 + e];
+            }
+        };
+        int t = (QL_ATT_ABLATE & 16) ? capacity : r;
+        if constexpr (kPre) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int tp = r + RP * i;
+                if (tp < capacity && !(QL_ATT_ABLATE & 16)) {
+                    float k0[8];
+                    unpack8<T>(kr[i], k0);
+                    fix_new(tp, k0);
+                    chunk_dot(tp, k0, mr[i]);
+                }
+            }
+            if (!(QL_ATT_ABLATE & 16)) t = r + RP * NP;
         }
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qs[c * 8 + e], kv[c][e], acc);
-        const float s = Act<T>::round(acc) + mk[t];
-        sc[t] = s;
-        mx = fmaxf(mx, s);
+        for (; t + 3 * RP < capacity; t += 4 * RP) {
+            float k0[8], k1[8], k2[8], k3[8];
+            load_chunk(t, k0);
+            load_chunk(t + RP, k1);
+            load_chunk(t + 2 * RP, k2);
+            load_chunk(t + 3 * RP, k3);
+            const float m0 = mk[t], m1 = mk[t + RP], m2 = mk[t + 2 * RP], m3 = mk[t + 3 * RP];   // unconditional too
+            fix_new(t, k0);
+            fix_new(t + RP, k1);
+            fix_new(t + 2 * RP, k2);
+            fix_new(t + 3 * RP, k3);
+            chunk_dot(t, k0, m0);
+            chunk_dot(t + RP, k1, m1);
+            chunk_dot(t + 2 * RP, k2, m2);
+            chunk_dot(t + 3 * RP, k3, m3);
+        }
+        for (; t < capacity; t += RP) {
+            float k0[8];
+            load_chunk(t, k0);
+            const float m0 = mk[t];
+            fix_new(t, k0);
+            chunk_dot(t, k0, m0);
+        }
     }
-    mx = block_max_256(mx, red);
+    mx = (QL_ATT_ABLATE & 4) ? 1.0f : block_max_256(mx, red);
     float sum = 0.f;
     for (int t = threadIdx.x; t < capacity; t += 256) {
         const float e = __expf(sc[t] - mx);
         sc[t] = e;
         sum += e;
     }
-    sum = block_sum_256(sum, red);
+    sum = (QL_ATT_ABLATE & 4) ? 100.f : block_sum_256(sum, red);
     const float inv = 1.0f / sum;
     for (int t = threadIdx.x; t < capacity; t += 256) sc[t] = Act<T>::round(sc[t] * inv);
     __syncthreads();
@@ -276,11 +349,23 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         if (threadIdx.x == 0) sc[wrow] = 0.f;
         __syncthreads();
     }
-    const int c = threadIdx.x % CH, sl = threadIdx.x / CH;
+    const int sl = r;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    int t = sl;
+    int t = (QL_ATT_ABLATE & 8) ? capacity : sl;
+    if constexpr (kPre) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int tp = sl + SL * i;
+            const float p = (tp < capacity && !(QL_ATT_ABLATE & 8)) ? sc[tp] : 0.f;
+            float v[8];
+            unpack8<T>(vr[i], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(p, v[e], o[e]);
+        }
+        if (!(QL_ATT_ABLATE & 8)) t = sl + SL * NP;
+    }
     for (; t + 3 * SL < capacity; t += 4 * SL) {              // 4 independent 16-byte loads in flight
         float v0[8], v1[8], v2[8], v3[8];
         load8<T>(vb + (int64_t)t * G * D + c * 8, v0);

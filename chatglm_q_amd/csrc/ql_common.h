@@ -121,6 +121,29 @@ __device__ __forceinline__ float wave_sum(float v) {
             __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
+// sum over aligned groups of W adjacent lanes (W = 4, 8, 16), result in every lane of the group: DPP only
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(W == 4 || W == 8 || W == 16, "group of 4, 8 or 16 lanes");
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    if constexpr (W >= 8) v += dpp_move<0x141>(v);
+    if constexpr (W >= 16) v += dpp_move<0x140>(v);
+    return v;
+}
+// maximum over the 64 lanes, result in every lane (DPP + readlane, like wave_sum)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    const int iv = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48))));
+}
+
 // 8 activation-dtype values held in one 16-byte register quad <-> fp32 (16-bit dtypes only)
 template <typename T>
 __device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {

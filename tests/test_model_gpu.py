@@ -168,7 +168,8 @@ def test_gate_epilogue_equals_separate_ops(dtype, bias):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("geom", [(2, 32, 2, 128, 192, 70), (3, 8, 4, 64, 64, 0), (1, 4, 1, 32, 40, 39)])
+@pytest.mark.parametrize("geom", [(2, 32, 2, 128, 192, 70), (3, 8, 4, 64, 64, 0), (1, 4, 1, 32, 40, 39),
+                                  (1, 32, 2, 128, 640, 300), (2, 8, 2, 128, 320, 319), (1, 32, 2, 128, 64, 0)])
 def test_rope_attention_single_launch_equals_two(dtype, geom):
     """decode_attention_rope against rope_kv_write followed by decode_attention: same cache rows bit for bit,
     same attention output up to the position of the new value in the PV sum."""
