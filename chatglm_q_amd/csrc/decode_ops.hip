@@ -429,7 +429,35 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const T* __restric
     const T* row = logits + (int64_t)blockIdx.x * ldl;
     float best = -INFINITY;
     int besti = 0x7fffffff;
-    for (int i = threadIdx.x; i < N; i += 1024) {
+    int i0 = 0;
+    if constexpr (sizeof(T) == 2) {
+        // 16-byte chunks, 8 per thread requested before the first compare (one block reads the whole row: with
+        // scalar 2-byte loads in a dependent loop this kernel took 24 us for 65024 logits)
+        if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+            const int nch = N >> 3;
+            for (int cbase = 0; cbase < nch; cbase += 8 * 1024) {
+                u32x4 r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = cbase + u * 1024 + threadIdx.x;
+                    r[u] = *reinterpret_cast<const u32x4*>(row + (int64_t)(ch < nch ? ch : nch - 1) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = cbase + u * 1024 + threadIdx.x;
+                    if (ch < nch) {
+                        float v[8];
+                        unpack8<T>(r[u], v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)           // ascending index: strict > keeps the lowest index on ties
+                            if (v[e] > best) { best = v[e]; besti = ch * 8 + e; }
+                    }
+                }
+            }
+            i0 = nch << 3;
+        }
+    }
+    for (int i = i0 + threadIdx.x; i < N; i += 1024) {
         const float v = Act<T>::load(row + i);
         if (v > best || (v == best && i < besti)) { best = v; besti = i; }
     }

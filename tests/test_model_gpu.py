@@ -194,3 +194,26 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
     got = F_.decode_attention_rope(qkv, table, pos, widx, k2, v2, mask, H, Gq, D)
     assert torch.equal(k1, k2) and torch.equal(v1, v2)
     assert O.rel_l2(t2n(got), t2n(want)) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N", [65024, 1003, 8])
+def test_greedy_advance_argmax_and_bookkeeping(dtype, N):
+    """tok = argmax (lowest index on ties, as torch.argmax), pos += 1, write_index += 1, mask[new index] = 0."""
+    from chatglm_q_amd import fused_ops as F_
+    g = torch.Generator(device=DEV).manual_seed(N)
+    B, cap = 3, 16
+    logits = torch.randn(B, N + 5, device=DEV, generator=g).to(dtype)[:, :N]      # row stride N + 5: rows 1, 2 unaligned
+    top = logits.max(dim=-1).values
+    for b in range(B):                                                              # plant ties with the maximum
+        idx = torch.randint(0, N, (3,), device=DEV, generator=g)
+        logits[b, idx] = top[b]
+    want = logits.float().argmax(dim=-1)
+    tok = torch.zeros(B, 1, dtype=torch.long, device=DEV)
+    widx = torch.tensor([4], dtype=torch.long, device=DEV)
+    pos = torch.full((B, 1), 5, dtype=torch.long, device=DEV)
+    mask = torch.full((B, 1, cap), -1e10, device=DEV)
+    F_.greedy_advance(logits, tok, widx, pos, mask)
+    assert torch.equal(tok[:, 0], want)
+    assert int(widx[0]) == 5 and torch.equal(pos, torch.full_like(pos, 6))
+    assert torch.all(mask[:, 0, 5] == 0) and torch.all(mask[:, 0, :5] == -1e10) and torch.all(mask[:, 0, 6:] == -1e10)
