@@ -715,10 +715,23 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
     }
 }
 
+// Which kernel serves M rows.  The VALU GEMV does 4 rows per pass at about 4x the issue cost of one row, the split-K
+// MFMA GEMM costs the same for 1..32 rows; measured (ChatGLM2-6B shapes, fp16, us):
+//   rows     4096->4608  4096->4096  4096->27392  13696->4096
+//   2 GEMV       6.8         6.0        19.8         20.3
+//   3-4 GEMV    11.5         8.4        48           29
+//   2-16 GEMM   12          11.2        28           20
+// so 3 and 4 rows move to the GEMM once the weight matrix is large.  QLINEAR_GEMV_MAX_ROWS forces the limit.
+bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
+    static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return M > forced;
+    return M > 4 || (M > 2 && N * K >= (int64_t)32 << 20);
+}
+
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st) {
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
-    if (M > 4 && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
+    if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
         return w4_packed_gemm(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     const PackedArgs p{A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, strict, st};
     switch (dtype) {

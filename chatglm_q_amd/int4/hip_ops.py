@@ -100,7 +100,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
         stream = _lib.stream_ptr(a.device)
         if packed is not None:
             # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
-            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group)) if M > 4 else 0
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group)) if M > 1 else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
             st = lib.qlinear_w4g32_fwd_packed(a2.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
                                               group, a2.stride(0) if M > 1 else K, N, code, flags, _lib.ptr(ws),

@@ -120,6 +120,10 @@ W4_SHAPES = [
     (33, 512, 384, "f16", False),
     (1, 4096, 4096, "bf16", False),
     (4, 1024, 512, "bf16", True),
+    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (w4_skinny.hip), split-K slabs
+    (33, 13696, 256, "f16", False),     # ... MT = 2, 428 groups: half-filled last super-step
+    (17, 576, 136, "bf16", True),       # ... 18 groups, ragged N
+    (64, 1024, 200, "f16", False),      # ... ragged N, N % 4 == 0
     (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
     (200, 1024, 640, "f16", False),     # MT = 4, ragged M (200 = 128 + 72)
     (129, 96, 136, "f16", True),        # odd group count (3): half-empty last K step; ragged N
@@ -253,6 +257,10 @@ W8_SHAPES = [
     (5, 512, 96, "f32", True),
     (128, 4096, 256, "f32", True),      # BASELINE config 1 shape (N cut for test time)
     (40, 1024, 256, "f16", False),
+    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (w4_skinny.hip), split-K slabs
+    (33, 13696, 256, "f16", False),     # ... MT = 2, 428 groups: half-filled last super-step
+    (17, 576, 136, "bf16", True),       # ... 18 groups, ragged N
+    (64, 1024, 200, "f16", False),      # ... ragged N, N % 4 == 0
     (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
     (200, 1024, 640, "f16", False),     # MT = 4, ragged M
     (129, 208, 136, "f16", True),       # K % 64 != 0 (K tail), ragged N
