@@ -64,6 +64,42 @@ __device__ __forceinline__ void store_out(T* c, float acc, const T* bias_n) {
     Act<T>::store(c, y);
 }
 
+// Epilogue of the 32x32 MFMA accumulator tiles (16-bit dtypes): the C/D layout gives a lane ONE column and 16 rows,
+// i.e. 2-byte global stores (measured: the epilogue was 40 % of the 512 x 4096 x 4096 int8 GEMM and 10 % of the
+// int4 GEMM at M = 8192).  The wave writes its rounded tile into a private 2 KB LDS region [32 rows][32 cols] and
+// reads it back as 16-byte row chunks: 2 stores per lane instead of 16.  `val(i)` = final fp32 value of accumulator
+// element i (row (i & 3) + 8 (i >> 2) + 4 kb, column j) BEFORE the output rounding; bias (nullable) is added as a
+// second rounded operation (store_out's sequence).  Requires 16-byte aligned C rows (n0 % 8 == 0, ldc % 8 == 0).
+template <typename T, typename F>
+__device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
+                                                 const T* __restrict__ bias, int lane, F val) {
+    static_assert(sizeof(T) == 2, "16-bit outputs");
+    const int j = lane & 31, kb = lane >> 5;
+    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
+        float y = Act<T>::round(val(i));
+        if (bias) y = y + bj;
+        Act<T>::store(lds_wave + row * 32 + j, y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h, row = q >> 2, c8 = (q & 3) * 8;
+        const int m = m_base + row, n = n0 + c8;
+        if (m >= M || n >= N) continue;
+        if (n + 8 <= N) {
+            *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = *reinterpret_cast<const u32x4*>(lds_wave + row * 32 + c8);
+        } else {                                 // ragged last chunk of the matrix: element by element from LDS
+            for (int e = 0; e < N - n; ++e) C[(int64_t)m * ldc + n + e] = lds_wave[row * 32 + c8 + e];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // XCD-aware tile order for 1-D grids.  Workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD
 // with its own L2.  Block `id` of `total` becomes position P in a tile order such that XCD c works on one
 // contiguous range of P (bijective for any total): tiles that share an operand panel share an L2.

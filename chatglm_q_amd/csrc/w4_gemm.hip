@@ -226,6 +226,18 @@ __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __rest
     }
 
     // C/D map of 32x32 MFMA: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    if (!part && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        // rounded tiles through the (now idle) A-tile LDS, 16-byte row chunks to global (ql_common.h)
+        T* lds_wave = reinterpret_cast<T*>(smem[0]) + wave * 1024;
+        static_assert(NW * 2048 <= 2 * BM * 128, "one 2 KB epilogue region per wave inside the A-tile buffers");
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n_base - j + 32 * t, M, N, bias, lane,
+                                    [&](int i) { return acc[mt][t][i]; });
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n_raw = n_base + 32 * t;

@@ -255,6 +255,15 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
         }
     }
 
+    if (!part && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        // rounded tiles through the (now idle) A-tile LDS, 16-byte row chunks to global (ql_common.h)
+        T* lds_wave = reinterpret_cast<T*>(smem[0]) + wave * 1024;
+        static_assert(NW * 2048 <= 2 * BM * 128, "one 2 KB epilogue region per wave inside the A-tile buffers");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n_raw - j, M, N, bias, lane, [&](int i) { return acc[mt][i]; });
+        return;
+    }
     if (n_raw < N) {
         const T* bn = bias ? bias + n_raw : nullptr;
 #pragma unroll

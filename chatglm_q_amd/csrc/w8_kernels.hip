@@ -11,6 +11,11 @@
 //   w8a8_mfma_kernel         i8 x i8 -> i32 on v_mfma_i32_32x32x32_i8, rank-1 scale epilogue
 #include <stdlib.h>
 
+// developer ablation switches for tools/microbench/w8a8_ablate.hip (always 0 in the library): 1 no MFMA, 2 no
+// steady-state global loads, 4 no LDS stores, 8 no LDS fragment reads, 16 no barriers
+#ifndef QL_W8A8_ABLATE
+#define QL_W8A8_ABLATE 0
+#endif
 #include "launch.h"
 #include "ql_common.h"
 
@@ -533,6 +538,12 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
     // an MFMA 32-64): reads of sub-step s + 1 are issued before the MFMAs of sub-step s
     auto read_frags = [&](int buf, int sub, i32x4 (&fa)[MT], i32x4& fb) {
         const int c = kb * 4 + sub;
+        if (QL_W8A8_ABLATE & 8) {
+            fb = i32x4{c, wr, buf, 1};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = i32x4{c, mt, buf, j};
+            return;
+        }
         fb = *reinterpret_cast<const i32x4*>(smem_w[buf] + (wr * 8 + (c ^ ((wr >> 1) & 7))) * 16);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -547,8 +558,11 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
         for (int sub = 0; sub < 4; ++sub) {
             if (sub < 3) read_frags(buf, sub + 1, fa[(sub + 1) & 1], fb[(sub + 1) & 1]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[sub & 1][mt], fb[sub & 1], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (QL_W8A8_ABLATE & 1) acc[mt][sub] += fa[sub & 1][mt][0] ^ fa[sub & 1][mt][1] ^ fa[sub & 1][mt][2] ^ fa[sub & 1][mt][3] ^
+                                                        fb[sub & 1][0] ^ fb[sub & 1][1] ^ fb[sub & 1][2] ^ fb[sub & 1][3];
+                else acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[sub & 1][mt], fb[sub & 1], acc[mt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x100, MT + 1, 0);        // next sub-step's DS reads first
             __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);            // then this sub-step's MFMAs
         }
@@ -569,10 +583,10 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
             const int buf = (kt + d) & 1;
             // slot d was stored to LDS last step; past the end this is a harmless re-read of the last step
             // (keeps the load count exact)
-            load_tiles(gstep(kt + d + DEPTH), a_st[d], w_st[d]);
+            if (!(QL_W8A8_ABLATE & 2)) load_tiles(gstep(kt + d + DEPTH), a_st[d], w_st[d]);
             mma_step(buf);
-            store_tiles(buf ^ 1, gstep(kt + d + 1), a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
-            __syncthreads();
+            if (!(QL_W8A8_ABLATE & 4)) store_tiles(buf ^ 1, gstep(kt + d + 1), a_st[(d + 1) % DEPTH], w_st[(d + 1) % DEPTH]);
+            if (!(QL_W8A8_ABLATE & 16)) __syncthreads();
         }
     }
     // tail: at most DEPTH steps, no further loads
@@ -587,8 +601,38 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
     }
 
     const int n = n0 + wave * 32 + j;
+    if (part) {                                               // split-K: int32 slab, summed and scaled by the reduce kernel
+        if (n < N) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                    if (m < M) part[((int64_t)blockIdx.z * M + m) * N + n] = acc[mt][i];
+                }
+        }
+        return;
+    }
+    const float ws = Act<T>::load(S + (n < N ? n : N - 1));
+    if constexpr (sizeof(T) == 2) {
+        if ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+            // rounded tile through the (now idle) A-tile LDS, 16-byte row chunks to global (ql_common.h)
+            T* lds_wave = reinterpret_cast<T*>(smem_w[0]) + wave * 1024;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float asc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                    asc[i] = a_scale[m < M ? m : M - 1];
+                }
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wave * 32, M, N, bias, lane,
+                                    [&](int i) { return (float)acc[mt][i] * (asc[i] * ws); });
+            }
+            return;
+        }
+    }
     if (n < N) {
-        const float ws = Act<T>::load(S + n);
         const T* bn = bias ? bias + n : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -596,12 +640,8 @@ __global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict
             for (int i = 0; i < 16; ++i) {
                 const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
                 if (m >= M) continue;
-                if (part) {
-                    part[((int64_t)blockIdx.z * M + m) * N + n] = acc[mt][i];
-                } else {
-                    const float comb = a_scale[m] * ws;
-                    store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][i] * comb, bn);
-                }
+                const float comb = a_scale[m] * ws;
+                store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][i] * comb, bn);
             }
     }
 }
