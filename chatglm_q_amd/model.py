@@ -128,15 +128,19 @@ class ChatGLM2Attention(nn.Module):
         """softmax((q / sqrt(D)) k^T + mask) v with the softmax in fp32 (chatglm_q/model.py:157-175).
         q (B,S,G,Hg,D); k_all, v_all (B,T,G,D); mask (B,S,T) additive.  Returns (B,S,H*D) (before o_proj)."""
         B, S, G, Hg, D = q.shape
-        qh = (q / math.sqrt(D)).permute(0, 2, 3, 1, 4)                    # (B,G,Hg,S,D)
-        kh = k_all.permute(0, 2, 3, 1)[:, :, None]                        # (B,G,1,D,T)
-        vh = v_all.permute(0, 2, 1, 3)[:, :, None]                        # (B,G,1,T,D)
-        qk = torch.matmul(qh, kh)                                         # (B,G,Hg,S,T)
-        if mask is not None:
-            qk = qk + mask[:, None, None, :, :]
-        p = F.softmax(qk.float(), dim=-1).to(x_dtype)
-        out = torch.matmul(p, vh)                                         # (B,G,Hg,S,D)
-        return out.permute(0, 3, 1, 2, 4).reshape(B, S, G * Hg * D)
+        T = k_all.shape[1]
+        # per sequence: one batched GEMM over the G groups with a group's Hg heads stacked along the rows; K^T and
+        # V are strided VIEWS of the cache (batch stride D, leading dimension G*D: what BLAS takes as-is), so no
+        # transposed / broadcast copies are made, and the fp32 softmax takes the cast inside its kernel
+        qh = (q / math.sqrt(D)).permute(0, 2, 3, 1, 4).reshape(B, G, Hg * S, D)
+        out = torch.empty((B, G, Hg * S, D), device=q.device, dtype=x_dtype)
+        for b in range(B):
+            qk = torch.bmm(qh[b], k_all[b].permute(1, 2, 0)).view(G, Hg, S, T)
+            if mask is not None:
+                qk = qk + mask[b][None, None]
+            p = F.softmax(qk, dim=-1, dtype=torch.float32).to(x_dtype).view(G, Hg * S, T)
+            torch.bmm(p, v_all[b].permute(1, 0, 2), out=out[b])
+        return out.view(B, G, Hg, S, D).permute(0, 3, 1, 2, 4).reshape(B, S, G * Hg * D)
 
 
 class GatedFeedForward(nn.Module):
