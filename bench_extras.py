@@ -217,8 +217,9 @@ def e2e_generate(torch, device):
     out["chunked_prefill_seq2048_batch4"] = {
         "chunk": CH, "seconds": round(dt, 4), "tokens_per_s": round(B * S / dt, 1),
         "linear_TFLOPs_if_all_time_were_linear": round(lin_flops / dt / 1e12, 1),
-        "note": "whole forward incl. plain-torch attention (reference op sequence, fp32 softmax, keys limited to the filled "
-                "prefix) and norms; lm_head for the last position only; torch's fused SDPA measured slower here (0.236 s)"}
+        "note": "whole forward incl. attention (reference op sequence: torch batched GEMMs on strided cache views, keys limited "
+                "to the filled prefix, mask add + fp32 softmax + cast in one HIP launch) and norms; lm_head for the last "
+                "position only; torch's fused SDPA measured slower here (0.236 s)"}
     del model, sess
     torch.cuda.empty_cache()
     return out

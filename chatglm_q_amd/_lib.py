@@ -67,6 +67,8 @@ EXPORTS = {
     "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p]),
     "qlinear_greedy_advance": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_int, c_void_p]),
+    "qlinear_masked_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                       c_int, c_void_p]),
     "qlinear_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -264,6 +264,17 @@ int qlinear_decode_attention_rope(const void* QKV, const void* table, const int6
                                  (hipStream_t)stream);
 }
 
+int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,
+                           int64_t lds, int64_t ldm, int64_t ldp, int dtype, void* stream) {
+    if (!scores || !P) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (rows < 0 || !fits_i32(T) || T <= 0 || lds < T || ldp < T || (mask && (mask_rows <= 0 || ldm < T)) ||
+        rows > ((int64_t)1 << 33))
+        return QL_ERR_BAD_SHAPE;
+    if (rows == 0) return 0;
+    return masked_softmax(dtype, scores, mask, P, rows, T, mask ? mask_rows : 1, lds, ldm, ldp, (hipStream_t)stream);
+}
+
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream) {
     if (!In || !Out) return QL_ERR_NULL_POINTER;

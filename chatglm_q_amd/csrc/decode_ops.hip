@@ -398,6 +398,57 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefill attention's middle: P = round(softmax_fp32(scores + mask)) row by row (chatglm_q/model.py:166-170: the
+// additive mask promotes the fp16 scores to fp32, the softmax runs in fp32, its result is cast to the activation
+// dtype).  As separate torch kernels that is 16 bytes of traffic per score (add, softmax, cast); here 4.
+// One wave per row; scores (rows, T) with row stride lds, mask row = row % mask_rows (the S query positions of a
+// chunk; every head shares them), mask row stride ldm.  T <= 64 * 32 is held in registers, longer rows loop.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void masked_softmax_kernel(const T* __restrict__ Sc, const float* __restrict__ mask,
+                                                             T* __restrict__ P, int64_t rows, int Tn, int mask_rows,
+                                                             int64_t lds, int64_t ldm, int64_t ldp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* s = Sc + row * lds;
+    const float* mk = mask ? mask + (row % mask_rows) * ldm : nullptr;
+    T* p = P + row * ldp;
+    constexpr int NR = 32;                                    // values per lane kept in registers
+    if (Tn <= 64 * NR) {
+        float v[NR];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int t = lane + 64 * i;
+            v[i] = t < Tn ? Act<T>::load(s + t) + (mk ? mk[t] : 0.f) : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max_dpp(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            v[i] = __expf(v[i] - mx);                         // exp(-inf) = 0 past the end of the row
+            sum += v[i];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int t = lane + 64 * i;
+            if (t < Tn) Act<T>::store(p + t, v[i] * inv);
+        }
+        return;
+    }
+    float mx = -INFINITY;
+    for (int t = lane; t < Tn; t += 64) mx = fmaxf(mx, Act<T>::load(s + t) + (mk ? mk[t] : 0.f));
+    mx = wave_max_dpp(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Tn; t += 64) sum += __expf(Act<T>::load(s + t) + (mk ? mk[t] : 0.f) - mx);
+    const float inv = 1.0f / wave_sum(sum);
+    for (int t = lane; t < Tn; t += 64) Act<T>::store(p + t, __expf(Act<T>::load(s + t) + (mk ? mk[t] : 0.f) - mx) * inv);
+}
+
 // out = round(round(silu(h)) * gate), (h, gate) = halves of a (rows, 2 hidden) matrix; 8 values per thread
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ In, T* __restrict__ Out, int hidden,
@@ -563,6 +614,13 @@ int greedy_advance(int dtype, const void* logits, int64_t B, int64_t N, int64_t 
                    int64_t* pos, float* mask, int64_t capacity, hipStream_t st) {
     QL_DT(dtype, (greedy_advance_kernel<T><<<(unsigned)B, 1024, 0, st>>>((const T*)logits, (int)N, ldl, tok, write_index, pos, mask,
                                                                           (int)capacity)))
+    return finish_launch();
+}
+
+int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_t rows, int64_t Tn, int64_t mask_rows, int64_t lds,
+                   int64_t ldm, int64_t ldp, hipStream_t st) {
+    QL_DT(dtype, (masked_softmax_kernel<T><<<(unsigned)((rows + 3) / 4), 256, 0, st>>>((const T*)Sc, mask, (T*)P, rows, (int)Tn,
+                                                                                       (int)mask_rows, lds, ldm, ldp)))
     return finish_launch();
 }
 

@@ -106,6 +106,8 @@ int decode_attention_rope(int dtype, const void* QKV, const void* table, const i
                           void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
                           int64_t capacity, int64_t ldqkv, hipStream_t st);
 int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st);
+int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_t rows, int64_t Tn, int64_t mask_rows, int64_t lds,
+                   int64_t ldm, int64_t ldp, hipStream_t st);
 int greedy_advance(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
                    int64_t* pos, float* mask, int64_t capacity, hipStream_t st);
 

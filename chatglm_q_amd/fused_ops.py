@@ -90,6 +90,27 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     return out
 
 
+def masked_softmax(scores: Tensor, mask: Tensor | None) -> Tensor:
+    """``softmax(scores.float() + mask, -1).to(scores.dtype)`` in one launch.  scores (..., S, T) contiguous, mask
+    (S, T) fp32 shared by all leading dims (or None)."""
+    lib = _lib.get_lib()
+    S, T = scores.shape[-2:]
+    scores = scores.contiguous()
+    out = torch.empty_like(scores)
+    rows = scores.numel() // T
+    if mask is not None:
+        if mask.shape != (S, T) or mask.dtype != torch.float32:
+            raise ValueError("mask must be an fp32 (S, T) tensor")
+        if mask.stride(1) != 1:
+            mask = mask.contiguous()
+    with torch.cuda.device(scores.device):
+        st = lib.qlinear_masked_softmax(scores.data_ptr(), _lib.ptr(mask), out.data_ptr(), rows, T, S, T,
+                                        mask.stride(0) if mask is not None else T, T, _lib.dtype_code(scores.dtype),
+                                        _lib.stream_ptr(scores.device))
+    _lib.check(st, "qlinear_masked_softmax")
+    return out
+
+
 def silu_mul(x: Tensor, hidden: int) -> Tensor:
     lib = _lib.get_lib()
     x2 = x.reshape(-1, x.shape[-1])

@@ -136,9 +136,13 @@ class ChatGLM2Attention(nn.Module):
         out = torch.empty((B, G, Hg * S, D), device=q.device, dtype=x_dtype)
         for b in range(B):
             qk = torch.bmm(qh[b], k_all[b].permute(1, 2, 0)).view(G, Hg, S, T)
-            if mask is not None:
-                qk = qk + mask[b][None, None]
-            p = F.softmax(qk, dim=-1, dtype=torch.float32).to(x_dtype).view(G, Hg * S, T)
+            if FUSED_DECODE_OPS and qk.is_cuda and qk.dtype in (torch.float16, torch.bfloat16) and qk.dtype == x_dtype:
+                from . import fused_ops
+                p = fused_ops.masked_softmax(qk, None if mask is None else mask[b]).view(G, Hg * S, T)   # add + softmax + cast
+            else:
+                if mask is not None:
+                    qk = qk + mask[b][None, None]
+                p = F.softmax(qk, dim=-1, dtype=torch.float32).to(x_dtype).view(G, Hg * S, T)
             torch.bmm(p, v_all[b].permute(1, 0, 2), out=out[b])
         return out.view(B, G, Hg, S, D).permute(0, 3, 1, 2, 4).reshape(B, S, G * Hg * D)
 

@@ -203,6 +203,10 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
 int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
                                   int64_t capacity, int64_t ldqkv, int dtype, void* stream);
+/* masked_softmax: P[r, :] = round(softmax_fp32(scores[r, :] + mask[r % mask_rows, :])) - the add / fp32 softmax / cast
+ * between the two GEMMs of the many-position attention (chatglm_q/model.py:166-170) in one pass; mask nullable. */
+int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,
+                           int64_t lds, int64_t ldm, int64_t ldp, int dtype, void* stream);
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream);
 /* greedy decode bookkeeping in one launch (chatglm_q/decoder.py:85,97 with temperature -> 0): tok[b] = argmax of logits

@@ -217,3 +217,24 @@ def test_greedy_advance_argmax_and_bookkeeping(dtype, N):
     assert torch.equal(tok[:, 0], want)
     assert int(widx[0]) == 5 and torch.equal(pos, torch.full_like(pos, 6))
     assert torch.all(mask[:, 0, 5] == 0) and torch.all(mask[:, 0, :5] == -1e10) and torch.all(mask[:, 0, 6:] == -1e10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 40, 70), (1, 3, 5, 2100), (2, 2, 64, 2048), (1, 1, 7, 3000)])
+def test_masked_softmax_equals_torch_sequence(dtype, shape):
+    """qlinear_masked_softmax against the reference op sequence: fp32 (scores + mask) -> softmax -> cast."""
+    from chatglm_q_amd import fused_ops as F_
+    G_, Hg, S, T = shape
+    g = torch.Generator(device=DEV).manual_seed(S * T)
+    scores = (torch.randn(G_, Hg, S, T, device=DEV, generator=g) * 3).to(dtype)
+    full = torch.zeros(S, T + 9, device=DEV)
+    full[:, T // 2:] = torch.where(torch.rand(S, T + 9 - T // 2, device=DEV, generator=g) < 0.5, -1e10, 0.0)
+    full[:, 0] = 0.0                                            # every row keeps at least one visible key
+    mask = full[:, :T]                                          # row stride T + 9, like a sliced cache mask
+    want = torch.softmax(scores.float() + mask[None, None], dim=-1).to(dtype)
+    got = F_.masked_softmax(scores, mask)
+    assert got.shape == scores.shape
+    assert torch.allclose(got.float(), want.float(), atol=2e-3 if dtype == torch.float16 else 1e-2, rtol=0)
+    assert O.rel_l2(t2n(got), t2n(want)) < (1e-3 if dtype == torch.float16 else 4e-3)
+    none = F_.masked_softmax(scores, None)
+    assert O.rel_l2(t2n(none), t2n(torch.softmax(scores.float(), -1).to(dtype))) < (1e-3 if dtype == torch.float16 else 4e-3)
