@@ -50,6 +50,8 @@ EXPORTS = {
                                                c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w8_fwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                     c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_bwd_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                      c_int, c_void_p]),
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),

@@ -156,6 +156,20 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);
 }
 
+int qlinear_w8_fwd_fused(int prologue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
+                         int64_t K, int64_t ldw_n, const void* delta, const void* ln_weight, void* hout, float eps, int dtype,
+                         void* stream) {
+    if (!A || !W || !S || !C || !ln_weight) return QL_ERR_NULL_POINTER;
+    const bool gate = (prologue & QL_EPI_SILU_GATE) != 0;
+    if ((prologue & ~QL_EPI_SILU_GATE) != QL_PRO_ADDNORM) return QL_ERR_UNSUPPORTED;
+    if (dtype != QL_DTYPE_F16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || K % 16 != 0 || ldw_n < K || (gate && N % 4 != 0)) return QL_ERR_BAD_SHAPE;
+    if (!aligned(W, 16) || ldw_n % 16 != 0 || !aligned(A, 16) || (delta && !aligned(delta, 16)) || !aligned(ln_weight, 16) ||
+        (hout && !aligned(hout, 16)))
+        return QL_ERR_MISALIGNED;
+    return w8_gemv_fused(dtype, gate, A, W, S, bias, C, N, K, ldw_n, delta, ln_weight, hout, eps, (hipStream_t)stream);
+}
+
 int qlinear_w8_bwd_input(const void* Gout, const int8_t* Wkn, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
                          int64_t ldg, int64_t ldda, int dtype, void* stream) {
     if (!Gout || !Wkn || !S || !dA) return QL_ERR_NULL_POINTER;

@@ -11,6 +11,17 @@ namespace ql {
 // into the ABI's return convention (0 OK, >0 hipError_t).
 int finish_launch();
 
+// activation prologue / gate epilogue of the one-row fused GEMVs (w4_packed.hip, w8_kernels.hip)
+enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
+struct Prologue {
+    const void* delta;      // PRO_ADDNORM: residual contribution to add first (nullable)
+    const void* ln_weight;  // PRO_ADDNORM
+    void* hout;             // PRO_ADDNORM: updated residual stream
+    float eps;
+    int gate_epilogue;      // 1: columns come in quads (h0, h1, gate0, gate1); C gets N / 2 columns
+                            //    out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias)   model.py:200-201
+};
+
 constexpr int64_t kCanonMChunk = 64;   // rows per pass of the canonical split-K path (bounds the workspace)
 
 // w4_kernels.hip
@@ -39,6 +50,9 @@ int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C
 // w8_kernels.hip
 int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
+// one decode row, fp16, K % 16 == 0: add + RMSNorm prologue, optional SiLU * gate epilogue (rows of W in (h, h, gate, gate) quads)
+int w8_gemv_fused(int dtype, bool gate_epilogue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
+                  int64_t K, int64_t ldw, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
             int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, bool strict, hipStream_t st);
 // MFMA GEMM launch plan (both weight formats).  mt: tile height in units of 32 rows - the tallest tile that

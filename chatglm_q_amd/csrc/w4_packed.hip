@@ -119,15 +119,7 @@ struct PackedTile16 {
 //   PRO_SILU     the input row is (h | gate), 2K wide: staged = round(round(silu(h)) * gate)      model.py:200-201
 //   PRO_ADDNORM  hnew = round(x + delta) (delta optional), written to pro.hout by block 0;
 //                staged = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)               model.py:62-73,243-245
-enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
-struct Prologue {
-    const void* delta;      // PRO_ADDNORM: residual contribution to add first (nullable)
-    const void* ln_weight;  // PRO_ADDNORM
-    void* hout;             // PRO_ADDNORM: updated residual stream
-    float eps;
-    int gate_epilogue;      // 1: columns come in quads (h0, h1, gate0, gate1); C gets N / 2 columns
-                            //    out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias)   model.py:200-201
-};
+// (enum PRO_* and struct Prologue: launch.h)
 
 template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
 __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,

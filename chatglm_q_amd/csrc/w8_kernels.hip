@@ -92,11 +92,15 @@ __device__ __forceinline__ u32x4 pair_even_odd(u32x4 x) {
 // VALU ops per 4 weights, closer to real arithmetic, ~2e-4 relative from the reference (see w4_packed.hip).
 // KS: the block's 4 waves cover 4/KS channel quads x KS slices of K (combined through LDS at the end), so that a
 // 4096 x 4096 layer gives 2 blocks per CU instead of 1 (see w4_packed.hip).
-template <int MB, int ACH, int KS, bool STRICT>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
+// PRO = PRO_ADDNORM (one row, LDS staging, K % 16 == 0): the residual add + RMSNorm in front of the projection runs
+// while the row is staged, and pro.gate_epilogue turns the quad's sums into SiLU(h) * gate - the int8 twin of
+// w4_packed.hip's fused decode GEMV (same rounding sequence).
+template <int MB, int ACH, int KS, bool STRICT, int PRO = PRO_NONE>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
 __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict__ A, const int8_t* __restrict__ W,
                                                           const f16* __restrict__ S, const f16* __restrict__ bias,
                                                           f16* __restrict__ C, int M, int N, int K, int64_t ldw,
-                                                          int64_t lda, int64_t ldc) {
+                                                          int64_t lda, int64_t ldc, Prologue pro = Prologue{}) {
+    static_assert(PRO == PRO_NONE || (PRO == PRO_ADDNORM && MB == 1 && ACH > 0), "prologue: one LDS-staged row");
     constexpr bool A_LDS = ACH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
 
     u32x4 areg[A_LDS ? ACH : 1];
+    u32x4 xreg[PRO == PRO_ADDNORM ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // ln weight, residual delta
     if constexpr (A_LDS) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
@@ -126,6 +131,10 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
             const int c = min(tid + i * 256, MB * ppr - 1);
             const int m = MB == 1 ? 0 : c / ppr, cc = c - m * ppr;
             areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
+            if constexpr (PRO == PRO_ADDNORM) {
+                xreg[i] = *reinterpret_cast<const u32x4*>((const f16*)pro.ln_weight + cc * 8);
+                yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const f16*)pro.delta : arow[0]) + cc * 8);
+            }
         }
     }
 
@@ -157,6 +166,40 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     if (iters > 0) t0 = load_tile(0);
     if (iters > 1) t1 = load_tile(1);
 
+    if constexpr (PRO == PRO_ADDNORM) {
+        // hnew = round(x + delta), written once (block 0); staged row = round(round(hnew * r) * ln_weight)
+        float* nred = reinterpret_cast<float*>(smem + (((size_t)kvec * sizeof(f16) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float));
+        float hv[ACH][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            float d[8];
+            unpack8<f16>(areg[i], hv[i]);
+            unpack8<f16>(yreg[i], d);
+            const int c = tid + i * 256;
+            if (pro.delta) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[i][e] = Act<f16>::round(hv[i][e] + d[e]);
+            }
+            if (c < ppr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[i][e], hv[i][e], ss);
+                if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((f16*)pro.hout + c * 8) = pack8<f16>(hv[i]);
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) nred[wave] = ss;
+        __syncthreads();
+        const float r = rsqrtf(((nred[0] + nred[1]) + (nred[2] + nred[3])) / (float)K + pro.eps);
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            float w[8];
+            unpack8<f16>(xreg[i], w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[i][e] = Act<f16>::round(hv[i][e] * r) * w[e];
+            areg[i] = pack8<f16>(hv[i]);
+        }
+    }
     if constexpr (A_LDS) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
@@ -315,6 +358,19 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     }
 
     if (wave_active && ks == 0 && lane == 0) {
+        if (PRO != PRO_NONE && pro.gate_epilogue) {
+            // rows of W come in (h, h, gate, gate) quads: C gets N / 2 values (chatglm_q/model.py:200-201)
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                y[c] = Act<f16>::round(acc[0][c]);
+                if (bias) y[c] = Act<f16>::round(y[c] + Act<f16>::load(bias + nb + c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                Act<f16>::store(C + (nb >> 1) + i, Act<f16>::round(Act<f16>::round(y[i] / (1.0f + __expf(-y[i]))) * y[i + 2]));
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (m0 + m >= M) break;
@@ -692,6 +748,19 @@ static int launch_w8_gemv_f16(const W8Args& p) {
     return finish_launch();
 }
 
+template <int ACH, int KS>
+static int launch_w8_gemv_fused(const W8Args& p, const Prologue& pro) {
+    const int quads = (p.N + 3) / 4;
+    constexpr int QW = 4 / KS;
+    dim3 grid((unsigned)((quads + QW - 1) / QW), 1);
+    // staged row, K-slice sums, the four per-wave partial sums of squares
+    const size_t lds = (((size_t)(p.K & ~15) * sizeof(f16) + 15) & ~(size_t)15) + (size_t)4 * 4 * sizeof(float) + 4 * sizeof(float);
+    w8_gemv_f16_kernel<1, ACH, KS, false, PRO_ADDNORM><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S,
+                                                                                (const f16*)p.bias, (f16*)p.C, 1, p.N, p.K, p.ldw,
+                                                                                p.lda, p.ldc, pro);
+    return finish_launch();
+}
+
 template <int MB, bool STRICT>
 static int launch_w8_gemv_f16_st(const W8Args& p) {
     const int64_t pieces = (int64_t)MB * ((p.K & ~15) / 8);
@@ -830,6 +899,24 @@ int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void
             int64_t N, int64_t K, int64_t ldw, int64_t lda, int64_t ldc, bool strict, hipStream_t st) {
     const W8Args p{strict, A, W, S, bias, C, (int)M, (int)N, (int)K, ldw, lda, ldc, st};
     return launch_w8_gemv_any(dtype, p);
+}
+int w8_gemv_fused(int dtype, bool gate_epilogue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
+                  int64_t K, int64_t ldw, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
+    if (dtype != QL_DTYPE_F16) return QL_ERR_BAD_DTYPE;
+    const int64_t pieces = K / 8;
+    if (K % 16 != 0 || pieces > 8 * 256 || (size_t)K * sizeof(f16) > 60 * 1024) return QL_ERR_UNSUPPORTED;
+    const W8Args p{false, A, W, S, bias, C, 1, (int)N, (int)K, ldw, K, N, st};
+    const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
+    const int64_t quads = (N + 3) / 4;
+    const bool split = (K >> 4) >= 128 && quads / 2 < 1024;    // the unfused kernel's rule
+    if (split) {
+        if (pieces <= 2 * 256) return launch_w8_gemv_fused<2, 2>(p, pro);
+        if (pieces <= 4 * 256) return launch_w8_gemv_fused<4, 2>(p, pro);
+        return launch_w8_gemv_fused<8, 2>(p, pro);
+    }
+    if (pieces <= 2 * 256) return launch_w8_gemv_fused<2, 1>(p, pro);
+    if (pieces <= 4 * 256) return launch_w8_gemv_fused<4, 1>(p, pro);
+    return launch_w8_gemv_fused<8, 1>(p, pro);
 }
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st) {

@@ -79,6 +79,25 @@ def dynamic_quant_matmul(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool
     return w8_forward(a, b, b_scale)
 
 
+def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None,
+                     delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
+                     eps: float = 0.0) -> Tensor:
+    """One-row fp16 forward with the add + RMSNorm prologue (``_lib.PRO_ADDNORM``, optionally ``| _lib.EPI_SILU_GATE``
+    on gate-interleaved rows, see ``int4.hip_ops.gate_interleave``).  ``weight_nk``: the module's (N, K) buffer."""
+    lib = _lib.get_lib()
+    N, K = weight_nk.shape
+    if a.numel() != K:
+        raise ValueError("fused prologues serve exactly one activation row")
+    a = a.contiguous()
+    c = torch.empty((*a.shape[:-1], N // 2 if kind & _lib.EPI_SILU_GATE else N), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd_fused(kind, a.data_ptr(), weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                      N, K, weight_nk.stride(0), _lib.ptr(delta), _lib.ptr(ln_weight), _lib.ptr(hout),
+                                      float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w8_fwd_fused")
+    return c
+
+
 def w8_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
     """Shapes / dtypes served by qlinear_w8_bwd_input (everything else takes the dense torch formula)."""
     return (grad_out.is_cuda and grad_out.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == grad_out.dtype

@@ -81,6 +81,23 @@ class DynamicQuantizeLinear(nn.Module):
         return out
 
     @torch.no_grad()
+    def gated(self, hidden: int):
+        """Row-permuted copy (weight, scale, bias) of a first MLP projection (out_features = 2 * hidden) in
+        (h_2t, h_2t+1, gate_2t, gate_2t+1) quads for the fused SiLU * gate epilogue (qlinear_w8_fwd_fused |
+        QL_EPI_SILU_GATE).  Cached, keyed on the buffers' identity and version; never part of the state_dict."""
+        if self.out_features != 2 * hidden:
+            raise ValueError("gated layout needs out_features == 2 * hidden")
+        key = (self.weight.data_ptr(), self.weight._version, self.weight_scale.data_ptr(), self.weight_scale._version,
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        if getattr(self, "_gated", None) is None or self._gated_key != key:
+            from ..int4.hip_ops import gate_interleave
+            perm = gate_interleave(hidden, self.weight.device)
+            self._gated = (self.weight.index_select(0, perm).contiguous(), self.weight_scale.index_select(0, perm).contiguous(),
+                           None if self.bias is None else self.bias.index_select(0, perm).contiguous())
+            self._gated_key = key
+        return self._gated
+
+    @torch.no_grad()
     def apply_weights_(self, q_weight: Tensor, scale: Tensor, bias: Tensor = None):
         self.weight.copy_(q_weight)
         self.weight_scale.copy_(scale)

@@ -233,8 +233,10 @@ class ChatGLM2Model(nn.Module):
         if S == 1:
             kv_len = None                              # the one-position kernels take the whole cache + mask
         mask = mask.contiguous()
-        if B * S == 1 and h.dtype in (torch.float16, torch.bfloat16) and self._int4_packed_ready():
-            return self._step_one_row(h, cache, write_index, position_ids, mask)
+        if B * S == 1 and h.dtype in (torch.float16, torch.bfloat16):
+            kind = self._one_row_kind(h.dtype)
+            if kind:
+                return self._step_one_row(h, cache, write_index, position_ids, mask, kind)
         delta = None                                   # pending residual contribution of the previous sub-block
         for i, layer in enumerate(self.layers):
             if delta is None:
@@ -255,44 +257,55 @@ class ChatGLM2Model(nn.Module):
         _, x = F_.add_rmsnorm(h, delta, self.final_ln.weight, self.final_ln.eps)
         return self.lm_head(x)
 
-    def _int4_packed_ready(self) -> bool:
-        """True when every QLinear of the graph is an int4g32 module whose derived layout can be used."""
-        ok = getattr(self, "_packed_ok", None)
-        if ok is None:
-            from .int4.qlinear import DynamicQuantizeLinear as Q4
-            mods = [self.lm_head] + [m for l in self.layers for m in (l.attn.qkv_proj, l.attn.o_proj, l.ffn.w_in, l.ffn.w_out)]
-            ok = all(isinstance(m, Q4) and m._packed_supported() for m in mods)
-            self._packed_ok = ok
-        return ok
+    def _one_row_kind(self, dtype) -> Optional[str]:
+        """"int4" / "int8" when every QLinear of the graph can take the fused one-row launches, else None."""
+        from .int4.qlinear import DynamicQuantizeLinear as Q4
+        from .int8.qlinear import DynamicQuantizeLinear as Q8
+        mods = [self.lm_head] + [m for l in self.layers for m in (l.attn.qkv_proj, l.attn.o_proj, l.ffn.w_in, l.ffn.w_out)]
+        kind = None
+        if all(isinstance(m, Q4) and m._packed_supported() for m in mods):
+            kind = "int4"
+        elif dtype == torch.float16 and self.config.hidden_size <= 16384 and all(
+                isinstance(m, Q8) and not m.act_quant and m.in_features % 16 == 0 and m.weight.is_contiguous() for m in mods):
+            kind = "int8"
+        return kind
 
-    def _step_one_row(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor) -> Tensor:
+    def _step_one_row(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
+                      kind: str) -> Tensor:
         """Decode step of ONE row: 5 launches per layer.  The residual add + RMSNorm in front of qkv_proj / w_in /
-        lm_head run inside those QLinear kernels' activation staging (qlinear_w4g32_fwd_packed_fused); rotary +
-        cache write + attention are one launch; SiLU * gate is w_in's epilogue."""
+        lm_head run inside those QLinear kernels' activation staging (qlinear_w4g32_fwd_packed_fused /
+        qlinear_w8_fwd_fused); rotary + cache write + attention are one launch; SiLU * gate is w_in's epilogue."""
         from . import _lib, fused_ops as F_
         from .int4 import hip_ops as H4
+        from .int8 import hip_ops as H8
         c = self.config
         H, G, D = c.num_attention_heads, c.num_multi_query_groups, c.head_hidden_size
+
+        def norm_linear(mod, x, delta, ln, hout, gate_hidden=None):
+            """mod(rmsnorm(x + delta)) with the updated residual stream written to hout; optional SiLU * gate."""
+            flags = _lib.PRO_ADDNORM | (_lib.EPI_SILU_GATE if gate_hidden else 0)
+            if kind == "int4":
+                packed, bias = mod.gated_packed(gate_hidden) if gate_hidden else (mod.prepare()._packed, mod.bias)
+                return H4.w4_forward_fused(flags, x, packed, mod.out_features, bias, delta, ln.weight, hout, ln.eps)
+            w, sc, bias = mod.gated(gate_hidden) if gate_hidden else (mod.weight, mod.weight_scale, mod.bias)
+            return H8.w8_forward_fused(flags, x, w, sc, bias, delta, ln.weight, hout, ln.eps)
+
         delta = None
         for i, layer in enumerate(self.layers):
             at, ff = layer.attn, layer.ffn
             hn = torch.empty_like(h)
-            qkv = H4.w4_forward_fused(_lib.PRO_ADDNORM, h, at.qkv_proj.prepare()._packed, at.qkv_proj.out_features,
-                                      at.qkv_proj.bias, delta, layer.attn_ln.weight, hn, layer.attn_ln.eps)
+            qkv = norm_linear(at.qkv_proj, h, delta, layer.attn_ln, hn)
             h = hn
             o = at.o_proj(F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i],
                                                    cache.v[i], mask, H, G, D))
             hn = torch.empty_like(h)
-            # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its derived layout (each wave owns
+            # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its weights (each wave owns
             # (h, h, gate, gate) column quads), so the (1, 2 * hidden) intermediate is never written.  (As a
             # PROLOGUE of w_out it measured +6 us: every one of w_out's ~1000 blocks redid the 13696 exponentials.)
-            gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
-            y = H4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gp, ff.w_in.out_features, gb, o,
-                                    layer.ffn_ln.weight, hn, layer.ffn_ln.eps)
+            y = norm_linear(ff.w_in, h, o, layer.ffn_ln, hn, gate_hidden=ff.hidden_dim)
             h = hn
             delta = ff.w_out(y)
-        return H4.w4_forward_fused(_lib.PRO_ADDNORM, h, self.lm_head.prepare()._packed, self.lm_head.out_features, None,
-                                   delta, self.final_ln.weight, None, self.final_ln.eps)
+        return norm_linear(self.lm_head, h, delta, self.final_ln, None)
 
     # -- reference-shaped call ----------------------------------------------------------------------
     def forward(self, input_ids: Optional[Tensor] = None, input_embeddings: Optional[Tensor] = None,

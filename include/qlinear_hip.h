@@ -149,6 +149,14 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
                    int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* One-row (decode) int8 forward with the add + RMSNorm PROLOGUE (QL_PRO_ADDNORM) and optionally the SiLU * gate
+ * EPILOGUE (| QL_EPI_SILU_GATE: the N rows of W - and S, bias - come in (h_2t, h_2t+1, gate_2t, gate_2t+1) quads,
+ * C receives N / 2 values): the int8 twin of qlinear_w4g32_fwd_packed_fused, same rounding sequence.
+ * W (N, K) int8 row-major with row stride ldw_n (the module's buffer), fp16, K % 16 == 0, K <= 16384. */
+int qlinear_w8_fwd_fused(int prologue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
+                         int64_t K, int64_t ldw_n, const void* delta, const void* ln_weight, void* hout, float eps, int dtype,
+                         void* stream);
+
 /* Backward of the int8 product w.r.t. the activations:
  *   dA (M, K) = Gout (M, N) . (Wkn * S[None, :])^T     Wkn = the logical (K, N) matrix, CONTIGUOUS (row stride N),
  *                                                      i.e. module.weight.t().contiguous(); S (N); fp16 / bf16

@@ -238,3 +238,66 @@ def test_masked_softmax_equals_torch_sequence(dtype, shape):
     assert O.rel_l2(t2n(got), t2n(want)) < (1e-3 if dtype == torch.float16 else 4e-3)
     none = F_.masked_softmax(scores, None)
     assert O.rel_l2(t2n(none), t2n(torch.softmax(scores.float(), -1).to(dtype))) < (1e-3 if dtype == torch.float16 else 4e-3)
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_int8_fused_prologue_and_gate_epilogue(bias):
+    """qlinear_w8_fwd_fused against the separate launches (add + RMSNorm, int8 GEMV, SiLU * gate)."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int8 import hip_ops as H8
+    from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear as L8
+    g = torch.Generator(device=DEV).manual_seed(44)
+    for K, N in ((4096, 4608), (4096, 27392), (256, 192)):
+        layer = L8(K, N, bias=bias, dtype=torch.float16, device=DEV)
+        layer.weight.copy_(torch.randint(-127, 128, (N, K), dtype=torch.int8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(N, device=DEV, generator=g) * 0.004 + 0.001).half())
+        if bias:
+            layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).half())
+        h = torch.randn(1, 1, K, device=DEV, generator=g).half()
+        d = torch.randn(1, 1, K, device=DEV, generator=g).half()
+        w = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).half()
+        for delta in (d, None):
+            hout = torch.empty_like(h)
+            got = H8.w8_forward_fused(_lib.PRO_ADDNORM, h, layer.weight, layer.weight_scale, layer.bias, delta, w, hout, 1e-5)
+            want_h, x = (h, F_.rmsnorm(h, w, 1e-5)) if delta is None else F_.add_rmsnorm(h, delta, w, 1e-5)
+            with torch.no_grad():
+                want = layer(x)
+            assert torch.equal(hout, want_h)
+            assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+        hidden = N // 2
+        gw, gs, gb = layer.gated(hidden)
+        hout = torch.empty_like(h)
+        got = H8.w8_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gw, gs, gb, d, w, hout, 1e-5)
+        want_h, x = F_.add_rmsnorm(h, d, w, 1e-5)
+        with torch.no_grad():
+            want = F_.silu_mul(layer(x), hidden)
+        assert got.shape == (1, 1, hidden) and torch.equal(hout, want_h)
+        assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+        assert layer.gated(hidden)[0] is gw
+
+
+def test_int8_model_one_row_step_matches_unfused_graph():
+    """The 5-launch decode step on an int8 model against the same model with the fused ops switched off."""
+    from chatglm_q_amd import model as M
+    from chatglm_q_amd.decoder import DecodeSession
+    cfg = M.ChatGLM2Config(hidden_size=256, inner_hidden_size=384, head_hidden_size=32, num_multi_query_groups=2,
+                           num_attention_heads=8, num_layers=2, vocab_size=320, max_sequence_length=64)
+    with torch.device(DEV):
+        model = M.create_quant_int8_model(cfg, dtype=torch.float16)
+    M.fill_synthetic_(model, 3)
+    model.eval()
+    assert model._one_row_kind(torch.float16) == "int8"
+    ids = torch.randint(0, 320, (1, 9), device=DEV)
+    outs = {}
+    for fused in (True, False):
+        M.FUSED_DECODE_OPS = fused
+        try:
+            sess = DecodeSession(model, 1, 32, use_graph=False)
+            logits = [sess.prefill(ids)]
+            sess.tok.copy_(logits[0].argmax(-1, keepdim=True))
+            for _ in range(3):
+                logits.append(sess.decode_step(greedy=True).clone())
+            outs[fused] = torch.stack([l.float() for l in logits])
+        finally:
+            M.FUSED_DECODE_OPS = True
+    assert O.rel_l2(t2n(outs[True]), t2n(outs[False])) < 5e-3
