@@ -569,11 +569,17 @@ static int env_int(const char* name, int dflt) {
 
 // K slices per block: as many as keep every lane of a wave busy (>= 64 groups per slice) while the
 // grid is still small (fewer than ~4 blocks per CU); QLINEAR_W4_KSPLIT overrides for measurements.
-static int choose_ksplit(int64_t quads, int64_t G) {
+// Every block stages its MB activation rows (MB * K values) into LDS.  Once that tile is large enough to limit the
+// blocks per CU (> 40 KB: w_out with 2 rows, 55 KB) more, smaller blocks only multiply the staging traffic (1024
+// blocks x 55 KB = 56 MB against 28 MB of weights: 20.4 us instead of 13.9), so the split is halved until the staged
+// bytes no longer exceed the weight bytes.  Small tiles keep the finer split (qkv_proj, 4 rows: 11.5 vs 14.1 us).
+static int choose_ksplit(int64_t quads, int64_t G, int mb = 1) {
     static const int forced = env_int("QLINEAR_W4_KSPLIT", 0);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     int ks = 1;
     while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 1024) ks *= 2;
+    if (mb > 1 && mb * G * 64 > 40 * 1024)
+        while (ks > 1 && (quads * ks / 4) * mb * (G * 32) * 2 > quads * 4 * G * 16) ks /= 2;
     return ks;
 }
 
@@ -624,7 +630,7 @@ static int launch_16_ach(const PackedArgs& p) {
 template <typename T, int MB, bool STRICT>
 static int launch_16_mb(const PackedArgs& p) {
     const int64_t Npad = (p.N + 3) & ~(int64_t)3;
-    switch (choose_ksplit(Npad / 4, p.K / 32)) {
+    switch (choose_ksplit(Npad / 4, p.K / 32, MB)) {
     case 4: return launch_16_ach<T, MB, 4, STRICT>(p);
     case 2: return launch_16_ach<T, MB, 2, STRICT>(p);
     default: return launch_16_ach<T, MB, 1, STRICT>(p);
