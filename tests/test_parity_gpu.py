@@ -128,6 +128,9 @@ W4_SHAPES = [
     (200, 1024, 640, "f16", False),     # MT = 4, ragged M (200 = 128 + 72)
     (129, 96, 136, "f16", True),        # odd group count (3): half-empty last K step; ragged N
     (2048, 4096, 256, "f16", False),    # prefill-sized M
+    (4096, 1024, 2048, "f16", True),    # 256 tiles of 128 x 256: the 8-wave tile
+    (4200, 1056, 2064, "f16", False),   # ... ragged M and N, odd group count (33)
+    (4096, 512, 2048, "bf16", True),    # ... bf16
     (70, 13696, 128, "bf16", True),     # bf16 MFMA, K = 13696
     (40, 512, 264, "bf16", False),
     (1, 4096, 4096, "f32", False),
@@ -265,6 +268,9 @@ W8_SHAPES = [
     (200, 1024, 640, "f16", False),     # MT = 4, ragged M
     (129, 208, 136, "f16", True),       # K % 64 != 0 (K tail), ragged N
     (2048, 4096, 256, "f16", False),    # prefill-sized M
+    (4096, 1024, 2048, "f16", True),    # 256 tiles of 128 x 256: the 8-wave tile
+    (4200, 1056, 2064, "f16", False),   # ... ragged M and N, odd group count (33)
+    (4096, 512, 2048, "bf16", True),    # ... bf16
     (70, 13696, 128, "bf16", True),     # bf16 MFMA
     (33, 400, 96, "bf16", False),
 ]
