@@ -59,7 +59,7 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
         if (group == 32 && N % 8 == 0) return w4_canon_workspace_bytes(M, N, K);
         return 0;
     case QL_OP_W4G32_FWD_PACKED:     // optional: without it the few-row MFMA GEMM runs unsplit (slower, same results)
-        return (group == 32 && K % 32 == 0 && w4_rows_use_gemm(M, N, K)) ? w4_packed_gemm_workspace_bytes(M, N, K) : 0;
+        return (group == 32 && K % 32 == 0) ? w4_packed_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8_FWD:
         return (M > 4 && K % 16 == 0) ? w8_gemm_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8A8_FWD:             // optional too: int32 split-K slabs for shapes with few row tiles

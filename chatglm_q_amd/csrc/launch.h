@@ -41,7 +41,13 @@ int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, cons
 int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
-bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K);   // w4_packed.hip: GEMV or GEMM for this row count
+bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K);
+size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K);   // of whichever kernel w4_packed() picks
+// w4_fewrow.hip (rows <= 32, fp16 / bf16): independent K-slice waves, MFMA
+bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K);
+size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // w4_packed.hip: GEMV or GEMM for this row count
 
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,

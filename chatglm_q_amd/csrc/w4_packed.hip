@@ -726,11 +726,18 @@ bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     return M > 4 || (M > 2 && N * K >= (int64_t)32 << 20);
 }
 
+size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (!w4_rows_use_gemm(M, N, K)) return 0;
+    return w4_fewrow_supported(M, N, K) ? w4_fewrow_workspace_bytes(M, N, K) : w4_packed_gemm_workspace_bytes(M, N, K);
+}
+
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st) {
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
-    if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
+    if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16)) {
+        if (w4_fewrow_supported(M, N, K)) return w4_fewrow(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
         return w4_packed_gemm(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    }
     const PackedArgs p{A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, strict, st};
     switch (dtype) {
     case QL_DTYPE_F16:
