@@ -96,8 +96,7 @@ int qlinear_w4g32_bwd_input(const void* Gout, const uint8_t* Wq, const void* S, 
 
 size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
     if (N <= 0 || K <= 0 || group != 32 || K % 32 != 0 || !dtype_ok(dtype)) return 0;
-    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    return (size_t)(Npad * G * 16 + Npad * G * esize(dtype));
+    return w4_layout(N, K, esize(dtype)).bytes;
 }
 
 int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, int64_t group,

@@ -22,6 +22,31 @@ struct Prologue {
                             //    out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias)   model.py:200-201
 };
 
+// Derived int4g32 layout = two copies of the weights in one buffer (qlinear_w4g32_packed_bytes):
+//   part 1 "column-major" (the GEMVs): Wt[n][g] 16-byte units, then Sp[n/4][g][n%4] scales (w4_packed.hip)
+//   part 2 "tile-major"  (the MFMA kernels): Wm[ct][kt][lane], ct = n / 32, kt = 64-deep K step, lane = 32 kb + j
+//          holding the unit of column 32 ct + j, group 2 kt + kb - exactly what lane (j, kb) of a wave feeds its MFMA
+//          sub-steps from, so a wave's load instruction is 1 KB contiguous and consecutive steps are consecutive
+//          (the per-column layout gave those kernels 32 bytes per 128-byte line per step, scattered over 32 DRAM
+//          rows: a timing probe with this addressing ran w_in at 8 rows in 21 instead of 27 us); then Sm likewise.
+//          Columns past N and the missing half of an odd last step hold q = 0 with scale 0.
+struct W4Layout {
+    int64_t G, Npad, ctiles, ksteps;
+    size_t off_sp, off_wm, off_sm, bytes;
+};
+inline W4Layout w4_layout(int64_t N, int64_t K, size_t esize) {
+    W4Layout L;
+    L.G = K / 32;
+    L.Npad = (N + 3) & ~(int64_t)3;
+    L.ctiles = (N + 31) / 32;
+    L.ksteps = (L.G + 1) / 2;
+    L.off_sp = (size_t)(L.Npad * L.G) * 16;
+    L.off_wm = (L.off_sp + (size_t)(L.Npad * L.G) * esize + 15) & ~(size_t)15;
+    L.off_sm = L.off_wm + (size_t)(L.ctiles * L.ksteps) * 1024;
+    L.bytes = L.off_sm + (size_t)(L.ctiles * L.ksteps) * 64 * esize;
+    return L;
+}
+
 constexpr int64_t kCanonMChunk = 64;   // rows per pass of the canonical split-K path (bounds the workspace)
 
 // w4_kernels.hip

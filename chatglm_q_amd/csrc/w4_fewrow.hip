@@ -7,7 +7,8 @@
 // many small INDEPENDENT waves.
 //   block = KW waves that share 32 output columns and split K between them (no barrier until the end);
 //   a wave walks its K slice in 64-deep steps exactly like a wave of w4_packed_gemm_kernel<T, 1, ...>: lane (j, kb)
-//   takes the 16-byte unit of column j, group 2 kt + kb, dequantises it (reference rounding) into the B fragments
+//   takes the 16-byte unit of column j, group 2 kt + kb (tile-major part of the derived layout: 1 KB contiguous
+//   per wave and step, consecutive steps consecutive), dequantises it (reference rounding) into the B fragments
 //   of 4 MFMA sub-steps; the A tile (up to 32 rows x 64 halves) is staged by THE WAVE ITSELF into a private 4 KB
 //   LDS region (swizzled, double buffered) - LDS operations of one wave execute in order, so no barrier is needed;
 //   the KW partial accumulators are summed through LDS by wave 0 after one __syncthreads().
@@ -19,8 +20,8 @@
 namespace ql {
 
 template <typename T, int KW, int NT>
-__global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
-                                                            const T* __restrict__ Sp, const T* __restrict__ bias,
+__global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wm,
+                                                            const T* __restrict__ Sm, const T* __restrict__ bias,
                                                             T* __restrict__ C, int M, int N, int K, int G, int64_t lda,
                                                             int64_t ldc, float* __restrict__ part, int per) {
     typedef Mma<T> MM;
@@ -39,13 +40,15 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
 
-    const u32x4* wcol[NT];
-    const T* scol[NT];
+    // tile-major part of the derived layout (launch.h): this wave's units of a step are 1 KB contiguous
+    const int ctiles = (N + 31) >> 5;
+    const u32x4* wtile[NT];
+    const T* stile[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int nr = n_base + 32 * t, n = nr < N ? nr : N - 1;
-        wcol[t] = Wt + (int64_t)n * G;
-        scol[t] = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+        const int ct = blockIdx.x * NT + t < ctiles ? blockIdx.x * NT + t : ctiles - 1;
+        wtile[t] = Wm + (int64_t)ct * ksteps * 64 + lane;
+        stile[t] = Sm + (int64_t)ct * ksteps * 64 + lane;
     }
     char* abuf = smem + wave * 8192;                           // two 4 KB tiles, private to the wave
 
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    typedef decltype(MM::scale_pair(scol[0], true)) scale_t;
+    typedef decltype(MM::scale_pair(stile[0], true)) scale_t;
     struct Stage {
         u32x4 a[4];
         u32x4 w[NT];
@@ -79,11 +82,10 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
         for (int u = 0; u < 4; ++u)
             if (8 * u < M)                                     // rows past M are never loaded (block-uniform test)
                 sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c_mine * 8));
-        const int g = 2 * kt + kb, gc = g < G ? g : G - 1;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            sg.w[t] = wcol[t][gc];                              // cacheable: the next 3 steps of this wave use the rest of the line
-            sg.s[t] = scol[t][(int64_t)gc * 4];
+            sg.w[t] = __builtin_nontemporal_load(wtile[t] + (int64_t)kt * 64);   // streamed once, whole lines
+            sg.s[t] = stile[t][(int64_t)kt * 64];
         }
     };
     auto store_a = [&](int buf, const Stage& sg) {
@@ -209,13 +211,12 @@ static FewRowPlan fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) 
     return {(int)ks, (int)per};
 }
 
-// Measured against w4_packed_gemm (one 32-row tile + split-K), ChatGLM2-6B shapes, fp16, us at M = 8 / 32:
-//   4096->4096  9.0 / 11.6 vs 11.6 / 13.1    4096->4608 10.5 / 12.6 vs 12.8 / 14.5    13696->4096 18.4 / 23.5 vs 20.6 / 21.2
-//   4096->27392 26.8 / 31.8 vs 27.9 / 31.4   4096->65024 51.5 / 60.9 vs 50.6 / 51.7
-// i.e. it pays for up to 16 rows on matrices narrower than ~8 k columns.  QLINEAR_FEWROW=0 disables it.
+// Measured against w4_packed_gemm (one 32-row tile + split-K over workgroups, fragments fetched per column), ChatGLM2-6B
+// shapes, fp16, us at 8 rows: 4096->4608 9.5 vs 12.8, 4096->4096 8.7 vs 11.6, 4096->27392 21.0 vs 27.9,
+// 13696->4096 14.3 vs 20.6 (the GEMV at ONE row: 5.3 / 4.7 / 14.1 / 10.2).  QLINEAR_FEWROW=0 disables it.
 bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K) {
     static const bool on = [] { const char* e = getenv("QLINEAR_FEWROW"); return !e || atoi(e) != 0; }();
-    return on && M <= 16 && N < 8192 && K >= 512;
+    return on && M <= 32 && K >= 512;
 }
 
 size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -228,9 +229,10 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
                             int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int KW = kFewRowWaves;
     const FewRowPlan plan = fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
-    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    const u32x4* Wt = (const u32x4*)packed;
-    const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
+    const W4Layout L = w4_layout(N, K, sizeof(T));
+    const int64_t G = L.G;
+    const u32x4* Wt = (const u32x4*)((const char*)packed + L.off_wm);
+    const T* Sp = (const T*)((const char*)packed + L.off_sm);
     float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
     constexpr size_t lds = (size_t)KW * 8192;

@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void w4_repack_kernel(const uint8_t* __restric
     Act<T>::store(Sp + ((int64_t)(n >> 2) * G + g) * 4 + (n & 3), sc);
 }
 
+// part 2 of the derived layout (launch.h): tile-major copy for the MFMA kernels, built from part 1
+template <typename T>
+__global__ __launch_bounds__(256) void w4_tile_kernel(const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                      u32x4* __restrict__ Wm, T* __restrict__ Sm, int Npad, int G,
+                                                      int ksteps, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (ct * ksteps + kt) * 64 + lane
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t step = idx >> 6;
+    const int kt = (int)(step % ksteps), ct = (int)(step / ksteps);
+    const int n = ct * 32 + (lane & 31), g = 2 * kt + (lane >> 5);
+    u32x4 w = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+    T sc = (T)0.f;
+    if (n < Npad && g < G) {
+        w = Wt[(int64_t)n * G + g];
+        sc = Sp[((int64_t)(n >> 2) * G + g) * 4 + (n & 3)];
+    }
+    Wm[idx] = w;
+    Sm[idx] = sc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 16-bit activation kernel (fp16 / bf16)
 // ---------------------------------------------------------------------------------------------
@@ -541,6 +562,13 @@ static int launch_w4_repack(const uint8_t* Wq, const void* S, void* packed, int6
     T* Sp = (T*)((char*)packed + Npad * G * 16);
     dim3 grid((unsigned)((Npad + 255) / 256), (unsigned)G);
     w4_repack_kernel<T><<<grid, 256, 0, st>>>(Wq, (const T*)S, Wt, Sp, (int)N, (int)Npad, (int)G);
+    const int rc = finish_launch();
+    if (rc != 0) return rc;
+    const W4Layout L = w4_layout(N, K, sizeof(T));
+    const int64_t total = L.ctiles * L.ksteps * 64;
+    w4_tile_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Wt, Sp, (u32x4*)((char*)packed + L.off_wm),
+                                                                      (T*)((char*)packed + L.off_sm), (int)Npad, (int)G,
+                                                                      (int)L.ksteps, total);
     return finish_launch();
 }
 
@@ -713,17 +741,20 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
     }
 }
 
-// Which kernel serves M rows.  The VALU GEMV does 4 rows per pass at about 4x the issue cost of one row, the split-K
-// MFMA GEMM costs the same for 1..32 rows; measured (ChatGLM2-6B shapes, fp16, us):
-//   rows     4096->4608  4096->4096  4096->27392  13696->4096
-//   2 GEMV       6.8         6.0        19.8         20.3
-//   3-4 GEMV    11.5         8.4        48           29
-//   2-16 GEMM   12          11.2        28           20
-// so 3 and 4 rows move to the GEMM once the weight matrix is large.  QLINEAR_GEMV_MAX_ROWS forces the limit.
+// Which kernel serves M rows.  The VALU GEMV does 4 rows per pass at about 4x the issue cost of one row; the MFMA
+// kernels (w4_fewrow.hip up to 32 rows, w4_gemm.hip above) cost the same for any row count of a tile.  Measured
+// (ChatGLM2-6B shapes, fp16, us):
+//   rows        4096->4608  4096->4096  4096->27392  13696->4096
+//   2  GEMV         6.8         6.1        19.2         14.2
+//   3-4 GEMV       11.4         8.3        48           29
+//   3-16 few-row    9.2-10.4    8.7-9.3    20-22.4      14.3-15.3
+// so the MFMA path starts at 3 rows.  QLINEAR_GEMV_MAX_ROWS forces the limit.
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return M > forced;
-    return M > 4 || (M > 2 && N * K >= (int64_t)32 << 20);
+    (void)N;
+    (void)K;
+    return M > 2;
 }
 
 size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -51,7 +51,8 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert _lib.get_lib().qlinear_status_string(0) == b"ok"
     assert b"group" in _lib.get_lib().qlinear_status_string(-4)
     # host-only queries (no GPU needed)
-    assert _lib.get_lib().qlinear_w4g32_packed_bytes(4096, 4096, 32, 1) == 4096 * 128 * 16 + 4096 * 128 * 2
+    # column-major part (GEMV) + tile-major part (MFMA kernels), each units + scales
+    assert _lib.get_lib().qlinear_w4g32_packed_bytes(4096, 4096, 32, 1) == 2 * (4096 * 128 * 16 + 4096 * 128 * 2)
     assert _lib.get_lib().qlinear_w4g32_packed_bytes(4096, 4096, 64, 1) == 0
     assert _lib.get_lib().qlinear_workspace_bytes(1, 1, 4096, 4096, 32) == 8 * 1 * 4096 * 4
     assert _lib.get_lib().qlinear_workspace_bytes(1, 1, 4096, 512, 32) == 0
