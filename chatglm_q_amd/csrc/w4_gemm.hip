@@ -8,7 +8,8 @@
 // products are exact and whose accumulation is fp32.
 //
 // Decomposition: block = 4 waves side by side in N (128 columns) x BM = 32 MT rows.  A wave owns 32
-// columns: lane (j = lane & 31, kb = lane >> 5) loads ONE 16-byte unit per 64-deep K step - the 32
+// columns: lane (j = lane & 31, kb = lane >> 5) loads ONE 16-byte unit per 64-deep K step (from the TILE-MAJOR
+// part of the derived layout, launch.h: the wave's 64 units of a step are 1 KB contiguous) - the 32
 // nibbles of column j, group 2 kt + kb - and turns word s of it into the B fragment of MFMA sub-step s
 // (the two half-waves supply the two groups of the step, so an MFMA's K = 16 is octet s of group 2kt
 // and octet s of group 2kt+1; the A fragment uses the same assignment, any consistent K permutation
@@ -61,14 +62,16 @@ __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __rest
     asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
 
+    // tile-major part of the derived layout (launch.h): the wave's units of a K step are 1 KB contiguous
+    const int ctiles = (N + 31) >> 5;
     const u32x4* wcol[NT];
     const T* scol[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int nr = n_base + 32 * t;
-        const int n = nr < N ? nr : N - 1;     // clamped column: loads stay in bounds, stores are masked
-        wcol[t] = Wt + (int64_t)n * G;
-        scol[t] = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+        const int ct_raw = (tile.x * NW + wave) * NT + t;
+        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;   // clamped column tile: loads stay in bounds, stores are masked
+        wcol[t] = Wt + (int64_t)ct * ksteps * 64 + lane;
+        scol[t] = Sp + (int64_t)ct * ksteps * 64 + lane;
     }
 
     // A staging: thread -> CH chunks; chunk q: row q / 8, 16-byte column q % 8
@@ -114,13 +117,11 @@ __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __rest
             }
         }
         if (steady && (QL_GEMM_ABLATE & 2)) return;
-        const int g = 2 * kt + kb;
-        const int gc = g < G ? g : G - 1;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            // plain (cacheable) loads: other row blocks re-read the same units, and a 128-byte line serves 4 steps
-            sg.w[t] = wcol[t][gc];
-            sg.s[t] = scol[t][(int64_t)gc * 4];
+            // plain (cacheable) loads: other row blocks re-read the same units
+            sg.w[t] = wcol[t][(int64_t)kt * 64];
+            sg.s[t] = scol[t][(int64_t)kt * 64];
         }
     };
     auto store_a = [&](int buf, const Stage& sg, bool steady = false) {
@@ -258,9 +259,10 @@ __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __rest
 template <typename T, int MT, int NT, int NW>
 static int launch_gemm(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
                        int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
-    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    const u32x4* Wt = (const u32x4*)packed;
-    const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
+    const W4Layout L = w4_layout(N, K, sizeof(T));
+    const int64_t G = L.G;
+    const u32x4* Wt = (const u32x4*)((const char*)packed + L.off_wm);     // tile-major part
+    const T* Sp = (const T*)((const char*)packed + L.off_sm);
     float* part = plan.ksplit > 1 ? ws : nullptr;
     constexpr int BN = NW * 32 * NT;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
