@@ -97,12 +97,6 @@ int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const voi
                       int64_t M, int64_t N, int64_t K, int64_t group, int64_t lda, int64_t ldc,
                       int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- int4 g32, derived streaming layout ----------------------------------------------------
- * A lazily built, non-persistent re-arrangement of the SAME bytes (weights transposed to
- * column-major with the 32 nibbles of one (column, group) in one 16-byte unit, scales regrouped
- * per 4 columns) so that one wave owns whole output columns and no cross-workgroup reduction is
- * needed.  Built once per weight by qlinear_w4g32_repack from the canonical buffers; canonical
- * buffers remain the source of truth (state_dict).  group must be 32. */
 /* Backward of the int4g32 product w.r.t. the activations (the weights are frozen integers):
  *   dA (M, K) = Gout (M, N) . dequant(Wq, S)^T      canonical layout, group 32, fp16 / bf16, N % 16 == 0
  * Same arithmetic as the reference's transposed kernel (every weight rounded to the activation dtype, fp32
@@ -112,6 +106,15 @@ int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const voi
 int qlinear_w4g32_bwd_input(const void* Gout, const uint8_t* Wq, const void* S, void* dA, int64_t M, int64_t N, int64_t K,
                             int64_t group, int64_t ldg, int64_t ldda, int dtype, void* stream);
 
+/* ---- int4 g32, derived layout ---------------------------------------------------------------
+ * A lazily built, non-persistent re-arrangement of the SAME weights, two copies in one buffer:
+ *   part 1, column-major (rows <= 2, GEMV): the 32 nibbles of one (column, group) in one 16-byte unit,
+ *           units K-contiguous per column, scales regrouped per 4 columns - one wave owns whole output
+ *           columns and no cross-workgroup reduction is needed;
+ *   part 2, tile-major (rows >= 3, MFMA kernels): the same units ordered [column / 32][64-deep K step][lane],
+ *           i.e. in the order the lanes of a wave feed their MFMA fragments (1 KB contiguous per load).
+ * Built once per weight by qlinear_w4g32_repack from the canonical buffers, which remain the source of truth
+ * (state_dict).  group must be 32.  Exact offsets: chatglm_q_amd/csrc/launch.h (W4Layout). */
 size_t qlinear_w4g32_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K,
                          int64_t group, int dtype, void* stream);
