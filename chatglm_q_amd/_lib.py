@@ -31,6 +31,7 @@ OP_W4G32_FWD = 1
 OP_W4G32_FWD_PACKED = 2
 OP_W8_FWD = 3
 OP_W8A8_FWD = 4
+OP_W8_FWD_TILED = 5
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -50,6 +51,10 @@ EXPORTS = {
                                                c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w8_tiled_bytes": (c_size_t, [c_int64, c_int64]),
+    "qlinear_w8_tile": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "qlinear_w8_fwd_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                     c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8_fwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w8_bwd_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,

@@ -62,6 +62,8 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
         return (group == 32 && K % 32 == 0) ? w4_packed_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8_FWD:
         return (M > 4 && K % 16 == 0) ? w8_gemm_workspace_bytes(M, N, K) : 0;
+    case QL_OP_W8_FWD_TILED:
+        return (M > 2 && K % 16 == 0) ? w8_tiled_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8A8_FWD:             // optional too: int32 split-K slabs for shapes with few row tiles
         return K % 16 == 0 ? w8a8_workspace_bytes(M, N, K) : 0;
     default: return 0;
@@ -153,6 +155,28 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
         return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, st);
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);
+}
+
+size_t qlinear_w8_tiled_bytes(int64_t N, int64_t K) {
+    if (N <= 0 || K <= 0 || K % 16 != 0) return 0;
+    return w8_tiled_bytes(N, K);
+}
+
+int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t ldw_n, void* stream) {
+    if (!W || !tiled) return QL_ERR_NULL_POINTER;
+    if (!fits_i32(N) || !fits_i32(K) || K % 16 != 0 || ldw_n < K) return QL_ERR_BAD_SHAPE;
+    if (!aligned(W, 16) || ldw_n % 16 != 0 || !aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    return w8_tile(W, (int8_t*)tiled, N, K, ldw_n, (hipStream_t)stream);
+}
+
+int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || K % 16 != 0 || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
+    return w8_fwd_tiled(dtype, A, (const int8_t*)tiled, S, bias, C, M, N, K, lda, ldc, workspace, workspace_bytes,
+                        (hipStream_t)stream);
 }
 
 int qlinear_w8_fwd_fused(int prologue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,

@@ -125,6 +125,14 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
             int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+// tile-major derived copy of int8 weights (16-byte aligned rows, K % 16 == 0) and the MFMA kernels on it
+size_t w8_tiled_bytes(int64_t N, int64_t K);
+int w8_tile(const int8_t* W, int8_t* Wm, int64_t N, int64_t K, int64_t ldw, hipStream_t st);
+size_t w8_tiled_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int w8_fwd_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // few-row kernel or tiled GEMM
+int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 int w8_gemm_scale_k(int dtype, const void* A, const int8_t* W, const void* S, void* C, int64_t M, int64_t N, int64_t K,
                     int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,

@@ -102,7 +102,7 @@ template <> struct W8Mma<__bf16> {
 // SK = false: S[n] scales the output channel (forward).  SK = true: S[k] scales the CONTRACTION index (the backward
 // product grad_A = grad_out . (W * s[:, None]) on a (K_out, N) row-major copy of the weights): the step's 64 scales go
 // through LDS (128 bytes per block) and are read back as broadcast fragments.
-template <typename T, int MT, int NW, int DEPTH, bool SK = false>
+template <typename T, int MT, int NW, int DEPTH, bool SK = false, bool TILED = false>
 __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
                                                       const T* __restrict__ S, const T* __restrict__ bias, T* __restrict__ C,
                                                       int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc,
@@ -131,7 +131,11 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
     asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
 
-    const int8_t* wrow = W + (int64_t)n * ldw + kb * 32;
+    // TILED: W is the tile-major derived copy (w8_tile_kernel): [column tile][K step][lane][32 bytes], zero padded
+    const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile.x * NW + wave;
+    const int8_t* wrow = TILED ? W + ((int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps * 64 + lane) * 32
+                               : W + (int64_t)n * ldw + kb * 32;
     const float sc = SK ? 0.f : Act<T>::load(S + n);
 
     const T* a_src[CH];
@@ -173,7 +177,8 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kt * 64 + kb * 32 + h * 16;
-            sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32));   // cacheable: re-read by other row tiles
+            if constexpr (TILED) sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)kt * 2048 + h * 16);
+            else sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32));   // cacheable: re-read by other row tiles
         }
     };
     auto store_a = [&](int buf, const Stage& sg) {
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
         // bytes of a K tail (k >= K) are replaced by 0: b = 0 contributes nothing whatever the (clamped) activations are
         u32x4 w[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) w[h] = (kt * 64 + kb * 32 + h * 16 <= kmax_w) ? w_in[h] : u32x4{0u, 0u, 0u, 0u};
+        for (int h = 0; h < 2; ++h) w[h] = (TILED || kt * 64 + kb * 32 + h * 16 <= kmax_w) ? w_in[h] : u32x4{0u, 0u, 0u, 0u};
         auto read_a = [&](int sub, u32x4 (&fr)[MT]) {
             const int c = kb * 4 + sub;
 #pragma unroll
@@ -278,14 +283,14 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T, int MT, int NW, bool SK = false>
+template <typename T, int MT, int NW, bool SK = false, bool TILED = false>
 static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int M, int N, int K,
                           int64_t ldw, int64_t lda, int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
     float* part = plan.ksplit > 1 ? ws : nullptr;
     constexpr int BN = NW * 32;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
-    w8_gemm_kernel<T, MT, NW, 3, SK><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
+    w8_gemm_kernel<T, MT, NW, 3, SK, TILED><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
                                                            ldc, part, plan.per,
         xcd_order(nbx, nby, (double)M * K * 2, (double)N * K));
     const int rc = finish_launch();
@@ -326,6 +331,244 @@ int w8_gemm_scale_k(int dtype, const void* A, const int8_t* W, const void* S, vo
     switch (dtype) {
     case QL_DTYPE_F16: return launch_w8_gemm_sk<f16>(A, W, S, C, M, N, K, ldw, lda, ldc, st);
     case QL_DTYPE_BF16: return launch_w8_gemm_sk<__bf16>(A, W, S, C, M, N, K, ldw, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// many rows on the tile-major derived copy of the weights (qlinear_w8_tile)
+template <typename T>
+static int launch_w8_gemm_tiled(const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                                int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    const GemmPlan plan = gemm_plan(M, N, (K + 63) / 64, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    switch (plan.mt) {
+    case 4:
+        if (((N + 255) / 256) * ((M + 127) / 128) >= 256)
+            return launch_w8_gemm<T, 4, 8, false, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, K, lda, ldc, plan, (float*)ws, st);
+        return launch_w8_gemm<T, 4, 4, false, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, K, lda, ldc, plan, (float*)ws, st);
+    case 2: return launch_w8_gemm<T, 2, 4, false, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, K, lda, ldc, plan, (float*)ws, st);
+    default: return launch_w8_gemm<T, 1, 4, false, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, K, lda, ldc, plan, (float*)ws, st);
+    }
+}
+
+int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_w8_gemm_tiled<f16>(A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_BF16: return launch_w8_gemm_tiled<__bf16>(A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// tile-major derived copy: Wm[ct][kt][lane][32 bytes], lane = 32 kb + j holds bytes k = 64 kt + 32 kb .. + 31 of output
+// channel 32 ct + j; rows past N and bytes past K are 0
+__global__ __launch_bounds__(256) void w8_tile_kernel(const int8_t* __restrict__ W, int8_t* __restrict__ Wm, int N, int K,
+                                                      int64_t ldw, int ksteps, int64_t total16) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte piece: ((ct * ksteps + kt) * 64 + lane) * 2 + h
+    if (idx >= total16) return;
+    const int h = (int)(idx & 1), lane = (int)((idx >> 1) & 63);
+    const int64_t step = idx >> 7;
+    const int kt = (int)(step % ksteps), ct = (int)(step / ksteps);
+    const int n = ct * 32 + (lane & 31), k = kt * 64 + (lane >> 5) * 32 + h * 16;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N && k < K) {
+        if (k + 16 <= K) {
+            v = *reinterpret_cast<const u32x4*>(W + (int64_t)n * ldw + k);
+        } else {
+            int8_t tmp[16];
+            for (int e = 0; e < 16; ++e) tmp[e] = k + e < K ? W[(int64_t)n * ldw + k + e] : (int8_t)0;
+            v = *reinterpret_cast<const u32x4*>(tmp);
+        }
+    }
+    reinterpret_cast<u32x4*>(Wm)[idx] = v;
+}
+
+size_t w8_tiled_bytes(int64_t N, int64_t K) { return (size_t)((N + 31) / 32) * ((K + 63) / 64) * 2048; }
+
+int w8_tile(const int8_t* W, int8_t* Wm, int64_t N, int64_t K, int64_t ldw, hipStream_t st) {
+    const int64_t ksteps = (K + 63) / 64, total16 = ((N + 31) / 32) * ksteps * 128;
+    w8_tile_kernel<<<(unsigned)((total16 + 255) / 256), 256, 0, st>>>(W, Wm, (int)N, (int)K, ldw, (int)ksteps, total16);
+    return finish_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Few rows (3 <= M <= 32) on the tile-major copy: the int8 twin of w4_fewrow_kernel (w4_fewrow.hip) - KW independent
+// waves per block share 32 output channels and split K, each stages its own A tile in a private LDS region, no block
+// barrier until the partial sums are combined through LDS; optional split over blockIdx.y into fp32 slabs.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KW>
+__global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict__ A, const int8_t* __restrict__ Wm,
+                                                            const T* __restrict__ S, const T* __restrict__ bias,
+                                                            T* __restrict__ C, int M, int N, int K, int64_t lda, int64_t ldc,
+                                                            float* __restrict__ part, int per) {
+    typedef W8Mma<T> MM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // KW x 2 x 4 KB A tiles; reused for the reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kb = lane >> 5;
+    const int n_raw = blockIdx.x * 32 + j;
+    const int ksteps = (K + 63) >> 6;
+    const int slice = blockIdx.y * KW + wave;
+    const int k0 = slice * per;
+    const int nst = k0 >= ksteps ? 0 : (ksteps - k0 < per ? ksteps - k0 : per);
+
+    u32 k_mask, k_magic;
+    asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
+
+    const int8_t* wtile = Wm + ((int64_t)blockIdx.x * ksteps * 64 + lane) * 32;
+    const float sc = Act<T>::load(S + (n_raw < N ? n_raw : N - 1));
+    char* abuf = smem + wave * 8192;
+
+    const T* a_src[4];
+    int a_dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u, r = q >> 3, c = q & 7;
+        a_src[u] = A + (int64_t)(r < M ? r : M - 1) * lda + c * 8;
+        a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
+    }
+    const int c_mine = lane & 7;
+    const int kmax = K - 8;
+
+    w8_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    struct Stage {
+        u32x4 a[4];
+        u32x4 w[2];
+    };
+    auto load_stage = [&](int kt, Stage& sg) {
+        const int k = kt * 64 + c_mine * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (8 * u < M)                                     // rows past M are never loaded (block-uniform test)
+                sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c_mine * 8));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            sg.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wtile + (int64_t)kt * 2048 + h * 16));
+    };
+    auto store_a = [&](int buf, const Stage& sg) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (8 * u < M)
+                *reinterpret_cast<u32x4*>(abuf + buf * 4096 + a_dst[u]) = MM::kPairedA ? w8g_pair_even_odd(sg.a[u]) : sg.a[u];
+    };
+    auto mma_step = [&](int buf, const u32x4 (&w)[2]) {
+        const char* sa = abuf + buf * 4096;
+        u32x4 fa[2];
+        typename MM::frag fb[2];
+        auto read_a = [&](int sub) {
+            const int c = kb * 4 + sub;
+            return *reinterpret_cast<const u32x4*>(sa + (j * 8 + (c ^ ((j >> 1) & 7))) * 16);
+        };
+        fa[0] = read_a(0);
+        fb[0] = MM::dequant(w[0][0], w[0][1], k_mask, k_magic, sc);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            if (sub < 3) {
+                const int s1 = sub + 1;
+                fa[s1 & 1] = read_a(s1);
+                fb[s1 & 1] = MM::dequant(w[s1 >> 1][2 * (s1 & 1)], w[s1 >> 1][2 * (s1 & 1) + 1], k_mask, k_magic, sc);
+            }
+            acc = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1]), fb[sub & 1], acc);
+        }
+    };
+
+    if (nst > 0) {
+        Stage st0, st1;
+        load_stage(k0, st0);
+        load_stage(k0 + (nst > 1 ? 1 : 0), st1);
+        int t = 0;
+        for (; t + 2 < nst; t += 2) {
+            store_a(0, st0);
+            {
+                const u32x4 w[2] = {st0.w[0], st0.w[1]};
+                load_stage(k0 + t + 2, st0);
+                mma_step(0, w);
+            }
+            store_a(1, st1);
+            {
+                const u32x4 w[2] = {st1.w[0], st1.w[1]};
+                load_stage(k0 + (t + 3 < nst ? t + 3 : nst - 1), st1);
+                mma_step(1, w);
+            }
+        }
+        store_a(0, st0);
+        mma_step(0, st0.w);
+        if (t + 1 < nst) {
+            store_a(1, st1);
+            mma_step(1, st1.w);
+        }
+    }
+
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((wave - 1) * 16 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < KW; ++w)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += red[((w - 1) * 16 + i) * 64 + lane];
+    if (n_raw >= N) return;
+    const T* bn = bias ? bias + n_raw : nullptr;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + 4 * kb;
+        if (m >= M) continue;
+        if (part) part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[i];
+        else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[i], bn);
+    }
+}
+
+constexpr int kW8FewRowWaves = 4;
+struct W8FewRowPlan {
+    int ksplit, per;
+};
+static W8FewRowPlan w8_fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
+    const int64_t ksteps = (K + 63) / 64, nb = (N + 31) / 32;
+    int64_t ks = (2048 + nb * kW8FewRowWaves - 1) / (nb * kW8FewRowWaves);
+    if (ks > ksteps / (2 * kW8FewRowWaves)) ks = ksteps / (2 * kW8FewRowWaves);
+    while (ks > 1 && (size_t)(ks * M * N) * sizeof(float) > ws_bytes) --ks;
+    if (ks < 1) ks = 1;
+    const int64_t per = (ksteps + ks * kW8FewRowWaves - 1) / (ks * kW8FewRowWaves);
+    return {(int)ks, (int)per};
+}
+
+template <typename T>
+static int launch_w8_fewrow(const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int M, int N, int K,
+                            int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int KW = kW8FewRowWaves;
+    const W8FewRowPlan plan = w8_fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)plan.ksplit);
+    w8_fewrow_kernel<T, KW><<<grid, KW * 64, (size_t)KW * 8192, st>>>((const T*)A, Wm, (const T*)S, (const T*)bias, (T*)C, M, N, K,
+                                                                      lda, ldc, part, plan.per);
+    const int rc = finish_launch();
+    if (rc != 0 || !part) return rc;
+    const int64_t total = (int64_t)M * N;
+    splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
+    return finish_launch();
+}
+
+// rows >= 3 on the tile-major copy: few-row kernel up to 32 rows, tiled GEMM above
+size_t w8_tiled_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 32) {
+        const W8FewRowPlan p = w8_fewrow_plan(M, N, K, (size_t)-1);
+        return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(float) : 0;
+    }
+    return w8_gemm_workspace_bytes(M, N, K);
+}
+
+int w8_fwd_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (M > 32) return w8_gemm_tiled(dtype, A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_w8_fewrow<f16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_BF16: return launch_w8_fewrow<__bf16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

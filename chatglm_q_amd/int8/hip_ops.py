@@ -79,6 +79,41 @@ def dynamic_quant_matmul(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool
     return w8_forward(a, b, b_scale)
 
 
+def tile_w8(weight_nk: Tensor) -> Tensor:
+    """Tile-major derived copy of an (N, K) int8 weight for the MFMA kernels (qlinear_w8_tile)."""
+    lib = _lib.get_lib()
+    N, K = weight_nk.shape
+    weight_nk = weight_nk.contiguous()
+    out = torch.empty(int(lib.qlinear_w8_tiled_bytes(N, K)), dtype=torch.uint8, device=weight_nk.device)
+    with torch.cuda.device(weight_nk.device):
+        st = lib.qlinear_w8_tile(weight_nk.data_ptr(), out.data_ptr(), N, K, K, _lib.stream_ptr(weight_nk.device))
+    _lib.check(st, "qlinear_w8_tile")
+    return out
+
+
+def w8_tiled_supported(a: Tensor, weight_nk: Tensor) -> bool:
+    return (a.is_cuda and a.dtype in (torch.float16, torch.bfloat16) and weight_nk.shape[1] % 16 == 0
+            and a.numel() // max(a.shape[-1], 1) > 2)
+
+
+def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """``a @ (W * scale).T (+ bias)`` for >= 3 rows on the tile-major copy (few-row kernel / tiled MFMA GEMM)."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    if bias is not None:
+        bias = bias.contiguous()
+    with torch.cuda.device(a.device):
+        ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8_FWD_TILED, M, n_out, K, 0))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
+        st = lib.qlinear_w8_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                      M, n_out, K, a2.stride(0) if M > 1 else K, n_out, _lib.dtype_code(a.dtype), _lib.ptr(ws),
+                                      ws_bytes, _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w8_fwd_tiled")
+    return c.reshape(*a.shape[:-1], n_out)
+
+
 def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None,
                      delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
                      eps: float = 0.0) -> Tensor:

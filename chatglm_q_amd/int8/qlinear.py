@@ -73,12 +73,24 @@ class DynamicQuantizeLinear(nn.Module):
         if check_input(input) and not (input.requires_grad and torch.is_grad_enabled()):
             if self.act_quant:
                 return hip_ops.w8a8_forward(input, self.weight, self.weight_scale, self.bias)
+            if hip_ops.w8_tiled_supported(input, self.weight):
+                # >= 3 rows: MFMA kernels on the tile-major derived copy (built lazily, keyed on the buffer's version)
+                return hip_ops.w8_forward_tiled(input, self.prepare()._tiled, self.out_features, self.weight_scale, self.bias)
             # bias fused after the output rounding: same two roundings as qlinear.py:90-93
             return hip_ops.w8_forward(input, self.weight.t(), self.weight_scale, self.bias)
         out = dynamic_quant_matmul(input, self.weight.t(), self.weight_scale)
         if self.bias is not None:
             out = out + self.bias              # not in place: the Function's output may be a view
         return out
+
+    @torch.no_grad()
+    def prepare(self):
+        """Build (or refresh) the tile-major derived copy now, e.g. before capturing a HIP graph."""
+        key = (self.weight.data_ptr(), self.weight._version)
+        if getattr(self, "_tiled", None) is None or self._tiled_key != key:
+            self._tiled = hip_ops.tile_w8(self.weight) if self.weight.is_cuda and self.in_features % 16 == 0 else None
+            self._tiled_key = key
+        return self
 
     @torch.no_grad()
     def gated(self, hidden: int):

@@ -70,6 +70,7 @@ extern "C" {
 #define QL_OP_W4G32_FWD_PACKED 2
 #define QL_OP_W8_FWD 3
 #define QL_OP_W8A8_FWD 4
+#define QL_OP_W8_FWD_TILED 5
 
 int qlinear_abi_version(void);
 const char* qlinear_status_string(int status);
@@ -80,7 +81,7 @@ uint64_t qlinear_launch_count(void);
 
 /* Bytes of scratch the op wants for this shape (0 = none).  The caller allocates it (e.g. from
  * torch's caching allocator so stream semantics hold) and passes it to the op.  It is REQUIRED by
- * QL_OP_W4G32_FWD (QL_ERR_WORKSPACE otherwise) and OPTIONAL for QL_OP_W4G32_FWD_PACKED / QL_OP_W8_FWD / QL_OP_W8A8_FWD,
+ * QL_OP_W4G32_FWD (QL_ERR_WORKSPACE otherwise) and OPTIONAL for QL_OP_W4G32_FWD_PACKED / QL_OP_W8_FWD[_TILED] / QL_OP_W8A8_FWD,
  * where it lets a few-row (5 <= M < ~256) MFMA GEMM split K over workgroups into fp32 slabs that a
  * second launch sums; without it (NULL / too small / not 16-byte aligned) those shapes run unsplit -
  * same rounding sequence, several times slower. */
@@ -151,6 +152,18 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
                    int64_t M, int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda,
                    int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
                    void* stream);
+
+/* ---- int8 weights, derived tile-major copy (rows >= 3: MFMA kernels) ------------------------
+ * tiled[N / 32][64-deep K step][lane][32 bytes]: lane = 32 kb + j holds bytes k = 64 kt + 32 kb .. + 31 of output
+ * channel 32 (n / 32) + j, zero padded - the order in which the lanes of a wave feed their MFMA fragments, so a
+ * wave's weight load is 2 KB contiguous (from the (N, K) buffer it is 32 bytes from each of 32 rows).  A lazily
+ * built, non-persistent copy like the int4 one; the (N, K) buffer stays the source of truth.  fp16 / bf16,
+ * K % 16 == 0.  qlinear_w8_fwd_tiled: few-row kernel (independent K-slice waves) up to 32 rows, tiled GEMM above;
+ * workspace as for qlinear_w8_fwd (QL_OP_W8_FWD_TILED, optional). */
+size_t qlinear_w8_tiled_bytes(int64_t N, int64_t K);
+int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t ldw_n, void* stream);
+int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One-row (decode) int8 forward with the add + RMSNorm PROLOGUE (QL_PRO_ADDNORM) and optionally the SiLU * gate
  * EPILOGUE (| QL_EPI_SILU_GATE: the N rows of W - and S, bias - come in (h_2t, h_2t+1, gate_2t, gate_2t+1) quads,

@@ -120,8 +120,8 @@ W4_SHAPES = [
     (33, 512, 384, "f16", False),
     (1, 4096, 4096, "bf16", False),
     (4, 1024, 512, "bf16", True),
-    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (w4_skinny.hip), split-K slabs
-    (33, 13696, 256, "f16", False),     # ... MT = 2, 428 groups: half-filled last super-step
+    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (independent K-slice waves), split-K slabs
+    (33, 13696, 256, "f16", False),     # ... 33 rows: tiled GEMM, MT = 2; 428 groups
     (17, 576, 136, "bf16", True),       # ... 18 groups, ragged N
     (64, 1024, 200, "f16", False),      # ... ragged N, N % 4 == 0
     (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
@@ -260,8 +260,8 @@ W8_SHAPES = [
     (5, 512, 96, "f32", True),
     (128, 4096, 256, "f32", True),      # BASELINE config 1 shape (N cut for test time)
     (40, 1024, 256, "f16", False),
-    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (w4_skinny.hip), split-K slabs
-    (33, 13696, 256, "f16", False),     # ... MT = 2, 428 groups: half-filled last super-step
+    (8, 4096, 4608, "f16", True),       # few-row MFMA kernel (independent K-slice waves), split-K slabs
+    (33, 13696, 256, "f16", False),     # ... 33 rows: tiled GEMM, MT = 2; 428 groups
     (17, 576, 136, "bf16", True),       # ... 18 groups, ragged N
     (64, 1024, 200, "f16", False),      # ... ragged N, N % 4 == 0
     (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
@@ -290,7 +290,12 @@ def test_int8_vs_oracle(M, K, N, dt, has_bias, strict):
     layer = layer.to(DEV)
     with torch.no_grad():
         out = h8.w8_forward(a.to(DEV), layer.weight.t(), layer.weight_scale, layer.bias, strict=strict)
-        assert torch.equal(layer(a.to(DEV)), h8.w8_forward(a.to(DEV), layer.weight.t(), layer.weight_scale, layer.bias))
+        mod = layer(a.to(DEV))
+        if h8.w8_tiled_supported(a.to(DEV), layer.weight):
+            # >= 3 rows of a 16-bit dtype: the module runs the MFMA kernels on its tile-major derived copy
+            assert_close(mod, ref, dt, f"module {M}x{K}x{N}")
+        else:
+            assert torch.equal(mod, h8.w8_forward(a.to(DEV), layer.weight.t(), layer.weight_scale, layer.bias))
     assert_close(out, ref, dt, f"{M}x{K}x{N}")
     if strict and dt == "f16":
         assert O.rel_l2(t2n(out), ref) <= 1.5e-4
