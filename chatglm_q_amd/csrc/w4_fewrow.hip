@@ -19,7 +19,7 @@
 
 namespace ql {
 
-template <typename T, int KW, int NT>
+template <typename T, int KW, int NT, int MT>
 __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wm,
                                                             const T* __restrict__ Sm, const T* __restrict__ bias,
                                                             T* __restrict__ C, int M, int N, int K, int G, int64_t lda,
@@ -50,13 +50,14 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
         wtile[t] = Wm + (int64_t)ct * ksteps * 64 + lane;
         stile[t] = Sm + (int64_t)ct * ksteps * 64 + lane;
     }
-    char* abuf = smem + wave * 8192;                           // two 4 KB tiles, private to the wave
+    constexpr int ATILE = 4096 * MT;                          // one A tile: 32 MT rows x 128 bytes
+    char* abuf = smem + wave * (2 * ATILE);                   // two tiles, private to the wave
 
     // A staging by the wave: chunk q = lane + 64 u -> row q >> 3 (8 u .. 8 u + 7), 16-byte column q & 7
-    const T* a_src[4];
-    int a_dst[4];
+    const T* a_src[4 * MT];
+    int a_dst[4 * MT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 4 * MT; ++u) {
         const int q = lane + 64 * u, r = q >> 3, c = q & 7;
         a_src[u] = A + (int64_t)(r < M ? r : M - 1) * lda + c * 8;
         a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
@@ -64,22 +65,24 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     const int c_mine = lane & 7;
     const int kmax = K - 8;
 
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.f;
 
     typedef decltype(MM::scale_pair(stile[0], true)) scale_t;
     struct Stage {
-        u32x4 a[4];
+        u32x4 a[4 * MT];
         u32x4 w[NT];
         T s[NT];
     };
     auto load_stage = [&](int kt, Stage& sg) {
         const int k = kt * 64 + c_mine * 8;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4 * MT; ++u)
             if (8 * u < M)                                     // rows past M are never loaded (block-uniform test)
                 sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c_mine * 8));
 #pragma unroll
@@ -90,8 +93,8 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     };
     auto store_a = [&](int buf, const Stage& sg) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (8 * u < M) *reinterpret_cast<u32x4*>(abuf + buf * 4096 + a_dst[u]) = sg.a[u];
+        for (int u = 0; u < 4 * MT; ++u)
+            if (8 * u < M) *reinterpret_cast<u32x4*>(abuf + buf * ATILE + a_dst[u]) = sg.a[u];
     };
     auto mma_step = [&](int buf, int kt, const u32x4 (&w)[NT], const T (&s_raw)[NT]) {
         const int g = 2 * kt + kb;
@@ -101,26 +104,32 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
             const T s_eff = g < G ? s_raw[t] : (T)0.f;       // the missing half of an odd last step contributes 0
             s[t] = MM::scale_pair(&s_eff, true);
         }
-        const char* sa = abuf + buf * 4096;
-        u32x4 fa[2];
+        const char* sa = abuf + buf * ATILE;
+        u32x4 fa[2][MT];
         typename MM::frag fb[2][NT];
-        auto read_a = [&](int sub) {
+        auto read_a = [&](int sub, u32x4 (&fr)[MT]) {
             const int c = kb * 4 + sub;
-            return *reinterpret_cast<const u32x4*>(sa + (j * 8 + (c ^ ((j >> 1) & 7))) * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = mt * 32 + j;
+                fr[mt] = *reinterpret_cast<const u32x4*>(sa + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+            }
         };
-        fa[0] = read_a(0);
+        read_a(0, fa[0]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) fb[0][t] = MM::dequant(w[t][0], k_mask_lo, k_mask_hi, k_magic, s[t]);
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             if (sub < 3) {
-                fa[(sub + 1) & 1] = read_a(sub + 1);
+                read_a(sub + 1, fa[(sub + 1) & 1]);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) fb[(sub + 1) & 1][t] = MM::dequant(w[t][sub + 1], k_mask_lo, k_mask_hi, k_magic, s[t]);
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1]), fb[sub & 1][t], acc[t]);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[mt][t] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]), fb[sub & 1][t], acc[mt][t]);
         }
     };
 
@@ -163,30 +172,36 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     float* red = reinterpret_cast<float*>(smem);
     if (wave > 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[(((wave - 1) * NT + t) * 16 + i) * 64 + lane] = acc[t][i];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[((((wave - 1) * MT + mt) * NT + t) * 16 + i) * 64 + lane] = acc[mt][t][i];
     }
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
     for (int w = 1; w < KW; ++w)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] += red[(((w - 1) * NT + t) * 16 + i) * 64 + lane];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][t][i] += red[((((w - 1) * MT + mt) * NT + t) * 16 + i) * 64 + lane];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n_raw = n_base + 32 * t;
         if (n_raw >= N) continue;
         const T* bn = bias ? bias + n_raw : nullptr;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = (i & 3) + 8 * (i >> 2) + 4 * kb;
-            if (m >= M) continue;
-            if (part) part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[t][i];
-            else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[t][i], bn);
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m >= M) continue;
+                if (part) part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[mt][t][i];
+                else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][t][i], bn);
+            }
     }
 }
 
@@ -216,7 +231,7 @@ static FewRowPlan fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) 
 // 13696->4096 14.3 vs 20.6 (the GEMV at ONE row: 5.3 / 4.7 / 14.1 / 10.2).  QLINEAR_FEWROW=0 disables it.
 bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K) {
     static const bool on = [] { const char* e = getenv("QLINEAR_FEWROW"); return !e || atoi(e) != 0; }();
-    return on && M <= 32 && K >= 512;
+    return on && M <= 32 && K >= 512;       // two row tiles (33..64 rows) measured no better than the tiled GEMM
 }
 
 size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -224,7 +239,7 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(float) : 0;
 }
 
-template <typename T, int NT>
+template <typename T, int NT, int MT>
 static int launch_fewrow_nt(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
                             int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int KW = kFewRowWaves;
@@ -235,9 +250,9 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
     const T* Sp = (const T*)((const char*)packed + L.off_sm);
     float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
-    constexpr size_t lds = (size_t)KW * 8192;
-    static_assert((KW - 1) * NT * 16 * 64 * 4 <= KW * 8192, "reduction scratch fits in the A buffers");
-    w4_fewrow_kernel<T, KW, NT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G, lda, ldc,
+    constexpr size_t lds = (size_t)KW * 8192 * MT;
+    static_assert((KW - 1) * MT * NT * 16 * 64 * 4 <= KW * 8192 * MT, "reduction scratch fits in the A buffers");
+    w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G, lda, ldc,
                                                             part, plan.per);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
@@ -249,7 +264,7 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
 template <typename T>
 static int launch_fewrow(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
                          int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    return launch_fewrow_nt<T, 1>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    return launch_fewrow_nt<T, 1, 1>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
 }
 
 int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,

@@ -124,7 +124,9 @@ W4_SHAPES = [
     (33, 13696, 256, "f16", False),     # ... 33 rows: tiled GEMM, MT = 2; 428 groups
     (17, 576, 136, "bf16", True),       # ... 18 groups, ragged N
     (64, 1024, 200, "f16", False),      # ... ragged N, N % 4 == 0
-    (64, 4096, 512, "f16", True),       # MFMA GEMM, MT = 2
+    (48, 4096, 4096, "f16", False),     # ... two row tiles
+    (65, 1024, 264, "f16", True),       # first row count of the tiled GEMM
+    (64, 4096, 512, "f16", True),       # two row tiles
     (200, 1024, 640, "f16", False),     # MT = 4, ragged M (200 = 128 + 72)
     (129, 96, 136, "f16", True),        # odd group count (3): half-empty last K step; ragged N
     (2048, 4096, 256, "f16", False),    # prefill-sized M
