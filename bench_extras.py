@@ -220,6 +220,27 @@ def e2e_generate(torch, device):
         "note": "whole forward incl. attention (reference op sequence: torch batched GEMMs on strided cache views, keys limited "
                 "to the filled prefix, mask add + fp32 softmax + cast in one HIP launch) and norms; lm_head for the last "
                 "position only; torch's fused SDPA measured slower here (0.236 s)"}
+    # batched greedy decode (graph-replayed step, 32-token prompts): aggregate tokens per second
+    bd = {}
+    for Bd in (8, 32):
+        try:
+            idsb = torch.randint(0, cfg.vocab_size, (Bd, 32), device=device)
+            sb = DecodeSession(model, Bd, 128, use_graph=True)
+            lg = sb.prefill(idsb)
+            sb.tok.copy_(lg.argmax(-1, keepdim=True))
+            sb.capture(greedy=True)
+            sb.decode_step(greedy=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(48):
+                sb.decode_step(greedy=True)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            bd[f"batch_{Bd}"] = {"ms_per_step": round(dtb / 48 * 1e3, 3), "tok_per_s": round(Bd * 48 / dtb, 1)}
+            del sb
+        except Exception as e:
+            bd[f"batch_{Bd}"] = {"error": repr(e)}
+    out["batched_decode"] = bd
     del model, sess
     torch.cuda.empty_cache()
     return out
