@@ -287,18 +287,27 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
     return decode_attention(dtype, Q, Kcache, Vcache, mask, Out, B, H, G, D, capacity, (hipStream_t)stream);
 }
 
+size_t qlinear_decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity) {
+    if (B <= 0 || H <= 0 || D <= 0 || capacity <= 0) return 0;
+    return decode_attention_split_bytes(B, H, D, capacity);
+}
+
 int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                                  int64_t capacity, int64_t ldqkv, int dtype, void* stream) {
+                                  int64_t capacity, int64_t ldqkv, int dtype, void* split_workspace,
+                                  size_t split_workspace_bytes, void* stream) {
     if (!QKV || !table || !pos || !widx || !Kcache || !Vcache || !mask || !Out) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(B) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) || H % G != 0 ||
         ldqkv < (H + 2 * G) * D)
         return QL_ERR_BAD_SHAPE;
-    if ((D != 128 && D != 64 && D != 32) || (capacity + 35 * D + 8) * 4 > 64 * 1024) return QL_ERR_UNSUPPORTED;
+    const bool split = split_workspace != nullptr;
+    if (split && (split_workspace_bytes < decode_attention_split_bytes(B, H, D, capacity) || !aligned(split_workspace, 4)))
+        return QL_ERR_WORKSPACE;
+    if ((D != 128 && D != 64 && D != 32) || (!split && (capacity + 35 * D + 8) * 4 > 64 * 1024)) return QL_ERR_UNSUPPORTED;
     if (!aligned(Kcache, 16) || !aligned(Vcache, 16)) return QL_ERR_MISALIGNED;
     return decode_attention_rope(dtype, QKV, table, pos, widx, Kcache, Vcache, mask, Out, B, H, G, D, capacity, ldqkv,
-                                 (hipStream_t)stream);
+                                 (float*)split_workspace, (hipStream_t)stream);
 }
 
 int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,

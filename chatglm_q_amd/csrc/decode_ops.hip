@@ -179,10 +179,16 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict_
 template <typename T, int D, bool ROPE>
 __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restrict__ Q, T* Kc, T* Vc,
                                                                const float* __restrict__ mask, T* __restrict__ Out, int H,
-                                                               int G, int capacity, float sqrt_d,
+                                                               int G, int cap_full, float sqrt_d,
                                                                const T* __restrict__ table, const int64_t* __restrict__ pos,
-                                                               const int64_t* __restrict__ widx, int64_t ldq) {
+                                                               const int64_t* __restrict__ widx, int64_t ldq,
+                                                               int window, float* __restrict__ split_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // Long contexts (split_out != nullptr): blockIdx.y owns the positions [t_lo, t_lo + capacity) and leaves
+    // (local max, local exp-sum, unnormalised output) for attention_combine_kernel - a decode step has only B * H
+    // blocks otherwise, and one block per head walking thousands of positions leaves most of the chip idle.
+    const int t_lo = split_out ? (int)blockIdx.y * window : 0;
+    const int capacity = split_out ? (cap_full - t_lo < window ? cap_full - t_lo : window) : cap_full;
     static_assert(2 * D <= 256, "one thread per q pair, k pair and v value");
     constexpr int CH = D / 8;                                 // 8-wide chunks per head row
     constexpr int SL = 256 / CH;                              // position slices in the PV phase
@@ -194,9 +200,9 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     float* vnew = knew + D;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int g = h / (H / G);
-    const T* kb = Kc + ((int64_t)b * capacity * G + g) * D;
-    const T* vb = Vc + ((int64_t)b * capacity * G + g) * D;
-    const float* mk = mask + (int64_t)b * capacity;
+    const T* kb = Kc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
+    const T* vb = Vc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
+    const float* mk = mask + (int64_t)b * cap_full + t_lo;
     // Thread (c, r) owns 16-byte chunk c of rows r, r + RP, r + 2 RP, ... in BOTH phases (Q.K and P.V).  A decode step
     // gives this kernel ~32 blocks, so its time is a chain of global round trips, not bandwidth: for the 16-bit
     // dtypes the key chunks, value chunks and mask entries of the first NP rows per thread (256 positions) are
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         // Q is the fused projection row (H q heads | G k heads | G v heads); rotate q and k exactly as
         // rope_kv_write_kernel does (rounded to T), keep k / v of the new position in LDS - the group's other
         // blocks must not read that cache row while block (h % (H/G) == 0) writes it
-        wrow = (int)widx[0];
+        wrow = (int)widx[0] - t_lo;                          // window-local; outside [0, capacity) for other windows
         const T* row = Q + (int64_t)b * ldq;
         const T* cs = table + pos[b] * D;
         const int d = threadIdx.x;
@@ -249,8 +255,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
             vnew[d - D] = Act<T>::load(row + (H + G + g) * D + (d - D));
         }
         __syncthreads();
-        if (h % (H / G) == 0 && d < 2 * D) {
-            const int64_t at = (((int64_t)b * capacity + wrow) * G + g) * D;
+        if (h % (H / G) == 0 && d < 2 * D && wrow >= 0 && wrow < capacity) {
+            const int64_t at = (((int64_t)b * cap_full + t_lo + wrow) * G + g) * D;
             if (d < D) Act<T>::store(Kc + at + d, knew[d]);
             else Act<T>::store(Vc + at + d - D, vnew[d - D]);
         }
@@ -339,10 +345,11 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     }
     sum = (QL_ATT_ABLATE & 4) ? 100.f : block_sum_256(sum, red);
     const float inv = 1.0f / sum;
-    for (int t = threadIdx.x; t < capacity; t += 256) sc[t] = Act<T>::round(sc[t] * inv);
+    if (!split_out)                                           // split mode keeps exp(s - local max): normalised by the combine
+        for (int t = threadIdx.x; t < capacity; t += 256) sc[t] = Act<T>::round(sc[t] * inv);
     __syncthreads();
     float pw = 0.f;
-    if constexpr (ROPE) {
+    if (ROPE && wrow >= 0 && wrow < capacity) {               // block-uniform
         // the new position's value comes from LDS: take its probability out of the table (0 x the cache row = 0)
         pw = sc[wrow];
         __syncthreads();
@@ -391,11 +398,32 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[sl * D + c * 8 + e] = o[e];
     __syncthreads();
+    float* so = split_out ? split_out + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (D + 2) : nullptr;
+    if (so && threadIdx.x == 0) {
+        so[0] = mx;
+        so[1] = sum;
+    }
     for (int d = threadIdx.x; d < D; d += 256) {
         float tot = 0.f;
         for (int s2 = 0; s2 < SL; ++s2) tot += part[s2 * D + d];
-        Act<T>::store(Out + ((int64_t)b * H + h) * D + d, tot);
+        if (so) so[2 + d] = tot;
+        else Act<T>::store(Out + ((int64_t)b * H + h) * D + d, tot);
     }
+}
+
+// out = sum_w o_w e^(m_w - m) / sum_w l_w e^(m_w - m): the windows of decode_attention_kernel's split mode
+template <typename T, int D>
+__global__ __launch_bounds__(D) void attention_combine_kernel(const float* __restrict__ part, T* __restrict__ Out, int nwin) {
+    const float* p = part + (int64_t)blockIdx.x * nwin * (D + 2);
+    float m = -INFINITY;
+    for (int w = 0; w < nwin; ++w) m = fmaxf(m, p[w * (D + 2)]);
+    float l = 0.f, o = 0.f;
+    for (int w = 0; w < nwin; ++w) {
+        const float f = __expf(p[w * (D + 2)] - m);
+        l = __builtin_fmaf(p[w * (D + 2) + 1], f, l);
+        o = __builtin_fmaf(p[w * (D + 2) + 2 + threadIdx.x], f, o);
+    }
+    Act<T>::store(Out + (int64_t)blockIdx.x * D + threadIdx.x, o / l);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -577,16 +605,25 @@ int rope_kv_write(int dtype, const void* QKV, const void* table, const int64_t* 
     return finish_launch();
 }
 
+constexpr int kAttnWindow = 256;                          // positions per block in split mode (= the prefetched tile)
 template <typename T, bool ROPE>
 static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G,
                             int64_t D, int64_t capacity, const void* table, const int64_t* pos, const int64_t* widx,
-                            int64_t ldq, hipStream_t st) {
+                            int64_t ldq, float* split_ws, hipStream_t st) {
     const float sq = sqrtf((float)D);
+    const int nwin = split_ws ? (int)((capacity + kAttnWindow - 1) / kAttnWindow) : 1;
+    dim3 grid((unsigned)(B * H), (unsigned)nwin);
 #define QL_ATT(DD)                                                                                                  \
     {                                                                                                               \
-        const size_t lds = (size_t)(capacity + DD + 4 + (256 / (DD / 8)) * DD + 2 * DD) * sizeof(float);           \
-        decode_attention_kernel<T, DD, ROPE><<<(unsigned)(B * H), 256, lds, st>>>(                                  \
-            (const T*)Q, (T*)Kc, (T*)Vc, mask, (T*)Out, (int)H, (int)G, (int)capacity, sq, (const T*)table, pos, widx, ldq); \
+        const size_t lds = (size_t)((split_ws ? kAttnWindow : capacity) + DD + 4 + (256 / (DD / 8)) * DD + 2 * DD) * sizeof(float); \
+        decode_attention_kernel<T, DD, ROPE><<<grid, 256, lds, st>>>(                                               \
+            (const T*)Q, (T*)Kc, (T*)Vc, mask, (T*)Out, (int)H, (int)G, (int)capacity, sq, (const T*)table, pos, widx, ldq, \
+            kAttnWindow, split_ws);                                                                                 \
+        if (split_ws) {                                                                                             \
+            const int rc = finish_launch();                                                                         \
+            if (rc != 0) return rc;                                                                                 \
+            attention_combine_kernel<T, DD><<<(unsigned)(B * H), DD, 0, st>>>(split_ws, (T*)Out, nwin);             \
+        }                                                                                                           \
     }
     if (D == 128) QL_ATT(128)
     else if (D == 64) QL_ATT(64)
@@ -599,14 +636,19 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
 int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
     QL_DT(dtype, return (launch_attention<T, false>(Q, (void*)Kc, (void*)Vc, mask, Out, B, H, G, D, capacity, nullptr, nullptr,
-                                                    nullptr, 0, st)))
+                                                    nullptr, 0, nullptr, st)))
     return QL_ERR_BAD_DTYPE;
+}
+
+size_t decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity) {
+    return (size_t)(B * H * ((capacity + kAttnWindow - 1) / kAttnWindow) * (D + 2)) * sizeof(float);
 }
 
 int decode_attention_rope(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kc,
                           void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                          int64_t capacity, int64_t ldqkv, hipStream_t st) {
-    QL_DT(dtype, return (launch_attention<T, true>(QKV, Kc, Vc, mask, Out, B, H, G, D, capacity, table, pos, widx, ldqkv, st)))
+                          int64_t capacity, int64_t ldqkv, float* split_ws, hipStream_t st) {
+    QL_DT(dtype, return (launch_attention<T, true>(QKV, Kc, Vc, mask, Out, B, H, G, D, capacity, table, pos, widx, ldqkv, split_ws,
+                                                   st)))
     return QL_ERR_BAD_DTYPE;
 }
 

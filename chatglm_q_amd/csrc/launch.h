@@ -157,7 +157,8 @@ int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, c
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st);
 int decode_attention_rope(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kc,
                           void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                          int64_t capacity, int64_t ldqkv, hipStream_t st);
+                          int64_t capacity, int64_t ldqkv, float* split_ws, hipStream_t st);   // split_ws: nullable
+size_t decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st);
 int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_t rows, int64_t Tn, int64_t mask_rows, int64_t lds,
                    int64_t ldm, int64_t ldp, hipStream_t st);

@@ -3,6 +3,8 @@ SURVEY.md 8f row N1).  Each replaces a handful of tiny torch launches with one H
 model graph's rounding sequence (chatglm_q/model.py, lines cited in include/qlinear_hip.h)."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -69,8 +71,11 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
     return out
 
 
+SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "768"))   # cache capacity from which windows are split
+
+
 def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
-                          mask: Tensor, n_head: int, n_groups: int, d_head: int) -> Tensor:
+                          mask: Tensor, n_head: int, n_groups: int, d_head: int, split: bool | None = None) -> Tensor:
     """``decode_attention(rope_kv_write(qkv, ...), ...)`` for one position per sequence in a single launch:
     qkv (B, 1, (H+2G) D) -> (B, 1, H*D); the rotated key and the value are written into the caches at
     ``write_index[0]``."""
@@ -80,11 +85,16 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
         raise ValueError("decode_attention_rope serves one position per sequence")
     qkv = qkv.contiguous()
     out = torch.empty((B, 1, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
+    capacity = k_cache.shape[1]
+    if split is None:
+        split = capacity >= SPLIT_ATTENTION_FROM
     with torch.cuda.device(qkv.device):
+        ws_bytes = int(lib.qlinear_decode_attention_split_bytes(B, n_head, d_head, capacity)) if split else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes else None
         st = lib.qlinear_decode_attention_rope(qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(),
                                                write_index.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
                                                mask.data_ptr(), out.data_ptr(), B, n_head, n_groups, d_head,
-                                               k_cache.shape[1], W, _lib.dtype_code(qkv.dtype),
+                                               capacity, W, _lib.dtype_code(qkv.dtype), _lib.ptr(ws), ws_bytes,
                                                _lib.stream_ptr(qkv.device))
     _lib.check(st, "qlinear_decode_attention_rope")
     return out

@@ -224,9 +224,15 @@ int qlinear_rope_kv_write(const void* QKV, const void* table, const int64_t* pos
                           int64_t capacity, int64_t ldqkv, int dtype, void* stream);
 int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, void* Out,
                              int64_t B, int64_t H, int64_t G, int64_t D, int64_t capacity, int dtype, void* stream);
+/* split_workspace (nullable, qlinear_decode_attention_split_bytes): long contexts - 256-position windows over
+ * blockIdx.y leave (max, exp-sum, unnormalised output) there and a second launch combines them; the probabilities are
+ * then not rounded to the activation dtype before P.V (same function within fp tolerance).  Without it one block per
+ * (sequence, head) walks the whole cache with the reference's rounding points (capacity <= ~15 k). */
+size_t qlinear_decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                                  int64_t capacity, int64_t ldqkv, int dtype, void* stream);
+                                  int64_t capacity, int64_t ldqkv, int dtype, void* split_workspace,
+                                  size_t split_workspace_bytes, void* stream);
 /* masked_softmax: P[r, :] = round(softmax_fp32(scores[r, :] + mask[r % mask_rows, :])) - the add / fp32 softmax / cast
  * between the two GEMMs of the many-position attention (chatglm_q/model.py:166-170) in one pass; mask nullable. */
 int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,

@@ -169,7 +169,8 @@ def test_gate_epilogue_equals_separate_ops(dtype, bias):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("geom", [(2, 32, 2, 128, 192, 70), (3, 8, 4, 64, 64, 0), (1, 4, 1, 32, 40, 39),
-                                  (1, 32, 2, 128, 640, 300), (2, 8, 2, 128, 320, 319), (1, 32, 2, 128, 64, 0)])
+                                  (1, 32, 2, 128, 640, 300), (2, 8, 2, 128, 320, 319), (1, 32, 2, 128, 64, 0),
+                                  (1, 32, 2, 128, 2048, 1500), (2, 4, 2, 64, 1000, 999)])
 def test_rope_attention_single_launch_equals_two(dtype, geom):
     """decode_attention_rope against rope_kv_write followed by decode_attention: same cache rows bit for bit,
     same attention output up to the position of the new value in the PV sum."""
@@ -191,9 +192,17 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
     (k1, v1), (k2, v2) = caches
     q = F_.rope_kv_write(qkv, table, pos, widx, k1, v1, H, Gq, D)
     want = F_.decode_attention(q, k1, v1, mask, H, Gq, D)
-    got = F_.decode_attention_rope(qkv, table, pos, widx, k2, v2, mask, H, Gq, D)
+    got = F_.decode_attention_rope(qkv, table, pos, widx, k2, v2, mask, H, Gq, D, split=False)
     assert torch.equal(k1, k2) and torch.equal(v1, v2)
     assert O.rel_l2(t2n(got), t2n(want)) < (1e-5 if dtype == torch.float32 else 2e-3)
+    # long-context form: 256-position windows + combine launch (probabilities not rounded before P.V)
+    g3 = torch.Generator(device=DEV).manual_seed(6)
+    k3 = torch.randn(B, cap, Gq, D, device=DEV, generator=g3).to(dtype)
+    v3 = torch.randn(B, cap, Gq, D, device=DEV, generator=g3).to(dtype)
+    got_split = F_.decode_attention_rope(qkv, table, pos, widx, k3, v3, mask, H, Gq, D, split=True)
+    assert torch.equal(k1, k3) and torch.equal(v1, v3)
+    # (bf16: the unsplit path rounds every probability to 8 mantissa bits, the split one does not)
+    assert O.rel_l2(t2n(got_split), t2n(want)) < {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
