@@ -71,7 +71,7 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
     return out
 
 
-SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "768"))   # cache capacity from which windows are split
+SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "448"))   # cache capacity from which windows are split
 
 
 def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,

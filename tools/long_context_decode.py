@@ -23,5 +23,5 @@ for ctx in [int(x) for x in os.environ.get("CONTEXTS", "128,1024,4096,8000").spl
         sess.decode_step(greedy=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 48
-    print(f"context {ctx:5d} (capacity {cap}): {dt * 1e3:.3f} ms/token  {1 / dt:.1f} tok/s  (split from {os.environ.get('QLINEAR_SPLIT_ATTENTION_FROM', '768')})", flush=True)
+    print(f"context {ctx:5d} (capacity {cap}): {dt * 1e3:.3f} ms/token  {1 / dt:.1f} tok/s  (split from {os.environ.get('QLINEAR_SPLIT_ATTENTION_FROM', '448')})", flush=True)
     del sess
