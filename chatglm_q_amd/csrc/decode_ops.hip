@@ -411,19 +411,317 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
     }
 }
 
-// out = sum_w o_w e^(m_w - m) / sum_w l_w e^(m_w - m): the windows of decode_attention_kernel's split mode
-template <typename T, int D>
-__global__ __launch_bounds__(D) void attention_combine_kernel(const float* __restrict__ part, T* __restrict__ Out, int nwin) {
-    const float* p = part + (int64_t)blockIdx.x * nwin * (D + 2);
-    float m = -INFINITY;
-    for (int w = 0; w < nwin; ++w) m = fmaxf(m, p[w * (D + 2)]);
-    float l = 0.f, o = 0.f;
-    for (int w = 0; w < nwin; ++w) {
-        const float f = __expf(p[w * (D + 2)] - m);
-        l = __builtin_fmaf(p[w * (D + 2) + 1], f, l);
-        o = __builtin_fmaf(p[w * (D + 2) + 2 + threadIdx.x], f, o);
+// ---------------------------------------------------------------------------------------------
+// Grouped-query decode attention on the matrix cores (16-bit dtypes, D = 128, 16 query heads per key/value group -
+// ChatGLM2's geometry): one block = (sequence, key/value GROUP, 256-position window), so a cache row is read once for
+// the group's 16 heads instead of once per head, and the 16 heads are the N dimension of 16x16 MFMA tiles:
+//   S^T (positions x heads) = K (positions x d) Q^T          v_mfma_f32_16x16x32: A = key rows straight from the cache
+//   O^T (d x heads)         = V^T (d x positions) P^T        v_mfma_f32_16x16x16: B = exp(S^T - max) in the C layout
+//                                                            of the first product, A = ds_read_b64_tr_b16 of the
+//                                                            wave's row-major value rows in LDS (pitch 288 B)
+// Wave w owns positions [64 w, 64 w + 64) of the window with its own running maximum; the four waves' partial
+// (max, exp-sum, O) are merged through LDS after ONE barrier - the same arithmetic attention_combine_kernel applies
+// across windows.  Rounding points: rotary outputs, q / sqrt(d), the scores and the output are rounded to T as in
+// decode_attention_kernel; P is rounded to T as exp(s - wave max) (the reference rounds exp(s - max) / sum: the same
+// relative error, not the same bits), the exp-sum uses the unrounded values.
+// Window fits one block (capacity <= 256): Out is written directly.  Otherwise split_out receives (max, sum, O) per
+// head and window for attention_combine_kernel.  The step's new key / value row is taken from LDS (only this block
+// touches the group's cache rows, so the row is written by the block whose window holds it).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2v __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct AttMma;
+template <> struct AttMma<f16> {
+    typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 qk(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
     }
-    Act<T>::store(Out + (int64_t)blockIdx.x * D + threadIdx.x, o / l);
+    static __device__ __forceinline__ f32x4 pv(u32x2v a, u32x2v b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+    }
+};
+template <> struct AttMma<__bf16> {
+    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x4 qk(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 pv(u32x2v a, u32x2v b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+};
+template <typename T>
+__device__ __forceinline__ u32 pack2(float a, float b) {
+    const T x = (T)a, y = (T)b;
+    uint16_t lo, hi;
+    __builtin_memcpy(&lo, &x, 2);
+    __builtin_memcpy(&hi, &y, 2);
+    return (u32)lo | ((u32)hi << 16);
+}
+template <typename T>
+__device__ __forceinline__ void unpack2(u32 w, float& a, float& b) {
+    const uint16_t lo = (uint16_t)(w & 0xFFFFu), hi = (uint16_t)(w >> 16);
+    T x, y;
+    __builtin_memcpy(&x, &lo, 2);
+    __builtin_memcpy(&y, &hi, 2);
+    a = (float)x;
+    b = (float)y;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __restrict__ QKV, T* Kc, T* Vc,
+                                                                    const float* __restrict__ mask, T* __restrict__ Out,
+                                                                    int H, int G, int cap_full, float sqrt_d,
+                                                                    const T* __restrict__ table,
+                                                                    const int64_t* __restrict__ pos,
+                                                                    const int64_t* __restrict__ widx, int64_t ldq,
+                                                                    float* __restrict__ split_out) {
+    static_assert(sizeof(T) == 2, "16-bit dtypes");
+    constexpr int D = 128, HP = 16, WIN = 256;
+    constexpr int VP = 288;                                   // bytes per value row in LDS: rows 8 banks apart (tr reads conflict-free)
+    constexpr int QP = 272;                                   // bytes per query head in LDS
+    constexpr int OP = 132;                                   // floats per head of a wave's partial output
+    __shared__ __attribute__((aligned(16))) unsigned char vimg[4][32 * VP];   // per wave: 32 value rows; later its partial O
+    __shared__ __attribute__((aligned(16))) unsigned char qs[HP * QP];
+    __shared__ __attribute__((aligned(16))) T knew[D];
+    __shared__ __attribute__((aligned(16))) T vnew[D];
+    __shared__ float mw[4][HP], lw[4][HP];
+    static_assert(HP * OP * 4 <= 32 * VP, "partial output fits the wave's value image");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int h0 = g * HP;
+    const int t_lo = (int)blockIdx.y * WIN;
+    const int wlen = cap_full - t_lo < WIN ? cap_full - t_lo : WIN;
+    const int p0 = wv * 64;                                   // the wave's first window-local position
+    const int64_t pitch = (int64_t)G * D;
+    const T* kb = Kc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
+    const T* vb = Vc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
+    const float* mk = mask + (int64_t)b * cap_full + t_lo;
+    const T* row = QKV + (int64_t)b * ldq;
+    const int wrow = (int)widx[0] - t_lo;                     // window-local row written by this step
+    const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
+    const T* cs = table + pos[b] * D;
+
+    // every load of the block up front: rotary inputs first (they are consumed first), then keys, values, mask
+    u32 xq[4], cq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, hh = idx >> 6, p = idx & 63;
+        xq[k] = *reinterpret_cast<const u32*>(row + (int64_t)(h0 + hh) * D + 2 * p);
+        cq[k] = *reinterpret_cast<const u32*>(cs + 2 * p);
+    }
+    const u32 xk = *reinterpret_cast<const u32*>(row + (int64_t)(H + g) * D + 2 * (tid & 63));
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(row + (int64_t)(H + G + g) * D + 8 * (tid & 15));
+    u32x4 kf[4][4];                                           // [position tile][d chunk j]: d = 32 j + 8 q .. + 7 of row li
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int r = p0 + 16 * pt + li, rc = r < wlen ? r : wlen - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[pt][j] = *reinterpret_cast<const u32x4*>(kb + rc * pitch + 32 * j + 8 * q);
+    }
+    u32x4 vr[16];                                             // row 4 i + q of the wave, 16-byte chunk li
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = p0 + 4 * i + q, rc = r < wlen ? r : wlen - 1;
+        vr[i] = *reinterpret_cast<const u32x4*>(vb + rc * pitch + 8 * li);
+    }
+    float mr[4][4];                                           // mask of position 16 pt + 4 q + e (the C layout's rows)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = p0 + 16 * pt + 4 * q + e;
+            mr[pt][e] = mk[r < wlen ? r : wlen - 1];
+        }
+
+    // rotary: 16 heads x 64 pairs (4 per thread), the group's key pair (threads 0..63), the value row (threads 64..79)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, hh = idx >> 6, p = idx & 63;
+        float x0, x1, c0, c1, y0, y1;
+        unpack2<T>(xq[k], x0, x1);
+        unpack2<T>(cq[k], c0, c1);
+        rope_pair(x0, x1, c0, c1, y0, y1);
+        *reinterpret_cast<u32*>(qs + hh * QP + 4 * p) =
+            pack2<T>(Act<T>::round(y0) / sqrt_d, Act<T>::round(y1) / sqrt_d);
+    }
+    if (tid < 64) {
+        float x0, x1, c0, c1, y0, y1;
+        unpack2<T>(xk, x0, x1);
+        unpack2<T>(cq[0], c0, c1);                            // idx = tid: pair tid
+        rope_pair(x0, x1, c0, c1, y0, y1);
+        reinterpret_cast<u32*>(knew)[tid] = pack2<T>(y0, y1);
+    } else if (tid < 80) {
+        reinterpret_cast<u32x4*>(vnew)[tid - 64] = xv;
+    }
+    __syncthreads();
+    if (has_new && tid < 32) {                                // the cache row of this step (read back from LDS by nobody else)
+        const int64_t at = (((int64_t)b * cap_full + t_lo + wrow) * G + g) * D;
+        if (tid < 16) *reinterpret_cast<u32x4*>(Kc + at + 8 * tid) = reinterpret_cast<const u32x4*>(knew)[tid];
+        else *reinterpret_cast<u32x4*>(Vc + at + 8 * (tid - 16)) = reinterpret_cast<const u32x4*>(vnew)[tid - 16];
+    }
+
+    // S^T = K Q^T: lane (li, q) ends with scores of head li at positions 16 pt + 4 q + e
+    const int wl = has_new ? wrow - p0 : -1;                  // wave-local new row (outside [0, 64): not this wave's)
+    u32x4 qf[4], knf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qf[j] = *reinterpret_cast<const u32x4*>(qs + li * QP + 64 * j + 16 * q);
+        knf[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(knew) + 64 * j + 16 * q);
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const bool is_new = wl == 16 * pt + li;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = AttMma<T>::qk(is_new ? knf[j] : kf[pt][j], qf[j], acc);
+        s[pt] = acc;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = p0 + 16 * pt + 4 * q + e;
+            const float sv = r < wlen ? Act<T>::round(s[pt][e]) + mr[pt][e] : -INFINITY;
+            s[pt][e] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float lsum = 0.f;
+    u32x2v pf[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        float ev[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ev[e] = s[pt][e] == -INFINITY ? 0.f : __expf(s[pt][e] - mx);
+            lsum += ev[e];
+        }
+        pf[pt] = u32x2v{pack2<T>(ev[0], ev[1]), pack2<T>(ev[2], ev[3])};
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+
+    // O^T = V^T P^T, 32 value rows at a time through the wave's LDS image
+    unsigned char* img = vimg[wv];
+    const u32x4 vnf = reinterpret_cast<const u32x4*>(vnew)[li];
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = 32 * hf + 4 * i + q;               // wave-local row
+            *reinterpret_cast<u32x4*>(img + (4 * i + q) * VP + 16 * li) = rl == wl ? vnf : vr[8 * hf + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ptl = 0; ptl < 2; ++ptl)
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const unsigned char* p = img + (16 * ptl + 4 * q + (li >> 2)) * VP + 2 * (16 * dt + 4 * (li & 3));
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
+                o[dt] = AttMma<T>::pv(__builtin_bit_cast(u32x2v, a), pf[2 * hf + ptl], o[dt]);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // partial results of the wave: O[head li][d = 16 dt + 4 q + e], max and exp-sum per head
+    float* ow = reinterpret_cast<float*>(img);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(ow + li * OP + 16 * dt + 4 * q) = o[dt];
+    if (q == 0) {
+        mw[wv][li] = mx;
+        lw[wv][li] = lsum;
+    }
+    __syncthreads();
+    {
+        const int hh = tid >> 4, ch = tid & 15;               // head, 8-wide d chunk
+        const float m0 = mw[0][hh], m1 = mw[1][hh], m2 = mw[2][hh], m3 = mw[3][hh];
+        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float f[4] = {m0 == -INFINITY ? 0.f : __expf(m0 - m), m1 == -INFINITY ? 0.f : __expf(m1 - m),
+                            m2 == -INFINITY ? 0.f : __expf(m2 - m), m3 == -INFINITY ? 0.f : __expf(m3 - m)};
+        float l = 0.f, acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            l = __builtin_fmaf(lw[w][hh], f[w], l);
+            const float* src = reinterpret_cast<const float*>(vimg[w]) + hh * OP + 8 * ch;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[e] = __builtin_fmaf(a0[e], f[w], acc[e]);
+                acc[4 + e] = __builtin_fmaf(a1[e], f[w], acc[4 + e]);
+            }
+        }
+        const int64_t head = (int64_t)b * H + h0 + hh;
+        if (split_out) {
+            float* so = split_out + (head * gridDim.y + blockIdx.y) * (D + 2);
+            if (ch == 0) {
+                so[0] = m;
+                so[1] = l;
+            }
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) *reinterpret_cast<f32x2*>(so + 2 + 8 * ch + e) = f32x2{acc[e], acc[e + 1]};
+        } else {
+            const float inv = 1.0f / l;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = acc[e] * inv;
+            store8<T>(Out + head * D + 8 * ch, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out = sum_w o_w e^(m_w - m) / sum_w l_w e^(m_w - m): the windows of the split modes above, one block per head.
+// The windows are independent loads: thread = (window slice, d pair), 4 windows in flight per thread (a loop over
+// the windows with one load each was a chain of nwin global round trips: 15 us at 32 windows).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part, T* __restrict__ Out, int nwin) {
+    constexpr int HD = D / 2, NS = 256 / HD;                  // d pairs, window slices
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float red[4];
+    __shared__ float acc[NS][D + 1];
+    const float* p = part + (int64_t)blockIdx.x * nwin * (D + 2);
+    const int tid = threadIdx.x, ws = tid / HD, dd = tid - ws * HD;
+    float m = -INFINITY;
+    for (int w = tid; w < nwin; w += 256) m = fmaxf(m, p[(int64_t)w * (D + 2)]);
+    m = block_max_256(m, red);
+    float l = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll 4
+    for (int w = ws; w < nwin; w += NS) {
+        const float* rec = p + (int64_t)w * (D + 2);
+        const f32x2 ml = *reinterpret_cast<const f32x2*>(rec);
+        const f32x2 x = *reinterpret_cast<const f32x2*>(rec + 2 + 2 * dd);
+        const float f = ml[0] == -INFINITY ? 0.f : __expf(ml[0] - m);
+        l = __builtin_fmaf(ml[1], f, l);
+        o0 = __builtin_fmaf(x[0], f, o0);
+        o1 = __builtin_fmaf(x[1], f, o1);
+    }
+    acc[ws][2 * dd] = o0;
+    acc[ws][2 * dd + 1] = o1;
+    if (dd == 0) acc[ws][D] = l;
+    __syncthreads();
+    if (tid < D) {
+        float o = 0.f, lt = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            o += acc[s2][tid];
+            lt += acc[s2][D];
+        }
+        Act<T>::store(Out + (int64_t)blockIdx.x * D + tid, o / lt);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -612,6 +910,21 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
                             int64_t ldq, float* split_ws, hipStream_t st) {
     const float sq = sqrtf((float)D);
     const int nwin = split_ws ? (int)((capacity + kAttnWindow - 1) / kAttnWindow) : 1;
+    if constexpr (ROPE && sizeof(T) == 2) {
+        // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_ATTENTION_MFMA=0: per-head kernels)
+        const char* mfma_env = getenv("QLINEAR_ATTENTION_MFMA");
+        const bool one_window = capacity <= kAttnWindow;
+        if (D == 128 && H == 16 * G && ldq % 8 == 0 && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
+            dim3 gridg((unsigned)(B * G), (unsigned)(one_window ? 1 : nwin));
+            decode_attention_mfma_kernel<T><<<gridg, 256, 0, st>>>((const T*)Q, (T*)Kc, (T*)Vc, mask, (T*)Out, (int)H, (int)G,
+                                                                  (int)capacity, sq, (const T*)table, pos, widx, ldq,
+                                                                  one_window ? nullptr : split_ws);
+            const int rc = finish_launch();
+            if (rc != 0 || one_window) return rc;
+            attention_combine_kernel<T, 128><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);
+            return finish_launch();
+        }
+    }
     dim3 grid((unsigned)(B * H), (unsigned)nwin);
 #define QL_ATT(DD)                                                                                                  \
     {                                                                                                               \
@@ -622,7 +935,7 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
         if (split_ws) {                                                                                             \
             const int rc = finish_launch();                                                                         \
             if (rc != 0) return rc;                                                                                 \
-            attention_combine_kernel<T, DD><<<(unsigned)(B * H), DD, 0, st>>>(split_ws, (T*)Out, nwin);             \
+            attention_combine_kernel<T, DD><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);             \
         }                                                                                                           \
     }
     if (D == 128) QL_ATT(128)

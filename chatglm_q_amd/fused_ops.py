@@ -71,6 +71,7 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
     return out
 
 
+GROUP_ATTENTION = os.environ.get("QLINEAR_ATTENTION_MFMA", "1") != "0"
 SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "448"))   # cache capacity from which windows are split
 
 
@@ -87,7 +88,9 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     out = torch.empty((B, 1, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
     capacity = k_cache.shape[1]
     if split is None:
-        split = capacity >= SPLIT_ATTENTION_FROM
+        # 16 heads per key/value group (16-bit, D = 128): the group kernel takes one 256-position window per block
+        group_kernel = qkv.dtype != torch.float32 and d_head == 128 and n_head == 16 * n_groups and GROUP_ATTENTION
+        split = capacity > 256 if group_kernel else capacity >= SPLIT_ATTENTION_FROM
     with torch.cuda.device(qkv.device):
         ws_bytes = int(lib.qlinear_decode_attention_split_bytes(B, n_head, d_head, capacity)) if split else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes else None
