@@ -227,7 +227,9 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
 /* split_workspace (nullable, qlinear_decode_attention_split_bytes): long contexts - 256-position windows over
  * blockIdx.y leave (max, exp-sum, unnormalised output) there and a second launch combines them; the probabilities are
  * then not rounded to the activation dtype before P.V (same function within fp tolerance).  Without it one block per
- * (sequence, head) walks the whole cache with the reference's rounding points (capacity <= ~15 k). */
+ * (sequence, head) walks the whole cache with the reference's rounding points (capacity <= ~15 k).
+ * H == 16 G, D == 128, fp16 / bf16, ldqkv % 8 == 0: one block per (sequence, group, window) on the matrix cores
+ * (a single launch up to capacity 256, split_workspace needed above; QLINEAR_ATTENTION_MFMA=0 turns it off). */
 size_t qlinear_decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
