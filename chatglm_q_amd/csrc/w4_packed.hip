@@ -99,10 +99,15 @@ __device__ __forceinline__ int a_chunk_pos(int g, int j) { return 4 * g + (j ^ (
 
 template <typename T> struct Splice;
 template <> struct Splice<f16> {
-    static constexpr u32 kMagic = 0x64006400u, kMask = 0x00F000F0u, kOnes = 0x3C003C00u;
-    static constexpr float kOffset = 1152.0f, kUnit = 0.0625f;
-    // nibble pair i = positions (i, i + 4) of the word = k pair (2i, 2i+1); bring it to bits 4..7 / 20..23
-    static __device__ __forceinline__ u32 align(u32 w, int i) { return i == 0 ? (w << 4) : (i == 1 ? w : (w >> (4 * i - 4))); }
+    // 0x6400 | n = 1024 + n for a nibble at mantissa bits 0..3, 0x6400 | (n << 4) = 1024 + 16 n for one at bits 4..7:
+    // nibble pairs 0 and 1 of a word (bits 0..3 / 16..19 and 4..7 / 20..23) are spliced where they lie, pairs 2 and
+    // 3 after ONE shift by 8 (one shift per word instead of three to bring every pair to the same bits).  The even
+    // pairs feed the `e` chain (unit weight), the odd pairs the `o` chain (16 x): sum (n - 8) a =
+    //   e + o / 16 - (1032 sum_e a + 72 sum_o a)
+    static constexpr u32 kMagic = 0x64006400u, kMask = 0x000F000Fu, kMaskOdd = 0x00F000F0u, kOnes = 0x3C003C00u;
+    static constexpr bool kSplitChains = true;
+    static __device__ __forceinline__ float combine(float e, float o) { return __builtin_fmaf(o, 0.0625f, e); }
+    static __device__ __forceinline__ float offset(float ae, float ao) { return __builtin_fmaf(1032.0f, ae, 72.0f * ao); }
     static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
         return __builtin_amdgcn_fdot2(as_h2(x), as_h2(a), acc, false);
     }
@@ -110,10 +115,12 @@ template <> struct Splice<f16> {
     static __device__ __forceinline__ float hi(u32 s) { return (float)as_h2(s).y; }
 };
 template <> struct Splice<__bf16> {
+    // 0x4300 | n = 128 + n (7 mantissa bits: only the low nibble position splices); every pair is shifted to bits 0..3
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    static constexpr u32 kMagic = 0x43004300u, kMask = 0x000F000Fu, kOnes = 0x3F803F80u;
-    static constexpr float kOffset = 136.0f, kUnit = 1.0f;
-    static __device__ __forceinline__ u32 align(u32 w, int i) { return w >> (4 * i); }
+    static constexpr u32 kMagic = 0x43004300u, kMask = 0x000F000Fu, kMaskOdd = 0x000F000Fu, kOnes = 0x3F803F80u;
+    static constexpr bool kSplitChains = false;
+    static __device__ __forceinline__ float combine(float e, float o) { return e + o; }
+    static __device__ __forceinline__ float offset(float ae, float ao) { return 136.0f * (ae + ao); }
     static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x), __builtin_bit_cast(bf2, a), acc, false);
     }
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 
     // splice constants live in registers so that (w & mask) | magic is ONE v_and_or_b32
     // (two 32-bit literals cannot be encoded in one VOP3 instruction)
-    u32 k_mask, k_magic;
-    asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask) : "i"(STRICT ? 0x000F000Fu : SP::kMask));
+    u32 k_mask, k_mask_odd, k_magic;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask) : "i"(SP::kMask));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask_odd) : "i"(SP::kMaskOdd));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(SP::kMagic));
 
     const T* arow[MB];
@@ -348,10 +356,9 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                     e = SP::dot(SP::kOnes, av[m][i], e);
                     o = SP::dot(SP::kOnes, av[m][i + 1], o);
                 }
-                corr[m] = SP::kOffset * (e + o);
+                corr[m] = SP::offset(e, o);
             }
-            const float sc[4] = {SP::lo(sv[0]) * SP::kUnit, SP::hi(sv[0]) * SP::kUnit, SP::lo(sv[1]) * SP::kUnit,
-                                 SP::hi(sv[1]) * SP::kUnit};
+            const float sc[4] = {SP::lo(sv[0]), SP::hi(sv[0]), SP::lo(sv[1]), SP::hi(sv[1])};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float e[MB], o[MB];                           // two independent dot chains per row
@@ -360,10 +367,11 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const u32 w = tl.w[c][j];
-                    const u32 x0 = (SP::align(w, 0) & k_mask) | k_magic;
-                    const u32 x1 = (SP::align(w, 1) & k_mask) | k_magic;
-                    const u32 x2 = (SP::align(w, 2) & k_mask) | k_magic;
-                    const u32 x3 = (SP::align(w, 3) & k_mask) | k_magic;
+                    const u32 wh = w >> 8;
+                    const u32 x0 = (w & k_mask) | k_magic;
+                    const u32 x1 = ((SP::kSplitChains ? w : (w >> 4)) & k_mask_odd) | k_magic;
+                    const u32 x2 = (wh & k_mask) | k_magic;
+                    const u32 x3 = ((SP::kSplitChains ? wh : (w >> 12)) & k_mask_odd) | k_magic;
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
                         e[m] = SP::dot(x0, av[m][4 * j + 0], e[m]);
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                     }
                 }
 #pragma unroll
-                for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(sc[c], (e[m] + o[m]) - corr[m], acc[m][c]);
+                for (int m = 0; m < MB; ++m) acc[m][c] = __builtin_fmaf(sc[c], SP::combine(e[m], o[m]) - corr[m], acc[m][c]);
             }
         }
     };

@@ -61,6 +61,49 @@ __global__ __launch_bounds__(256) void stride_read_kernel(const u32x4* __restric
     if (lane == 0) out[wave] = x;
 }
 
+// the one-row GEMV's load pattern without any math: block = 4/KS column quads x KS K-slices, a wave issues ITERS tiles
+// of (4 columns x 1 KiB + 512 B of scales); STAGE: also stage K halves of x into LDS first (as the GEMV does)
+template <int KS, bool STAGE, bool SCALES>
+__global__ __launch_bounds__(256) void gemv_pattern_kernel(const u32x4* __restrict__ Wt, const uint2* __restrict__ Sp,
+                                                           const u32x4* __restrict__ X, uint32_t* __restrict__ out, int G,
+                                                           int quads, int xchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave % KS, QW = 4 / KS;
+    int t = blockIdx.x * QW + wave / KS;
+    if (t >= quads) t = 0;
+    const int gs = (G + KS - 1) / KS, g0 = ks * gs, g1 = min(G, g0 + gs);
+    const int iters = (g1 - g0 + 63) >> 6;
+    uint32_t x = 0;
+    if (STAGE) {
+        for (int c = tid; c < xchunks; c += 256) reinterpret_cast<u32x4*>(smem)[c] = X[c];
+    }
+    const u32x4* wb = Wt + (size_t)t * 4 * G;
+    const uint2* sb = Sp + (size_t)t * G;
+    for (int it = 0; it < iters; it += 2) {
+        u32x4 v[8];
+        uint2 sc[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int g = g0 + (it + u) * 64 + lane;
+            if (g >= g1 || it + u >= iters) g = G - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u * 4 + c] = __builtin_nontemporal_load(wb + (size_t)c * G + g);
+            if (SCALES) sc[u] = sb[g];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+        x ^= sc[0].x ^ sc[0].y ^ sc[1].x ^ sc[1].y;
+    }
+    if (STAGE) {
+        __syncthreads();
+        x ^= reinterpret_cast<uint32_t*>(smem)[tid];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (lane == 0) out[blockIdx.x * 4 + wave] = x;
+}
+
 __global__ void empty_kernel() {}
 
 struct Timer {
@@ -135,6 +178,37 @@ int main(int argc, char** argv) {
         us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
         char nm[64]; snprintf(nm, sizeof nm, "w4 packed gemv QL_VARIANT=%s", getenv("QL_VARIANT") ? getenv("QL_VARIANT") : "0");
         report(nm, us, alg);
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "pattern")) {
+        // bytes the GEMV reads: part 1 of the derived layout (weights + scales)
+        const size_t wbytes = (size_t)N * G * 16, sbytes = (size_t)N * G * 2;
+        const int quads = N / 4;
+        const int lds = K * 2;
+        auto run_pat = [&](auto kern, int ks, int ldsb, const char* name) {
+            const int blocks = (quads + 4 / ks - 1) / (4 / ks);
+            double t = T.run(STEPS, [&](int i) {
+                kern<<<blocks, 256, ldsb, T.st>>>((const u32x4*)pk[i % SETS], (const uint2*)((const char*)pk[i % SETS] + wbytes),
+                                                  (const u32x4*)A, out, G, quads, K / 8);
+            });
+            report(name, t, (double)(wbytes + sbytes));
+        };
+        {
+            const size_t n16 = (wbytes + sbytes) / 16;
+            const int waves = (int)((n16 + 9 * 64 - 1) / (9 * 64));
+            us = T.run(STEPS, [&](int i) { read_kernel<9, true><<<(waves + 3) / 4, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], out, n16); });
+            report("pure read nt of part 1, 9x16B/thread", us, (double)(wbytes + sbytes));
+        }
+        run_pat(gemv_pattern_kernel<1, false, false>, 1, 0, "pattern KS=1 weights only");
+        run_pat(gemv_pattern_kernel<2, false, false>, 2, 0, "pattern KS=2 weights only");
+        run_pat(gemv_pattern_kernel<4, false, false>, 4, 0, "pattern KS=4 weights only");
+        run_pat(gemv_pattern_kernel<4, false, true>, 4, 0, "pattern KS=4 weights + scales");
+        run_pat(gemv_pattern_kernel<4, false, true>, 4, lds, "pattern KS=4 weights + scales, LDS allocated");
+        run_pat(gemv_pattern_kernel<4, true, true>, 4, lds, "pattern KS=4 weights + scales + x staging");
+        run_pat(gemv_pattern_kernel<2, true, true>, 2, lds, "pattern KS=2 weights + scales + x staging");
+        run_pat(gemv_pattern_kernel<1, true, true>, 1, lds, "pattern KS=1 weights + scales + x staging");
+        us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
+        report("w4 packed gemv (rotating)", us, alg);
         return 0;
     }
     us = T.run(STEPS, [&](int) { empty_kernel<<<1, 64, 0, T.st>>>(); });
