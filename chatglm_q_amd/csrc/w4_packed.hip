@@ -139,6 +139,7 @@ struct PackedTile16 {
 // kernel to attribute time.  Only VAR == 0 is instantiated unless QL_DEV_VARIANTS is defined.
 //   1: no math (loaded words are XOR-folded), 2: math with a constant activation (no LDS reads),
 //   4: as 2 and no activation staging at all (no staging loads, no LDS writes, no barrier)
+//   5: as 1 and no activation staging at all (weight / scale loads, reduction and epilogue only)
 // KS: the block's 4 waves cover 4/KS column quads x KS slices of K (combined through LDS at the end):
 // shapes with few columns but a long K (w_out: 13696 -> 4096) get 4x the workgroups and 4x the loads
 // in flight per column instead of one wave walking 7 tiles in sequence.
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     // (1) activation staging loads first: oldest in the VM queue
     u32x4 areg[A_LDS ? ACH : 1];
     u32x4 xreg[PRO != PRO_NONE ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // prologue operands
-    if constexpr (A_LDS && VAR != 4) {
+    if constexpr (A_LDS && VAR != 4 && VAR != 5) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             // unconditional (clamped) load: a load under a per-element condition makes hipcc branch
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             areg[i] = pack8<T>(hv[i]);
         }
     }
-    if constexpr (A_LDS && VAR != 4) {
+    if constexpr (A_LDS && VAR != 4 && VAR != 5) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * 256;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 x;
-                if constexpr (VAR == 2 || VAR == 4)
+                if constexpr (VAR == 2 || VAR == 4 || VAR == 5)
                     x = u32x4{SP::kOnes, SP::kOnes, SP::kOnes, SP::kOnes};
                 else if constexpr (A_LDS)
                     x = *reinterpret_cast<const u32x4*>(smem + ((int64_t)m * cpr + a_chunk_pos(gc, j)) * 16);
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                 av[m][4 * j + 3] = x[3];
             }
         const u32x2 sv = g < g_end ? tl.s : u32x2{0u, 0u};    // out-of-range lanes contribute 0
-        if constexpr (VAR == 1) {
+        if constexpr (VAR == 1 || VAR == 5) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 acc[0][c] += u32_as_f32((tl.w[c][0] ^ tl.w[c][1] ^ tl.w[c][2] ^ tl.w[c][3] ^ sv[0] ^ sv[1] ^ av[0][c]) &
@@ -641,6 +642,10 @@ static int launch_16(const PackedArgs& p) {
         }
         if (dev_variant() == 4) {
             w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 4><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
+            return finish_launch();
+        }
+        if (dev_variant() == 5) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 5><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N, p.K, (int)G, p.lda, p.ldc, Prologue{});
             return finish_launch();
         }
     }

@@ -1,0 +1,66 @@
+"""Developer tool: condense the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof) into profiles/:
+per-shape kernel-trace durations of the one-row int4g32 kernel, the PMC traffic of the headline kernel (gfx950
+correction of MI355X_MICROARCH.md: read bytes = 2 x FETCH_SIZE x 1024), and copies of the kernel-stats tables."""
+import csv, json, os, shutil, statistics, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof")
+dst = os.path.join(root, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+csv.field_size_limit(1 << 30)
+
+shapes = {131072: "int4g32 1x4096->4096 (headline; 512 blocks x 256 threads, KS=2)", 147456: "qkv_proj 4096->4608 (KS=2)",
+          438272: "w_in 4096->27392 (KS=1)", 262144: "w_out 13696->4096 (KS=4)", 1040384: "lm_head 4096->65024 (KS=1)"}
+dur = {}
+with open(os.path.join(src, "bench", "bench_kernel_trace.csv")) as f:
+    for r in csv.DictReader(f):
+        if "w4_packed_gemv_16_kernel" not in r["Kernel_Name"]:
+            continue
+        g = int(r["Grid_Size_X"])
+        if g in shapes:
+            dur.setdefault(shapes[g], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+trace = {}
+for name, d in dur.items():
+    d.sort()
+    trace[name] = {"launches": len(d), "avg_ns": round(statistics.fmean(d)), "median_ns": statistics.median(d),
+                   "p10_ns": d[len(d) // 10], "p90_ns": d[len(d) * 9 // 10]}
+
+def pmc(counter):
+    vals = []
+    with open(os.path.join(src, f"pmc_{counter}", "pmc_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if "w4_packed_gemv_16_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == 131072 and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+
+fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+fetch_kb, write_kb = statistics.fmean(fetch), statistics.fmean(write)
+alg = 4096 * 4096 // 2 + 128 * 4096 * 2 + 4096 * 2 + 4096 * 2
+summary = {
+    "kernel_trace_durations_under_rocprofv3": trace,
+    "pmc": {
+        "kernel": "w4_packed_gemv_16_kernel<f16, MB=1, ACH=2, KS=2> on int4g32 1x4096->4096",
+        "FETCH_SIZE_KB_per_launch_raw": round(fetch_kb, 1), "WRITE_SIZE_KB_per_launch_raw": round(write_kb, 1),
+        "launches_sampled": len(fetch),
+        "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams (MI355X_MICROARCH.md, HBM): "
+                      "read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE used as reported",
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "algorithmic_bytes_per_launch": alg,
+        "commands": ["tools/profile_round.sh (rocprofv3 --kernel-trace --stats of bench.py; separate --pmc FETCH_SIZE and "
+                     "--pmc WRITE_SIZE passes of bench.py --steps 288 --warmup 72 --no-extras --no-cpu-baseline --launch eager; "
+                     "kernel traces of tools/profile_decode.py 64 and tools/profile_prefill.py)",
+                     "tools/make_profile_summary.py"],
+    },
+}
+with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+for a, b in (("bench/bench_kernel_stats.csv", "bench_kernel_stats.csv"), ("decode/decode_kernel_stats.csv", "decode_step_kernel_stats.csv"),
+             ("prefill/prefill_kernel_stats.csv", "prefill_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
+for a, b in (("bench_unprofiled.json", "bench_unprofiled.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json")):
+    line = open(os.path.join(src, a)).read().strip().split("\n")[-1]
+    with open(os.path.join(dst, f"{tag}_{b}"), "w") as f:
+        json.dump(json.loads(line), f, indent=1)
+shutil.copy(os.path.join(dst, f"{tag}_bench_unprofiled.json"), os.path.join(dst, f"{tag}_bench_latest.json"))
+print(json.dumps(summary["kernel_trace_durations_under_rocprofv3"], indent=1))
+print(json.dumps({k: v for k, v in summary["pmc"].items() if k != "commands"}, indent=1))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Developer tool: the rocprofv3 runs behind profiles/ (run through gpurun from the repo root; outputs land in gpurun_out/).
+#   kernel trace + stats of the default bench, PMC passes (FETCH_SIZE, WRITE_SIZE separately) of the headline kernel,
+#   kernel trace of a graph-replayed decode and of a chunked prefill.
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 python $ROOT/bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_rocprof.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --steps 288 --warmup 72 --no-extras --no-cpu-baseline --launch eager > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o decode -- python $ROOT/tools/profile_decode.py 64 > $OUT/decode.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefill -o prefill -- python $ROOT/tools/profile_prefill.py > $OUT/prefill.log 2>&1
+# keep only what fits the 64 MiB return budget: stats and (for the PMC / bench runs) the counter / kernel trace tables
+find $OUT -name "*_agent_info.csv" -delete
+find $OUT/decode $OUT/prefill -name "*kernel_trace.csv" -delete
+ls -la $OUT $OUT/*/* 2>/dev/null | head -60
+du -sh $OUT
