@@ -210,7 +210,8 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
 @pytest.mark.parametrize("geom", [(1, 32, 2, 128, 256, 130), (2, 32, 2, 128, 192, 70), (1, 16, 1, 128, 40, 39),
                                   (1, 32, 2, 128, 2048, 1500), (2, 16, 1, 128, 320, 319), (1, 32, 2, 128, 8064, 7000),
                                   (3, 16, 1, 128, 1000, 256), (1, 32, 2, 128, 520, 511), (1, 32, 2, 128, 64, 0),
-                                  (2, 48, 3, 128, 516, 300)])
+                                  (2, 48, 3, 128, 516, 300), (1, 32, 2, 128, 37, 36), (1, 16, 1, 128, 257, 256),
+                                  (2, 32, 2, 128, 300, 150), (1, 32, 2, 128, 255, 0), (1, 16, 1, 128, 1, 0)])
 def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatch):
     """16 heads per key/value group: the group kernel (one block per group and 256-position window, Q.K and P.V as
     16x16 MFMA tiles, values transposed by ds_read_b64_tr_b16) against the per-head kernels: same
