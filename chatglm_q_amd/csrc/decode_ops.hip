@@ -471,13 +471,15 @@ __device__ __forceinline__ void unpack2(u32 w, float& a, float& b) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __restrict__ QKV, T* Kc, T* Vc,
-                                                                    const float* __restrict__ mask, T* __restrict__ Out,
-                                                                    int H, int G, int cap_full, float sqrt_d,
+__global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
+                                                                    const int64_t* __restrict__ widx, T* Kc, T* Vc, int H,
+                                                                    int G, int cap_full, int ldq32,
                                                                     const T* __restrict__ table,
-                                                                    const int64_t* __restrict__ pos,
-                                                                    const int64_t* __restrict__ widx, int64_t ldq,
-                                                                    float* __restrict__ split_out) {
+                                                                    const float* __restrict__ mask, float sqrt_d,
+                                                                    T* __restrict__ Out, float* __restrict__ split_out) {
+    // Argument order: the leading 14 dwords are preloaded into SGPRs at wave launch (Makefile); they are what the
+    // query / key / value loads need, so those are in flight before the scalar loads of the rest (and of pos / widx,
+    // which live in device memory) have returned.  The rotary table row depends on pos: it is requested last.
     static_assert(sizeof(T) == 2, "16-bit dtypes");
     constexpr int D = 128, HP = 16, WIN = 256;
     constexpr int VP = 288;                                   // bytes per value row in LDS: rows 8 banks apart (tr reads conflict-free)
@@ -498,19 +500,15 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     const int64_t pitch = (int64_t)G * D;
     const T* kb = Kc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
     const T* vb = Vc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
-    const float* mk = mask + (int64_t)b * cap_full + t_lo;
-    const T* row = QKV + (int64_t)b * ldq;
-    const int wrow = (int)widx[0] - t_lo;                     // window-local row written by this step
-    const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
-    const T* cs = table + pos[b] * D;
+    const T* row = QKV + (int64_t)b * ldq32;
 
-    // every load of the block up front: rotary inputs first (they are consumed first), then keys, values, mask
+    // every load of the block up front: this step's q / k / v (just written: cache-hot), then keys, values, mask and
+    // - once pos has arrived - the rotary table row
     u32 xq[4], cq[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = tid + 256 * k, hh = idx >> 6, p = idx & 63;
         xq[k] = *reinterpret_cast<const u32*>(row + (int64_t)(h0 + hh) * D + 2 * p);
-        cq[k] = *reinterpret_cast<const u32*>(cs + 2 * p);
     }
     const u32 xk = *reinterpret_cast<const u32*>(row + (int64_t)(H + g) * D + 2 * (tid & 63));
     const u32x4 xv = *reinterpret_cast<const u32x4*>(row + (int64_t)(H + G + g) * D + 8 * (tid & 15));
@@ -527,6 +525,7 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
         const int r = p0 + 4 * i + q, rc = r < wlen ? r : wlen - 1;
         vr[i] = *reinterpret_cast<const u32x4*>(vb + rc * pitch + 8 * li);
     }
+    const float* mk = mask + (int64_t)b * cap_full + t_lo;
     float mr[4][4];                                           // mask of position 16 pt + 4 q + e (the C layout's rows)
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
@@ -535,6 +534,11 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
             const int r = p0 + 16 * pt + 4 * q + e;
             mr[pt][e] = mk[r < wlen ? r : wlen - 1];
         }
+    const int wrow = (int)widx[0] - t_lo;                     // window-local row written by this step
+    const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
+    const T* cs = table + pos[b] * D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cq[k] = *reinterpret_cast<const u32*>(cs + 2 * ((tid + 256 * k) & 63));
 
     // rotary: 16 heads x 64 pairs (4 per thread), the group's key pair (threads 0..63), the value row (threads 64..79)
 #pragma unroll
@@ -914,10 +918,10 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
         // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_ATTENTION_MFMA=0: per-head kernels)
         const char* mfma_env = getenv("QLINEAR_ATTENTION_MFMA");
         const bool one_window = capacity <= kAttnWindow;
-        if (D == 128 && H == 16 * G && ldq % 8 == 0 && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
+        if (D == 128 && H == 16 * G && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
             dim3 gridg((unsigned)(B * G), (unsigned)(one_window ? 1 : nwin));
-            decode_attention_mfma_kernel<T><<<gridg, 256, 0, st>>>((const T*)Q, (T*)Kc, (T*)Vc, mask, (T*)Out, (int)H, (int)G,
-                                                                  (int)capacity, sq, (const T*)table, pos, widx, ldq,
+            decode_attention_mfma_kernel<T><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
+                                                                  (int)capacity, (int)ldq, (const T*)table, mask, sq, (T*)Out,
                                                                   one_window ? nullptr : split_ws);
             const int rc = finish_launch();
             if (rc != 0 || one_window) return rc;

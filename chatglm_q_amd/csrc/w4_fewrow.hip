@@ -21,9 +21,10 @@ namespace ql {
 
 template <typename T, int KW, int NT, int MT>
 __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wm,
-                                                            const T* __restrict__ Sm, const T* __restrict__ bias,
-                                                            T* __restrict__ C, int M, int N, int K, int G, int64_t lda,
-                                                            int64_t ldc, float* __restrict__ part, int per) {
+                                                            const T* __restrict__ Sm, int M, int N, int K, int G, int64_t lda,
+                                                            int per, const T* __restrict__ bias, T* __restrict__ C,
+                                                            int64_t ldc, float* __restrict__ part) {
+    // (argument order: the leading 14 dwords - what the first loads need - are preloaded into SGPRs at wave launch)
     typedef Mma<T> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // KW x 2 x 4 KB A tiles; reused for the reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,8 +253,8 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
     constexpr size_t lds = (size_t)KW * 8192 * MT;
     static_assert((KW - 1) * MT * NT * 16 * 64 * 4 <= KW * 8192 * MT, "reduction scratch fits in the A buffers");
-    w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G, lda, ldc,
-                                                            part, plan.per);
+    w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
+                                                            (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;

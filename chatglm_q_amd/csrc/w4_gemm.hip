@@ -33,10 +33,10 @@ namespace ql {
 
 template <typename T, int MT, int NT, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
-                                                                 const T* __restrict__ Sp, const T* __restrict__ bias,
-                                                                 T* __restrict__ C, int M, int N, int K, int G,
-                                                                 int64_t lda, int64_t ldc, float* __restrict__ part,
-                                                                 int per, int nbx) {
+                                                                 const T* __restrict__ Sp, int M, int N, int K, int G,
+                                                                 int64_t lda, int per, int nbx, const T* __restrict__ bias,
+                                                                 T* __restrict__ C, int64_t ldc, float* __restrict__ part) {
+    // (argument order: the leading 14 dwords - what the first loads need - are preloaded into SGPRs at wave launch)
     constexpr int BM = 32 * MT;                // rows per block
     constexpr int WN = 32 * NT;                // columns per wave
     constexpr int NTHR = NW * 64;
@@ -267,9 +267,8 @@ static int launch_gemm(const void* A, const void* packed, const void* bias, void
     constexpr int BN = NW * 32 * NT;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
-    w4_packed_gemm_kernel<T, MT, NT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, (const T*)bias, (T*)C, M, N, K, (int)G,
-                                                                      lda, ldc, part, plan.per,
-        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5));
+    w4_packed_gemm_kernel<T, MT, NT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
+        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5), (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;

@@ -104,9 +104,11 @@ template <> struct W8Mma<__bf16> {
 // through LDS (128 bytes per block) and are read back as broadcast fragments.
 template <typename T, int MT, int NW, int DEPTH, bool SK = false, bool TILED = false>
 __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ A, const int8_t* __restrict__ W,
-                                                      const T* __restrict__ S, const T* __restrict__ bias, T* __restrict__ C,
-                                                      int M, int N, int K, int64_t ldw, int64_t lda, int64_t ldc,
-                                                      float* __restrict__ part, int per, int nbx) {
+                                                      const T* __restrict__ S, int M, int N, int K, int ldw32, int lda32,
+                                                      int per, int nbx, const T* __restrict__ bias, T* __restrict__ C,
+                                                      int64_t ldc, float* __restrict__ part) {
+    // (argument order: the leading 14 dwords - what the first loads need - are preloaded into SGPRs at wave launch)
+    const int64_t ldw = ldw32, lda = lda32;
     constexpr int BM = 32 * MT;
     constexpr int NTHR = NW * 64;
     constexpr int CH = (BM * 8 + NTHR - 1) / NTHR;   // 16-byte A chunks staged per thread per K step
@@ -286,13 +288,13 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
 template <typename T, int MT, int NW, bool SK = false, bool TILED = false>
 static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int M, int N, int K,
                           int64_t ldw, int64_t lda, int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
+    if (ldw > 0x7fffffff || lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;     // strides travel as 32 bits
     float* part = plan.ksplit > 1 ? ws : nullptr;
     constexpr int BN = NW * 32;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
-    w8_gemm_kernel<T, MT, NW, 3, SK, TILED><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, M, N, K, ldw, lda,
-                                                           ldc, part, plan.per,
-        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K));
+    w8_gemm_kernel<T, MT, NW, 3, SK, TILED><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, M, N, K, (int)ldw, (int)lda, plan.per,
+        xcd_order(nbx, nby, (double)M * K * 2, (double)N * K), (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
@@ -397,9 +399,10 @@ int w8_tile(const int8_t* W, int8_t* Wm, int64_t N, int64_t K, int64_t ldw, hipS
 // ---------------------------------------------------------------------------------------------
 template <typename T, int KW>
 __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict__ A, const int8_t* __restrict__ Wm,
-                                                            const T* __restrict__ S, const T* __restrict__ bias,
-                                                            T* __restrict__ C, int M, int N, int K, int64_t lda, int64_t ldc,
-                                                            float* __restrict__ part, int per) {
+                                                            const T* __restrict__ S, int M, int N, int K, int64_t lda, int per,
+                                                            const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                            float* __restrict__ part) {
+    // (argument order: the leading 14 dwords - what the first loads need - are preloaded into SGPRs at wave launch)
     typedef W8Mma<T> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // KW x 2 x 4 KB A tiles; reused for the reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -545,8 +548,8 @@ static int launch_w8_fewrow(const void* A, const int8_t* Wm, const void* S, cons
     const W8FewRowPlan plan = w8_fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)plan.ksplit);
-    w8_fewrow_kernel<T, KW><<<grid, KW * 64, (size_t)KW * 8192, st>>>((const T*)A, Wm, (const T*)S, (const T*)bias, (T*)C, M, N, K,
-                                                                      lda, ldc, part, plan.per);
+    w8_fewrow_kernel<T, KW><<<grid, KW * 64, (size_t)KW * 8192, st>>>((const T*)A, Wm, (const T*)S, M, N, K, lda, plan.per,
+                                                                      (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;

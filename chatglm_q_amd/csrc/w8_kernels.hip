@@ -97,9 +97,14 @@ __device__ __forceinline__ u32x4 pair_even_odd(u32x4 x) {
 // w4_packed.hip's fused decode GEMV (same rounding sequence).
 template <int MB, int ACH, int KS, bool STRICT, int PRO = PRO_NONE>   // ACH: 16-byte activation pieces staged per thread; 0 = activations from global
 __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict__ A, const int8_t* __restrict__ W,
-                                                          const f16* __restrict__ S, const f16* __restrict__ bias,
-                                                          f16* __restrict__ C, int M, int N, int K, int64_t ldw,
-                                                          int64_t lda, int64_t ldc, Prologue pro = Prologue{}) {
+                                                          const void* pro_delta, const void* pro_ln_weight, int N, int K,
+                                                          int M, int ldw32, int lda32, const f16* __restrict__ S,
+                                                          const f16* __restrict__ bias, f16* __restrict__ C, int64_t ldc,
+                                                          void* pro_hout, float pro_eps, int pro_gate) {
+    // (argument order: the leading 14 dwords - all that the first loads need - are preloaded into SGPRs at wave
+    // launch, see w4_packed_gemv_16_kernel)
+    const int64_t ldw = ldw32, lda = lda32;
+    const Prologue pro{pro_delta, pro_ln_weight, pro_hout, pro_eps, pro_gate};
     static_assert(PRO == PRO_NONE || (PRO == PRO_ADDNORM && MB == 1 && ACH > 0), "prologue: one LDS-staged row");
     constexpr bool A_LDS = ACH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -524,10 +529,12 @@ __global__ __launch_bounds__(256) void act_quant_rowwise_kernel(const T* __restr
 //   Accumulator map: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
 // =============================================================================================
 template <typename T, int MT, int DEPTH>
-__global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict__ Aq, const float* __restrict__ a_scale,
-                                                        const int8_t* __restrict__ W, const T* __restrict__ S,
-                                                        const T* __restrict__ bias, T* __restrict__ C, int M, int N,
-                                                        int K, int64_t ldc, int* __restrict__ part, int per) {
+__global__ __launch_bounds__(256) void w8a8_mfma_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ W, int M,
+                                                        int N, int K, int per, const float* __restrict__ a_scale,
+                                                        const T* __restrict__ S, const T* __restrict__ bias,
+                                                        T* __restrict__ C, int64_t ldc, int* __restrict__ part) {
+    // (argument order: the operands of the first loads lead - preloaded into SGPRs at wave launch; scales, bias and
+    // the output are needed in the epilogue only)
     constexpr int BM = 32 * MT;
     constexpr int ACH = BM * 8 / 256;          // 16-byte A chunks staged per thread per K step
     constexpr int WCH = 4;                     // 128 rows x 8 chunks / 256 threads
@@ -743,8 +750,10 @@ static int launch_w8_gemv_f16(const W8Args& p) {
     dim3 grid((unsigned)((quads + QW - 1) / QW), (unsigned)((p.M + MB - 1) / MB));
     const size_t lds = (ACH > 0 ? (((size_t)MB * (p.K & ~15) * sizeof(f16) + 15) & ~(size_t)15) : 0) +
                        (KS > 1 ? (size_t)4 * MB * 4 * sizeof(float) : 0);
-    w8_gemv_f16_kernel<MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S, (const f16*)p.bias,
-                                                          (f16*)p.C, p.M, p.N, p.K, p.ldw, p.lda, p.ldc);
+    if (p.ldw > 0x7fffffff || p.lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;   // strides travel as 32 bits
+    w8_gemv_f16_kernel<MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, nullptr, nullptr, p.N, p.K, p.M, (int)p.ldw,
+                                                          (int)p.lda, (const f16*)p.S, (const f16*)p.bias, (f16*)p.C, p.ldc,
+                                                          nullptr, 0.f, 0);
     return finish_launch();
 }
 
@@ -755,9 +764,11 @@ static int launch_w8_gemv_fused(const W8Args& p, const Prologue& pro) {
     dim3 grid((unsigned)((quads + QW - 1) / QW), 1);
     // staged row, K-slice sums, the four per-wave partial sums of squares
     const size_t lds = (((size_t)(p.K & ~15) * sizeof(f16) + 15) & ~(size_t)15) + (size_t)4 * 4 * sizeof(float) + 4 * sizeof(float);
-    w8_gemv_f16_kernel<1, ACH, KS, false, PRO_ADDNORM><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, (const f16*)p.S,
-                                                                                (const f16*)p.bias, (f16*)p.C, 1, p.N, p.K, p.ldw,
-                                                                                p.lda, p.ldc, pro);
+    if (p.ldw > 0x7fffffff || p.lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;
+    w8_gemv_f16_kernel<1, ACH, KS, false, PRO_ADDNORM><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, pro.delta, pro.ln_weight, p.N,
+                                                                                p.K, 1, (int)p.ldw, (int)p.lda, (const f16*)p.S,
+                                                                                (const f16*)p.bias, (f16*)p.C, p.ldc, pro.hout,
+                                                                                pro.eps, pro.gate_epilogue);
     return finish_launch();
 }
 
@@ -856,11 +867,11 @@ static int launch_w8a8_mt(const int8_t* Aq, const float* a_scale, const int8_t* 
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)), (unsigned)plan.ksplit);
     static const int forced_depth = [] { const char* e = getenv("QLINEAR_W8A8_DEPTH"); return e ? atoi(e) : 0; }();
     if (forced_depth ? forced_depth == 4 : (int64_t)grid.x * grid.y * grid.z <= 256)
-        w8a8_mfma_kernel<T, MT, 4><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
-                                                         (int)N, (int)K, ldc, part, plan.per);
+        w8a8_mfma_kernel<T, MT, 4><<<grid, 256, 0, st>>>(Aq, W, (int)M, (int)N, (int)K, plan.per, a_scale, (const T*)S,
+                                                         (const T*)bias, (T*)C, ldc, part);
     else
-        w8a8_mfma_kernel<T, MT, 2><<<grid, 256, 0, st>>>(Aq, a_scale, W, (const T*)S, (const T*)bias, (T*)C, (int)M,
-                                                         (int)N, (int)K, ldc, part, plan.per);
+        w8a8_mfma_kernel<T, MT, 2><<<grid, 256, 0, st>>>(Aq, W, (int)M, (int)N, (int)K, plan.per, a_scale, (const T*)S,
+                                                         (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = M * N;
