@@ -470,33 +470,40 @@ __device__ __forceinline__ void unpack2(u32 w, float& a, float& b) {
     b = (float)y;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
-                                                                    const int64_t* __restrict__ widx, T* Kc, T* Vc, int H,
-                                                                    int G, int cap_full, int ldq32,
-                                                                    const T* __restrict__ table,
-                                                                    const float* __restrict__ mask, float sqrt_d,
-                                                                    T* __restrict__ Out, float* __restrict__ split_out) {
+template <typename T, int NWV>
+__global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
+                                                                         const int64_t* __restrict__ widx, T* Kc, T* Vc,
+                                                                         int H, int G, int cap_full, int ldq32,
+                                                                         const T* __restrict__ table,
+                                                                         const float* __restrict__ mask, float sqrt_d,
+                                                                         T* __restrict__ Out, float* __restrict__ split_out) {
     // Argument order: the leading 14 dwords are preloaded into SGPRs at wave launch (Makefile); they are what the
     // query / key / value loads need, so those are in flight before the scalar loads of the rest (and of pos / widx,
     // which live in device memory) have returned.  The rotary table row depends on pos: it is requested last.
+    // NWV waves share the 256-position window: 64 (4 waves) or 32 (8 waves: half the dependent chain per wave)
+    // positions each.
     static_assert(sizeof(T) == 2, "16-bit dtypes");
-    constexpr int D = 128, HP = 16, WIN = 256;
+    static_assert(NWV == 4 || NWV == 8, "waves per block");
+    constexpr int D = 128, HP = 16, WIN = 256, NTH = NWV * 64;
+    constexpr int PW = WIN / NWV;                             // positions per wave
+    constexpr int PT = PW / 16;                               // 16-position tiles per wave
+    constexpr int NH = PW / 32;                               // 32-row value images per wave
+    constexpr int QPT = HP * 64 / NTH;                        // query pairs rotated per thread
     constexpr int VP = 288;                                   // bytes per value row in LDS: rows 8 banks apart (tr reads conflict-free)
     constexpr int QP = 272;                                   // bytes per query head in LDS
     constexpr int OP = 132;                                   // floats per head of a wave's partial output
-    __shared__ __attribute__((aligned(16))) unsigned char vimg[4][32 * VP];   // per wave: 32 value rows; later its partial O
+    __shared__ __attribute__((aligned(16))) unsigned char vimg[NWV][32 * VP];   // per wave: 32 value rows; later its partial O
     __shared__ __attribute__((aligned(16))) unsigned char qs[HP * QP];
     __shared__ __attribute__((aligned(16))) T knew[D];
     __shared__ __attribute__((aligned(16))) T vnew[D];
-    __shared__ float mw[4][HP], lw[4][HP];
+    __shared__ float mw[NWV][HP], lw[NWV][HP];
     static_assert(HP * OP * 4 <= 32 * VP, "partial output fits the wave's value image");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, q = lane >> 4;
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int h0 = g * HP;
     const int t_lo = (int)blockIdx.y * WIN;
     const int wlen = cap_full - t_lo < WIN ? cap_full - t_lo : WIN;
-    const int p0 = wv * 64;                                   // the wave's first window-local position
+    const int p0 = wv * PW;                                   // the wave's first window-local position
     const int64_t pitch = (int64_t)G * D;
     const T* kb = Kc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
     const T* vb = Vc + (((int64_t)b * cap_full + t_lo) * G + g) * D;
@@ -504,31 +511,31 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
 
     // every load of the block up front: this step's q / k / v (just written: cache-hot), then keys, values, mask and
     // - once pos has arrived - the rotary table row
-    u32 xq[4], cq[4];
+    u32 xq[QPT], cq[QPT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k, hh = idx >> 6, p = idx & 63;
+    for (int k = 0; k < QPT; ++k) {
+        const int idx = tid + NTH * k, hh = idx >> 6, p = idx & 63;
         xq[k] = *reinterpret_cast<const u32*>(row + (int64_t)(h0 + hh) * D + 2 * p);
     }
     const u32 xk = *reinterpret_cast<const u32*>(row + (int64_t)(H + g) * D + 2 * (tid & 63));
     const u32x4 xv = *reinterpret_cast<const u32x4*>(row + (int64_t)(H + G + g) * D + 8 * (tid & 15));
-    u32x4 kf[4][4];                                           // [position tile][d chunk j]: d = 32 j + 8 q .. + 7 of row li
+    u32x4 kf[PT][4];                                          // [position tile][d chunk j]: d = 32 j + 8 q .. + 7 of row li
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
         const int r = p0 + 16 * pt + li, rc = r < wlen ? r : wlen - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) kf[pt][j] = *reinterpret_cast<const u32x4*>(kb + rc * pitch + 32 * j + 8 * q);
     }
-    u32x4 vr[16];                                             // row 4 i + q of the wave, 16-byte chunk li
+    u32x4 vr[8 * NH];                                         // row 4 i + q of the wave, 16-byte chunk li
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 8 * NH; ++i) {
         const int r = p0 + 4 * i + q, rc = r < wlen ? r : wlen - 1;
         vr[i] = *reinterpret_cast<const u32x4*>(vb + rc * pitch + 8 * li);
     }
     const float* mk = mask + (int64_t)b * cap_full + t_lo;
-    float mr[4][4];                                           // mask of position 16 pt + 4 q + e (the C layout's rows)
+    float mr[PT][4];                                          // mask of position 16 pt + 4 q + e (the C layout's rows)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = p0 + 16 * pt + 4 * q + e;
@@ -538,12 +545,12 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
     const T* cs = table + pos[b] * D;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cq[k] = *reinterpret_cast<const u32*>(cs + 2 * ((tid + 256 * k) & 63));
+    for (int k = 0; k < QPT; ++k) cq[k] = *reinterpret_cast<const u32*>(cs + 2 * ((tid + NTH * k) & 63));
 
-    // rotary: 16 heads x 64 pairs (4 per thread), the group's key pair (threads 0..63), the value row (threads 64..79)
+    // rotary: 16 heads x 64 pairs (QPT per thread), the group's key pair (threads 0..63), the value row (threads 64..79)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + 256 * k, hh = idx >> 6, p = idx & 63;
+    for (int k = 0; k < QPT; ++k) {
+        const int idx = tid + NTH * k, hh = idx >> 6, p = idx & 63;
         float x0, x1, c0, c1, y0, y1;
         unpack2<T>(xq[k], x0, x1);
         unpack2<T>(cq[k], c0, c1);
@@ -568,16 +575,16 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     }
 
     // S^T = K Q^T: lane (li, q) ends with scores of head li at positions 16 pt + 4 q + e
-    const int wl = has_new ? wrow - p0 : -1;                  // wave-local new row (outside [0, 64): not this wave's)
+    const int wl = has_new ? wrow - p0 : -1;                  // wave-local new row (outside [0, PW): not this wave's)
     u32x4 qf[4], knf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         qf[j] = *reinterpret_cast<const u32x4*>(qs + li * QP + 64 * j + 16 * q);
         knf[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(knew) + 64 * j + 16 * q);
     }
-    f32x4 s[4];
+    f32x4 s[PT];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
         const bool is_new = wl == 16 * pt + li;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = p0 + 16 * pt + 4 * q + e;
@@ -597,9 +604,9 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float lsum = 0.f;
-    u32x2v pf[4];
+    u32x2v pf[PT];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
         float ev[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int rl = 32 * hf + 4 * i + q;               // wave-local row
@@ -648,23 +655,26 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
     }
     __syncthreads();
     {
-        const int hh = tid >> 4, ch = tid & 15;               // head, 8-wide d chunk
-        const float m0 = mw[0][hh], m1 = mw[1][hh], m2 = mw[2][hh], m3 = mw[3][hh];
-        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        const float f[4] = {m0 == -INFINITY ? 0.f : __expf(m0 - m), m1 == -INFINITY ? 0.f : __expf(m1 - m),
-                            m2 == -INFINITY ? 0.f : __expf(m2 - m), m3 == -INFINITY ? 0.f : __expf(m3 - m)};
-        float l = 0.f, acc[8];
+        constexpr int CW = HP * D / NTH;                      // d values per thread: 8 (4 waves) or 4 (8 waves)
+        constexpr int CPH = D / CW;                           // threads per head
+        const int hh = tid / CPH, ch = tid - hh * CPH;
+        float m = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int w = 0; w < NWV; ++w) m = fmaxf(m, mw[w][hh]);
+        float l = 0.f, acc[CW];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            l = __builtin_fmaf(lw[w][hh], f[w], l);
-            const float* src = reinterpret_cast<const float*>(vimg[w]) + hh * OP + 8 * ch;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+        for (int e = 0; e < CW; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[e] = __builtin_fmaf(a0[e], f[w], acc[e]);
-                acc[4 + e] = __builtin_fmaf(a1[e], f[w], acc[4 + e]);
+        for (int w = 0; w < NWV; ++w) {
+            const float mwv = mw[w][hh];
+            const float fw = mwv == -INFINITY ? 0.f : __expf(mwv - m);
+            l = __builtin_fmaf(lw[w][hh], fw, l);
+            const float* src = reinterpret_cast<const float*>(vimg[w]) + hh * OP + CW * ch;
+#pragma unroll
+            for (int e4 = 0; e4 < CW; e4 += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + e4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e4 + e] = __builtin_fmaf(a[e], fw, acc[e4 + e]);
             }
         }
         const int64_t head = (int64_t)b * H + h0 + hh;
@@ -676,13 +686,19 @@ __global__ __launch_bounds__(256) void decode_attention_mfma_kernel(const T* __r
             }
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) *reinterpret_cast<f32x2*>(so + 2 + 8 * ch + e) = f32x2{acc[e], acc[e + 1]};
+            for (int e = 0; e < CW; e += 2) *reinterpret_cast<f32x2*>(so + 2 + CW * ch + e) = f32x2{acc[e], acc[e + 1]};
         } else {
             const float inv = 1.0f / l;
-            float y[8];
+            T* dst = Out + head * D + CW * ch;
+            if constexpr (CW == 8) {
+                float y[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = acc[e] * inv;
-            store8<T>(Out + head * D + 8 * ch, y);
+                for (int e = 0; e < 8; ++e) y[e] = acc[e] * inv;
+                store8<T>(dst, y);
+            } else {
+                typedef u32 u32x2s __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2s*>(dst) = u32x2s{pack2<T>(acc[0] * inv, acc[1] * inv), pack2<T>(acc[2] * inv, acc[3] * inv)};
+            }
         }
     }
 }
@@ -920,9 +936,15 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
         const bool one_window = capacity <= kAttnWindow;
         if (D == 128 && H == 16 * G && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
             dim3 gridg((unsigned)(B * G), (unsigned)(one_window ? 1 : nwin));
-            decode_attention_mfma_kernel<T><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
-                                                                  (int)capacity, (int)ldq, (const T*)table, mask, sq, (T*)Out,
-                                                                  one_window ? nullptr : split_ws);
+            static const int waves = [] { const char* e = getenv("QLINEAR_ATTENTION_WAVES"); return e ? atoi(e) : 8; }();
+            if (waves == 4)
+                decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
+                                                                         (int)capacity, (int)ldq, (const T*)table, mask, sq,
+                                                                         (T*)Out, one_window ? nullptr : split_ws);
+            else
+                decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
+                                                                         (int)capacity, (int)ldq, (const T*)table, mask, sq,
+                                                                         (T*)Out, one_window ? nullptr : split_ws);
             const int rc = finish_launch();
             if (rc != 0 || one_window) return rc;
             attention_combine_kernel<T, 128><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);
