@@ -25,6 +25,7 @@ STRICT_DEFAULT = os.environ.get("QLINEAR_STRICT", "0") not in ("0", "", "false",
 
 PRO_SILU = 1
 PRO_ADDNORM = 2
+NEXT_W4G32_PACKED, NEXT_W8_ROWS = 1, 2     # qlinear_decode_attention_rope_prefetch
 EPI_SILU_GATE = 0x100
 
 OP_W4G32_FWD = 1
@@ -73,6 +74,8 @@ EXPORTS = {
     "qlinear_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_decode_attention_split_bytes": (c_size_t, [c_int64] * 4),
     "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_decode_attention_rope_prefetch": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                                        c_int64, c_int64, c_void_p]),
     "qlinear_greedy_advance": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_int, c_void_p]),
     "qlinear_masked_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,

@@ -292,10 +292,10 @@ size_t qlinear_decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int
     return decode_attention_split_bytes(B, H, D, capacity);
 }
 
-int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
+static int attention_rope_checked(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
                                   int64_t capacity, int64_t ldqkv, int dtype, void* split_workspace,
-                                  size_t split_workspace_bytes, void* stream) {
+                                  size_t split_workspace_bytes, const Prefetch& pf, void* stream) {
     if (!QKV || !table || !pos || !widx || !Kcache || !Vcache || !mask || !Out) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(B) || !fits_i32(H) || !fits_i32(G) || !fits_i32(D) || !fits_i32(capacity) || H % G != 0 ||
@@ -307,7 +307,42 @@ int qlinear_decode_attention_rope(const void* QKV, const void* table, const int6
     if ((D != 128 && D != 64 && D != 32) || (!split && (capacity + 35 * D + 8) * 4 > 64 * 1024)) return QL_ERR_UNSUPPORTED;
     if (!aligned(Kcache, 16) || !aligned(Vcache, 16)) return QL_ERR_MISALIGNED;
     return decode_attention_rope(dtype, QKV, table, pos, widx, Kcache, Vcache, mask, Out, B, H, G, D, capacity, ldqkv,
-                                 (float*)split_workspace, (hipStream_t)stream);
+                                 (float*)split_workspace, pf, (hipStream_t)stream);
+}
+
+int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
+                                  void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
+                                  int64_t capacity, int64_t ldqkv, int dtype, void* split_workspace,
+                                  size_t split_workspace_bytes, void* stream) {
+    return attention_rope_checked(QKV, table, pos, widx, Kcache, Vcache, mask, Out, B, H, G, D, capacity, ldqkv, dtype,
+                                  split_workspace, split_workspace_bytes, Prefetch{}, stream);
+}
+
+int qlinear_decode_attention_rope_prefetch(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx,
+                                           void* Kcache, void* Vcache, const float* mask, void* Out, int64_t B, int64_t H,
+                                           int64_t G, int64_t D, int64_t capacity, int64_t ldqkv, int dtype,
+                                           void* split_workspace, size_t split_workspace_bytes, const void* next_weights,
+                                           int next_kind, int64_t next_N, int64_t next_K, void* stream) {
+    Prefetch pf{};
+    if (next_weights) {
+        if (next_N <= 0 || next_K <= 0 || !aligned(next_weights, 16)) return QL_ERR_BAD_SHAPE;
+        int64_t wb = 0, sb = 0, soff = 0, blocks = 0;
+        if (next_kind == QL_NEXT_W4G32_PACKED) {
+            if (next_K % 32 != 0) return QL_ERR_BAD_SHAPE;
+            w4_gemv_blocks(next_N, next_K, &wb, &sb, &soff, &blocks);
+            pf = Prefetch{{(const char*)next_weights, (const char*)next_weights + soff}, {wb, sb}, (int)blocks};
+            // the last workgroup's range may pass the end of a ragged matrix: leave it out
+            if (blocks * wb > soff) pf.blocks = (int)(soff / wb);
+        } else if (next_kind == QL_NEXT_W8_ROWS) {
+            if (next_K % 16 != 0) return QL_ERR_BAD_SHAPE;
+            w8_gemv_blocks(next_N, next_K, next_K, &wb, &blocks);
+            pf = Prefetch{{(const char*)next_weights, nullptr}, {wb, 0}, (int)(blocks * wb > next_N * next_K ? next_N * next_K / wb : blocks)};
+        } else {
+            return QL_ERR_UNSUPPORTED;
+        }
+    }
+    return attention_rope_checked(QKV, table, pos, widx, Kcache, Vcache, mask, Out, B, H, G, D, capacity, ldqkv, dtype,
+                                  split_workspace, split_workspace_bytes, pf, stream);
 }
 
 int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,

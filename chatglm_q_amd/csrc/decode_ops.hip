@@ -432,6 +432,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2v __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup p of np prefetchers.  The attention launch's workgroup (att_blocks + p) runs on XCD (att_blocks + p) % 8 and
+// consumer workgroup g of the next launch on XCD g % 8: p takes the consumers g = q, q + np', ... with
+// q = 8 (p / 8) + (att_blocks + p) % 8 (np' = np rounded down to a multiple of 8), i.e. only ones of its own XCD, and
+// reads their bytes once with plain (cacheable) 16-byte loads.  Measured on attention + o_proj (int4g32 4096 x 4096,
+// capacity 256; tools/attention_prefetch.py): 10.8 us without; everything prefetched from the start 10.9 (the
+// attention's own loads queue behind 9.4 MB); started ~1.7 us late and capped at ~7 MB 10.3.
+constexpr int64_t kPrefetchBudget = 7 << 20;                  // bytes that fit in the attention's shadow
+__device__ __forceinline__ void prefetch_blocks(const Prefetch& pf, int p, int np, int att_blocks) {
+    const int np8 = np & ~7;
+    if (p >= np8) return;
+    const int q = 8 * (p >> 3) + ((att_blocks + p) & 7);
+    const int64_t per_block = pf.block_bytes[0] + pf.block_bytes[1];
+    const int64_t fit = kPrefetchBudget / (per_block > 0 ? per_block : 1);
+    const int gmax = fit < pf.blocks ? (int)fit : pf.blocks;
+    // let the attention workgroups' own requests reach the memory system first
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(8);
+    u32 x = 0;
+    for (int g = q; g < gmax; g += np8) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t nb = pf.block_bytes[r];
+            if (nb == 0) continue;
+            const char* src = pf.base[r] + (int64_t)g * nb;
+            int64_t off = (int64_t)threadIdx.x * 16;
+            const int64_t step = (int64_t)blockDim.x * 16;
+            for (; off + 3 * step + 16 <= nb; off += 4 * step) {          // 4 independent loads in flight per thread
+                const u32x4 a = *reinterpret_cast<const u32x4*>(src + off);
+                const u32x4 b = *reinterpret_cast<const u32x4*>(src + off + step);
+                const u32x4 c = *reinterpret_cast<const u32x4*>(src + off + 2 * step);
+                const u32x4 d = *reinterpret_cast<const u32x4*>(src + off + 3 * step);
+                x ^= a[0] ^ b[0] ^ c[0] ^ d[0];
+            }
+            for (; off + 16 <= nb; off += step) x ^= (*reinterpret_cast<const u32x4*>(src + off))[0];
+        }
+    }
+    asm volatile("" ::"v"(x));                                // the loads are the point: keep them
+}
+
 template <typename T> struct AttMma;
 template <> struct AttMma<f16> {
     typedef _Float16 v8 __attribute__((ext_vector_type(8)));
@@ -476,7 +514,13 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
                                                                          int H, int G, int cap_full, int ldq32,
                                                                          const T* __restrict__ table,
                                                                          const float* __restrict__ mask, float sqrt_d,
-                                                                         T* __restrict__ Out, float* __restrict__ split_out) {
+                                                                         T* __restrict__ Out, float* __restrict__ split_out,
+                                                                         Prefetch next, int att_blocks) {
+    // Workgroups past the attention ones (blockIdx.y == 0 only) warm the caches for the next launch: see Prefetch.
+    if ((int)blockIdx.x >= att_blocks) {
+        if (blockIdx.y == 0) prefetch_blocks(next, (int)blockIdx.x - att_blocks, (int)gridDim.x - att_blocks, att_blocks);
+        return;
+    }
     // Argument order: the leading 14 dwords are preloaded into SGPRs at wave launch (Makefile); they are what the
     // query / key / value loads need, so those are in flight before the scalar loads of the rest (and of pos / widx,
     // which live in device memory) have returned.  The rotary table row depends on pos: it is requested last.
@@ -927,7 +971,7 @@ constexpr int kAttnWindow = 256;                          // positions per block
 template <typename T, bool ROPE>
 static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G,
                             int64_t D, int64_t capacity, const void* table, const int64_t* pos, const int64_t* widx,
-                            int64_t ldq, float* split_ws, hipStream_t st) {
+                            int64_t ldq, float* split_ws, const Prefetch& pf, hipStream_t st) {
     const float sq = sqrtf((float)D);
     const int nwin = split_ws ? (int)((capacity + kAttnWindow - 1) / kAttnWindow) : 1;
     if constexpr (ROPE && sizeof(T) == 2) {
@@ -935,16 +979,20 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
         const char* mfma_env = getenv("QLINEAR_ATTENTION_MFMA");
         const bool one_window = capacity <= kAttnWindow;
         if (D == 128 && H == 16 * G && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
-            dim3 gridg((unsigned)(B * G), (unsigned)(one_window ? 1 : nwin));
+            // prefetch workgroups: about one per CU (they only issue loads); none without a descriptor, none when the
+            // attention itself fills the chip (windows of a long context, large batches: measured slower)
+            const int att_blocks = (int)(B * G);
+            const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < 256 ? ((pf.blocks + 7) & ~7) : 256) : 0;
+            dim3 gridg((unsigned)(att_blocks + npf), (unsigned)(one_window ? 1 : nwin));
             static const int waves = [] { const char* e = getenv("QLINEAR_ATTENTION_WAVES"); return e ? atoi(e) : 8; }();
             if (waves == 4)
                 decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws);
+                                                                         (T*)Out, one_window ? nullptr : split_ws, pf, att_blocks);
             else
                 decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws);
+                                                                         (T*)Out, one_window ? nullptr : split_ws, pf, att_blocks);
             const int rc = finish_launch();
             if (rc != 0 || one_window) return rc;
             attention_combine_kernel<T, 128><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);
@@ -975,7 +1023,7 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
 int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st) {
     QL_DT(dtype, return (launch_attention<T, false>(Q, (void*)Kc, (void*)Vc, mask, Out, B, H, G, D, capacity, nullptr, nullptr,
-                                                    nullptr, 0, nullptr, st)))
+                                                    nullptr, 0, nullptr, Prefetch{}, st)))
     return QL_ERR_BAD_DTYPE;
 }
 
@@ -985,9 +1033,9 @@ size_t decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t cap
 
 int decode_attention_rope(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kc,
                           void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                          int64_t capacity, int64_t ldqkv, float* split_ws, hipStream_t st) {
+                          int64_t capacity, int64_t ldqkv, float* split_ws, const Prefetch& pf, hipStream_t st) {
     QL_DT(dtype, return (launch_attention<T, true>(QKV, Kc, Vc, mask, Out, B, H, G, D, capacity, table, pos, widx, ldqkv, split_ws,
-                                                   st)))
+                                                   pf, st)))
     return QL_ERR_BAD_DTYPE;
 }
 

@@ -155,9 +155,21 @@ int rope_kv_write(int dtype, const void* QKV, const void* table, const int64_t* 
                   int64_t ldqkv, hipStream_t st);
 int decode_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, void* Out, int64_t B,
                      int64_t H, int64_t G, int64_t D, int64_t capacity, hipStream_t st);
+// Bytes that block g of the NEXT launch on the stream will read first: [base[r] + g * block_bytes[r], + block_bytes[r])
+// for r = 0, 1 (block_bytes[r] == 0: no such region), g < blocks.  The grouped attention kernel is a chain of round
+// trips on B * G workgroups; its launch carries extra workgroups that pull these bytes into L2 / the memory-side cache
+// meanwhile, placed on the XCD of the workgroup that will read them (workgroups go to XCDs round robin).
+struct Prefetch {
+    const char* base[2];
+    int64_t block_bytes[2];
+    int blocks;
+};
 int decode_attention_rope(int dtype, const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kc,
                           void* Vc, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
-                          int64_t capacity, int64_t ldqkv, float* split_ws, hipStream_t st);   // split_ws: nullable
+                          int64_t capacity, int64_t ldqkv, float* split_ws, const Prefetch& pf, hipStream_t st);   // split_ws: nullable
+// how the one-row GEMVs walk their weights (for Prefetch): bytes per workgroup of the weight and the scale stream
+void w4_gemv_blocks(int64_t N, int64_t K, int64_t* w_block_bytes, int64_t* s_block_bytes, int64_t* s_offset, int64_t* blocks);
+void w8_gemv_blocks(int64_t N, int64_t K, int64_t ldw, int64_t* w_block_bytes, int64_t* blocks);
 size_t decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st);
 int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_t rows, int64_t Tn, int64_t mask_rows, int64_t lds,

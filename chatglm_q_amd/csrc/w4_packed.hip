@@ -770,6 +770,15 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
 //   3-4 GEMV       11.4         8.3        48           29
 //   3-16 few-row    9.2-10.4    8.7-9.3    20-22.4      14.3-15.3
 // so the MFMA path starts at 3 rows.  QLINEAR_GEMV_MAX_ROWS forces the limit.
+void w4_gemv_blocks(int64_t N, int64_t K, int64_t* w_block_bytes, int64_t* s_block_bytes, int64_t* s_offset, int64_t* blocks) {
+    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3, quads = Npad / 4;
+    const int qw = 4 / choose_ksplit(quads, G);               // column quads per workgroup of the one-row kernel
+    *w_block_bytes = (int64_t)qw * 4 * G * 16;
+    *s_block_bytes = (int64_t)qw * G * 8;                     // 16-bit scales: 4 per (quad, group)
+    *s_offset = Npad * G * 16;
+    *blocks = (quads + qw - 1) / qw;
+}
+
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return M > forced;

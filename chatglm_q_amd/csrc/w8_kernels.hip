@@ -796,6 +796,16 @@ static int launch_w8_gemv_f16_mb(const W8Args& p) {
     return p.strict ? launch_w8_gemv_f16_st<MB, true>(p) : launch_w8_gemv_f16_st<MB, false>(p);
 }
 
+// how the one-row fp16 kernel walks the weights (Prefetch, launch.h): 4 / KS channel quads of ldw bytes per workgroup
+void w8_gemv_blocks(int64_t N, int64_t K, int64_t ldw, int64_t* w_block_bytes, int64_t* blocks) {
+    static const int forced = [] { const char* e = getenv("QLINEAR_W8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int64_t quads = (N + 3) / 4;
+    const bool split = forced ? forced == 2 : ((K >> 4) >= 128 && quads / 2 < 1024);
+    const int qw = split ? 2 : 4;
+    *w_block_bytes = (int64_t)qw * 4 * ldw;
+    *blocks = (quads + qw - 1) / qw;
+}
+
 static int launch_w8_gemv_any(int dtype, const W8Args& p) {
     switch (dtype) {
     case QL_DTYPE_F16:

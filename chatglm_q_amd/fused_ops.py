@@ -72,14 +72,18 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
 
 
 GROUP_ATTENTION = os.environ.get("QLINEAR_ATTENTION_MFMA", "1") != "0"
+PREFETCH_NEXT = os.environ.get("QLINEAR_ATTENTION_PREFETCH", "1") != "0"   # spare workgroups warm the next linear's weights
 SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "448"))   # cache capacity from which windows are split
 
 
 def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
-                          mask: Tensor, n_head: int, n_groups: int, d_head: int, split: bool | None = None) -> Tensor:
+                          mask: Tensor, n_head: int, n_groups: int, d_head: int, split: bool | None = None,
+                          prefetch: tuple | None = None) -> Tensor:
     """``decode_attention(rope_kv_write(qkv, ...), ...)`` for one position per sequence in a single launch:
     qkv (B, 1, (H+2G) D) -> (B, 1, H*D); the rotated key and the value are written into the caches at
-    ``write_index[0]``."""
+    ``write_index[0]``.  ``prefetch = (weights, kind, N, K)``: the weights of the next one-row linear on the stream
+    (kind ``_lib.NEXT_W4G32_PACKED`` / ``_lib.NEXT_W8_ROWS``) are pulled into the caches by spare workgroups of this
+    launch (include/qlinear_hip.h)."""
     lib = _lib.get_lib()
     B, S, W = qkv.shape
     if S != 1:
@@ -94,12 +98,17 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     with torch.cuda.device(qkv.device):
         ws_bytes = int(lib.qlinear_decode_attention_split_bytes(B, n_head, d_head, capacity)) if split else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes else None
-        st = lib.qlinear_decode_attention_rope(qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(),
-                                               write_index.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-                                               mask.data_ptr(), out.data_ptr(), B, n_head, n_groups, d_head,
-                                               capacity, W, _lib.dtype_code(qkv.dtype), _lib.ptr(ws), ws_bytes,
-                                               _lib.stream_ptr(qkv.device))
-    _lib.check(st, "qlinear_decode_attention_rope")
+        args = (qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(), write_index.data_ptr(), k_cache.data_ptr(),
+                v_cache.data_ptr(), mask.data_ptr(), out.data_ptr(), B, n_head, n_groups, d_head, capacity, W,
+                _lib.dtype_code(qkv.dtype), _lib.ptr(ws), ws_bytes)
+        if prefetch is not None and PREFETCH_NEXT:
+            weights, kind, n_next, k_next = prefetch
+            st = lib.qlinear_decode_attention_rope_prefetch(*args, weights.data_ptr(), kind, n_next, k_next,
+                                                            _lib.stream_ptr(qkv.device))
+            _lib.check(st, "qlinear_decode_attention_rope_prefetch")
+        else:
+            st = lib.qlinear_decode_attention_rope(*args, _lib.stream_ptr(qkv.device))
+            _lib.check(st, "qlinear_decode_attention_rope")
     return out
 
 

@@ -296,8 +296,14 @@ class ChatGLM2Model(nn.Module):
             hn = torch.empty_like(h)
             qkv = norm_linear(at.qkv_proj, h, delta, layer.attn_ln, hn)
             h = hn
+            # the attention launch is a chain of round trips on B * G workgroups: its spare workgroups read o_proj's
+            # weights into the caches meanwhile
+            if kind == "int4":
+                nxt = (at.o_proj.prepare()._packed, _lib.NEXT_W4G32_PACKED, at.o_proj.out_features, at.o_proj.in_features)
+            else:
+                nxt = (at.o_proj.weight, _lib.NEXT_W8_ROWS, at.o_proj.out_features, at.o_proj.in_features)
             o = at.o_proj(F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i],
-                                                   cache.v[i], mask, H, G, D))
+                                                   cache.v[i], mask, H, G, D, prefetch=nxt))
             hn = torch.empty_like(h)
             # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its weights (each wave owns
             # (h, h, gate, gate) column quads), so the (1, 2 * hidden) intermediate is never written.  (As a

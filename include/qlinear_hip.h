@@ -235,6 +235,18 @@ int qlinear_decode_attention_rope(const void* QKV, const void* table, const int6
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,
                                   int64_t capacity, int64_t ldqkv, int dtype, void* split_workspace,
                                   size_t split_workspace_bytes, void* stream);
+/* The same launch, carrying extra workgroups that read the weights of the NEXT one-row linear on the stream (the
+ * attention output projection) into L2 / the memory-side cache while the attention itself - a chain of round trips on
+ * B * G workgroups - leaves the chip and HBM idle.  next_weights: QL_NEXT_W4G32_PACKED = buffer of
+ * qlinear_w4g32_repack, QL_NEXT_W8_ROWS = contiguous (N, K) int8 rows; NULL: no prefetch.  Only the group kernel
+ * (H == 16 G, D == 128, fp16 / bf16) prefetches; results never depend on it. */
+#define QL_NEXT_W4G32_PACKED 1
+#define QL_NEXT_W8_ROWS 2
+int qlinear_decode_attention_rope_prefetch(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx,
+                                           void* Kcache, void* Vcache, const float* mask, void* Out, int64_t B, int64_t H,
+                                           int64_t G, int64_t D, int64_t capacity, int64_t ldqkv, int dtype,
+                                           void* split_workspace, size_t split_workspace_bytes, const void* next_weights,
+                                           int next_kind, int64_t next_N, int64_t next_K, void* stream);
 /* masked_softmax: P[r, :] = round(softmax_fp32(scores[r, :] + mask[r % mask_rows, :])) - the add / fp32 softmax / cast
  * between the two GEMMs of the many-position attention (chatglm_q/model.py:166-170) in one pass; mask nullable. */
 int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,

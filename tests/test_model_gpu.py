@@ -247,6 +247,42 @@ def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatc
     assert ((a - r).norm(dim=-1) <= 4 * tol * r.norm(dim=-1) + 1e-3).all()
 
 
+@pytest.mark.parametrize("kind", ["int4", "int8"])
+@pytest.mark.parametrize("nk", [(4096, 4096), (1000, 512), (36, 64)])
+def test_attention_prefetch_workgroups_change_nothing(kind, nk):
+    """The spare workgroups that warm the next linear's weights only read: outputs and caches are bit-identical with
+    and without them, also for weight buffers smaller than one prefetch unit."""
+    from chatglm_q_amd import _lib, fused_ops as F_
+    from chatglm_q_amd import model as M
+    N, K = nk
+    B, H, Gq, D, cap, n = 2, 32, 2, 128, 192, 70
+    g = torch.Generator(device=DEV).manual_seed(3)
+    if kind == "int4":
+        from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+        layer = DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16, device=DEV)
+        layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).half())
+        nxt = (layer.prepare()._packed, _lib.NEXT_W4G32_PACKED, N, K)
+    else:
+        w = torch.randint(-127, 128, (N, K), device=DEV, generator=g, dtype=torch.int8)
+        nxt = (w, _lib.NEXT_W8_ROWS, N, K)
+    qkv = torch.randn(B, 1, (H + 2 * Gq) * D, device=DEV, generator=g).half()
+    table = M.rotary_table(D, cap + 8).to(DEV).half().reshape(cap + 8, -1).contiguous()
+    pos = torch.full((B, 1), n + 1, dtype=torch.long, device=DEV)
+    widx = torch.tensor([n], dtype=torch.long, device=DEV)
+    mask = torch.full((B, 1, cap), -1e10, device=DEV)
+    mask[:, :, : n + 1] = 0
+    outs = []
+    for pf in (None, nxt):
+        g2 = torch.Generator(device=DEV).manual_seed(4)
+        k = torch.randn(B, cap, Gq, D, device=DEV, generator=g2).half()
+        v = torch.randn(B, cap, Gq, D, device=DEV, generator=g2).half()
+        outs.append((F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, Gq, D, prefetch=pf), k, v))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("N", [65024, 1003, 8])
 def test_greedy_advance_argmax_and_bookkeeping(dtype, N):
