@@ -140,6 +140,7 @@ struct PackedTile16 {
 //   1: no math (loaded words are XOR-folded), 2: math with a constant activation (no LDS reads),
 //   4: as 2 and no activation staging at all (no staging loads, no LDS writes, no barrier)
 //   5: as 1 and no activation staging at all (weight / scale loads, reduction and epilogue only)
+//   6: as 5 plus the staging loads, LDS writes and barrier (staged data unused); 7: as 5 plus the staging LOADS only
 // KS: the block's 4 waves cover 4/KS column quads x KS slices of K (combined through LDS at the end):
 // shapes with few columns but a long K (w_out: 13696 -> 4096) get 4x the workgroups and 4x the loads
 // in flight per column instead of one wave walking 7 tiles in sequence.
@@ -280,7 +281,11 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             areg[i] = pack8<T>(hv[i]);
         }
     }
-    if constexpr (A_LDS && VAR != 4 && VAR != 5) {
+    if constexpr (A_LDS && VAR == 7) {
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) asm volatile("" ::"v"(areg[i][0]));   // keep the loads
+    }
+    if constexpr (A_LDS && VAR != 4 && VAR != 5 && VAR != 7) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const int c = tid + i * 256;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 x;
-                if constexpr (VAR == 2 || VAR == 4 || VAR == 5)
+                if constexpr (VAR == 2 || VAR == 4 || VAR == 5 || VAR == 6 || VAR == 7)
                     x = u32x4{SP::kOnes, SP::kOnes, SP::kOnes, SP::kOnes};
                 else if constexpr (A_LDS)
                     x = *reinterpret_cast<const u32x4*>(smem + ((int64_t)m * cpr + a_chunk_pos(gc, j)) * 16);
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                 av[m][4 * j + 3] = x[3];
             }
         const u32x2 sv = g < g_end ? tl.s : u32x2{0u, 0u};    // out-of-range lanes contribute 0
-        if constexpr (VAR == 1 || VAR == 5) {
+        if constexpr (VAR == 1 || VAR == 5 || VAR == 6 || VAR == 7) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 acc[0][c] += u32_as_f32((tl.w[c][0] ^ tl.w[c][1] ^ tl.w[c][2] ^ tl.w[c][3] ^ sv[0] ^ sv[1] ^ av[0][c]) &
@@ -649,6 +654,14 @@ static int launch_16(const PackedArgs& p) {
         }
         if (dev_variant() == 4) {
             w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 4><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, nullptr, nullptr, p.N, p.K, p.M, (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0);
+            return finish_launch();
+        }
+        if (dev_variant() == 6) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 6><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, nullptr, nullptr, p.N, p.K, p.M, (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0);
+            return finish_launch();
+        }
+        if (dev_variant() == 7) {
+            w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 7><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, nullptr, nullptr, p.N, p.K, p.M, (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0);
             return finish_launch();
         }
         if (dev_variant() == 5) {
