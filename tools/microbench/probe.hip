@@ -104,6 +104,66 @@ __global__ __launch_bounds__(256) void gemv_pattern_kernel(const u32x4* __restri
     if (lane == 0) out[blockIdx.x * 4 + wave] = x;
 }
 
+// Hand-off feasibility: workgroups 0..P-1 are "producers" (a dependent chain of `spin` s_sleep rounds standing in for the
+// attention, then 8 KB of output, release fence, flag = tag); the others are GEMV-pattern consumers that request their
+// weights at once, wait for the P flags, acquire, read the 8 KB and finish.  tag must differ between launches.
+__global__ __launch_bounds__(256) void handoff_kernel(const u32x4* __restrict__ Wt, const uint2* __restrict__ Sp, u32x4* xbuf,
+                                                      uint32_t* flags, const uint32_t* __restrict__ tagp, uint32_t* __restrict__ out,
+                                                      int G, int quads, int P, int spin, int delay) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tag = tagp[0];
+    if ((int)blockIdx.x < P) {
+        for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);
+        for (int c = tid; c < 512; c += 256) xbuf[c] = u32x4{tag, (uint32_t)c, 1u, 2u};
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + blockIdx.x, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int blk = (int)blockIdx.x - P;
+    int t = blk * 4 + wave;
+    if (t >= quads) t = 0;
+    for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(8);
+    const u32x4* wb = Wt + (size_t)t * 4 * G;
+    const uint2* sb = Sp + (size_t)t * G;
+    u32x4 v[8];
+    uint2 sc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int g = u * 64 + lane;
+        if (g >= G) g = G - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u * 4 + c] = __builtin_nontemporal_load(wb + (size_t)c * G + g);
+        sc[u] = sb[g];
+    }
+    // wait for the producers (one lane polls, bounded)
+    if (tid == 0) {
+        for (int p = 0; p < P; ++p) {
+            int guard = 0;
+            while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag && ++guard < (1 << 20))
+                __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t x = 0;
+    for (int c = tid; c < 512; c += 256) {
+        const u32x4 a = xbuf[c];
+        x ^= a[0] ^ a[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+    x ^= sc[0].x ^ sc[1].y;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (lane == 0) out[blk * 4 + wave] = x;
+}
+__global__ void bump_kernel(uint32_t* tagp) { tagp[0] += 1; }
+__global__ __launch_bounds__(256) void chain_kernel(u32x4* xbuf, const uint32_t* tagp, int spin) {
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);
+    for (int c = threadIdx.x; c < 512; c += 256) xbuf[c] = u32x4{tagp[0], (uint32_t)c, 1u, 2u};
+}
+
 __global__ void empty_kernel() {}
 
 struct Timer {
@@ -178,6 +238,35 @@ int main(int argc, char** argv) {
         us = T.run(STEPS, [&](int i) { qlinear_w4g32_fwd_packed(A, pk[i % SETS], nullptr, C, M, N, K, 32, K, N, QL_DTYPE_F16, FLAGS, nullptr, 0, T.st); });
         char nm[64]; snprintf(nm, sizeof nm, "w4 packed gemv QL_VARIANT=%s", getenv("QL_VARIANT") ? getenv("QL_VARIANT") : "0");
         report(nm, us, alg);
+        return 0;
+    }
+    if (argc > 4 && !strcmp(argv[4], "handoff")) {
+        const size_t wbytes = (size_t)N * G * 16;
+        const int quads = N / 4, nblk = (quads + 3) / 4, P = 2;
+        u32x4* xbuf; uint32_t *flags, *tagp;
+        CK(hipMalloc(&xbuf, 8192)); CK(hipMalloc(&flags, 64)); CK(hipMalloc(&tagp, 4));
+        CK(hipMemset(flags, 0, 64)); CK(hipMemset(tagp, 0, 4));
+        for (int spin : {0, 8, 16, 24}) {
+            // separate launches: chain kernel (2 workgroups) then the GEMV pattern (KS = 1, reads the 8 KB)
+            us = T.run(STEPS, [&](int i) {
+                chain_kernel<<<P, 256, 0, T.st>>>(xbuf, tagp, spin);
+                gemv_pattern_kernel<1, true, true><<<nblk, 256, K * 2, T.st>>>((const u32x4*)pk[i % SETS], (const uint2*)((const char*)pk[i % SETS] + wbytes),
+                                                                              (const u32x4*)xbuf, out, G, quads, K / 8);
+            });
+            printf("spin %2d: separate launches (chain + pattern)      %8.3f us\n", spin, us);
+            us = T.run(STEPS, [&](int) { chain_kernel<<<P, 256, 0, T.st>>>(xbuf, tagp, spin); });
+            printf("spin %2d: chain kernel alone                        %8.3f us\n", spin, us);
+            for (int delay : {0, 4, 8}) {
+                us = T.run(STEPS, [&](int i) {
+                    bump_kernel<<<1, 1, 0, T.st>>>(tagp);
+                    handoff_kernel<<<P + nblk, 256, 0, T.st>>>((const u32x4*)pk[i % SETS], (const uint2*)((const char*)pk[i % SETS] + wbytes), xbuf, flags,
+                                                                tagp, out, G, quads, P, spin, delay);
+                });
+                printf("spin %2d: one launch with hand-off (+ bump kernel), consumer delay %d  %8.3f us\n", spin, delay, us);
+            }
+        }
+        us = T.run(STEPS, [&](int) { bump_kernel<<<1, 1, 0, T.st>>>(tagp); });
+        printf("bump kernel alone %8.3f us\n", us);
         return 0;
     }
     if (argc > 4 && !strcmp(argv[4], "pattern")) {
