@@ -140,6 +140,15 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
     return w4_packed_fused(dtype, prologue, gate, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
 }
 
+int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
+                                      int64_t N, int64_t K, int dtype, void* stream) {
+    if (!A || !packed || !C || !residual) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || N <= 0 || K <= 0 || K % 32 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(packed, 16) || !aligned(A, 16)) return QL_ERR_MISALIGNED;
+    return w4_packed_residual(dtype, A, packed, bias, residual, C, N, K, (hipStream_t)stream);
+}
+
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, int flags,
                    void* workspace, size_t workspace_bytes, void* stream) {

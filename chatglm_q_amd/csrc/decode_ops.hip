@@ -490,24 +490,6 @@ template <> struct AttMma<__bf16> {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
     }
 };
-template <typename T>
-__device__ __forceinline__ u32 pack2(float a, float b) {
-    const T x = (T)a, y = (T)b;
-    uint16_t lo, hi;
-    __builtin_memcpy(&lo, &x, 2);
-    __builtin_memcpy(&hi, &y, 2);
-    return (u32)lo | ((u32)hi << 16);
-}
-template <typename T>
-__device__ __forceinline__ void unpack2(u32 w, float& a, float& b) {
-    const uint16_t lo = (uint16_t)(w & 0xFFFFu), hi = (uint16_t)(w >> 16);
-    T x, y;
-    __builtin_memcpy(&x, &lo, 2);
-    __builtin_memcpy(&y, &hi, 2);
-    a = (float)x;
-    b = (float)y;
-}
-
 template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
                                                                          const int64_t* __restrict__ widx, T* Kc, T* Vc,

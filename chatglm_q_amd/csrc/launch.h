@@ -12,7 +12,7 @@ namespace ql {
 int finish_launch();
 
 // activation prologue / gate epilogue of the one-row fused GEMVs (w4_packed.hip, w8_kernels.hip)
-enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2 };
+enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2, PRO_NORM = 3 };   // PRO_NORM: ADDNORM without delta / hout (internal)
 struct Prologue {
     const void* delta;      // PRO_ADDNORM: residual contribution to add first (nullable)
     const void* ln_weight;  // PRO_ADDNORM
@@ -59,6 +59,8 @@ int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st);
 
+int w4_packed_residual(int dtype, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
+                       int64_t K, hipStream_t st);
 int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,
                     int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 

@@ -53,6 +53,25 @@ template <> struct Act<__bf16> {
     static __device__ __forceinline__ void store(__bf16* p, float x) { *p = (__bf16)x; }
 };
 
+// two activations <-> one 32-bit word (16-bit dtypes)
+template <typename T>
+__device__ __forceinline__ u32 pack2(float a, float b) {
+    const T x = (T)a, y = (T)b;
+    uint16_t lo, hi;
+    __builtin_memcpy(&lo, &x, 2);
+    __builtin_memcpy(&hi, &y, 2);
+    return (u32)lo | ((u32)hi << 16);
+}
+template <typename T>
+__device__ __forceinline__ void unpack2(u32 w, float& a, float& b) {
+    const uint16_t lo = (uint16_t)(w & 0xFFFFu), hi = (uint16_t)(w >> 16);
+    T x, y;
+    __builtin_memcpy(&x, &lo, 2);
+    __builtin_memcpy(&y, &hi, 2);
+    a = (float)x;
+    b = (float)y;
+}
+
 // Output epilogue shared by every kernel: one rounding of the fp32 accumulator to the activation
 // dtype, then the bias add as a second rounded operation - exactly the reference's
 // "acc.to(C.dtype)" (chatglm_q/int4/triton_ops.py:80) followed by the in-place "out += bias"

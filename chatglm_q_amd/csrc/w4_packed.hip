@@ -156,7 +156,11 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                                                                 const T* __restrict__ Sp, const void* pro_delta,
                                                                 const void* pro_ln_weight, int N, int K, int M, int lda32,
                                                                 const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
-                                                                void* pro_hout, float pro_eps, int pro_gate) {
+                                                                void* pro_hout, float pro_eps, int pro_gate,
+                                                                const T* __restrict__ resid = nullptr) {
+    // resid (one row, nullable): the residual stream the output is added to in the epilogue - out = round(y + resid),
+    // y = rounded sum (+ bias) - so that the NEXT projection's RMSNorm prologue needs no delta operand
+    // (chatglm_q/model.py:243,245: hidden = hidden + sublayer(...)).
     // Argument order: everything the first loads need sits in the leading 14 dwords, which are preloaded into SGPRs at
     // wave launch (-amdgpu-kernarg-preload-count, Makefile); the rest costs a scalar-load round trip that used to
     // sit in front of the first weight load (4096 x 4096: 4.25 -> 3.97 us).
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 
     // (1) activation staging loads first: oldest in the VM queue
     u32x4 areg[A_LDS ? ACH : 1];
+    constexpr bool kNorm = PRO == PRO_ADDNORM || PRO == PRO_NORM;
     u32x4 xreg[PRO != PRO_NONE ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // prologue operands
     if constexpr (A_LDS && VAR != 4 && VAR != 5) {
 #pragma unroll
@@ -204,12 +209,19 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
             areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
             if constexpr (PRO == PRO_SILU) xreg[i] = *reinterpret_cast<const u32x4*>(arow[0] + K + cc * 8);
-            if constexpr (PRO == PRO_ADDNORM) {
-                xreg[i] = *reinterpret_cast<const u32x4*>((const T*)pro.ln_weight + cc * 8);
+            if constexpr (kNorm) xreg[i] = *reinterpret_cast<const u32x4*>((const T*)pro.ln_weight + cc * 8);
+            if constexpr (PRO == PRO_ADDNORM)
                 yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const T*)pro.delta : arow[0]) + cc * 8);
-            }
         }
     }
+
+    // Epilogue operands of this wave's column quad (bias, residual) requested NOW, behind the staging loads: fetched
+    // at the end they are a global round trip in the tail of every wave (the residual epilogue measured no gain that
+    // way).  Unconditional loads from a safe address; used only when the quad is whole and the rows are 8-byte aligned.
+    const bool quad_early = MB == 1 && t * 4 + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
+    const int tq = quad_early ? t * 4 : 0;
+    const u32x2 bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : (const T*)Sp) + tq);
+    const u32x2 resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : (const T*)Sp) + tq);
 
     const u32x4* wbase = Wt + (int64_t)t * 4 * G;
     const T* sbase = Sp + (int64_t)t * G * 4;
@@ -248,24 +260,28 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             areg[i] = pack8<T>(h);
         }
     }
-    if constexpr (PRO == PRO_ADDNORM) {
+    if constexpr (kNorm) {
         float* nred = reinterpret_cast<float*>(smem + (((size_t)K * sizeof(T) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float));
         float hv[ACH][8];
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            float d[8];
             unpack8<T>(areg[i], hv[i]);
-            unpack8<T>(yreg[i], d);
             const int c = tid + i * 256;
-            if (pro.delta) {
+            if constexpr (PRO == PRO_ADDNORM) {
+                if (pro.delta) {
+                    float d[8];
+                    unpack8<T>(yreg[i], d);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hv[i][e] = Act<T>::round(hv[i][e] + d[e]);
+                    for (int e = 0; e < 8; ++e) hv[i][e] = Act<T>::round(hv[i][e] + d[e]);
+                }
             }
             if (c < cpr) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[i][e], hv[i][e], ss);
-                if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((T*)pro.hout + c * 8) = pack8<T>(hv[i]);
+                if constexpr (PRO == PRO_ADDNORM) {
+                    if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((T*)pro.hout + c * 8) = pack8<T>(hv[i]);
+                }
             }
         }
         ss = wave_sum(ss);
@@ -445,17 +461,35 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     }
 
     if (wave_active && ks == 0 && lane == 0) {
+        float bq[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (quad_early) {
+            unpack2<T>(bias_q[0], bq[0], bq[1]);
+            unpack2<T>(bias_q[1], bq[2], bq[3]);
+            unpack2<T>(resid_q[0], rq[0], rq[1]);
+            unpack2<T>(resid_q[1], rq[2], rq[3]);
+        }
         if (PRO != PRO_NONE && pro.gate_epilogue) {
             // SiLU(h) * gate on the quad's (h0, h1, gate0, gate1) sums; N is a multiple of 4 here
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 y[c] = Act<T>::round(acc[0][c]);
-                if (bias) y[c] = Act<T>::round(y[c] + Act<T>::load(bias + t * 4 + c));
+                if (bias) y[c] = Act<T>::round(y[c] + (quad_early ? bq[c] : Act<T>::load(bias + t * 4 + c)));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 Act<T>::store(C + t * 2 + i, Act<T>::round(Act<T>::round(y[i] / (1.0f + __expf(-y[i]))) * y[i + 2]));
+            return;
+        }
+        if (quad_early) {                                     // one row, whole quad: one 8-byte store
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                y[c] = Act<T>::round(acc[0][c]);
+                if (bias) y[c] = resid ? Act<T>::round(y[c] + bq[c]) : y[c] + bq[c];
+                if (resid) y[c] = y[c] + rq[c];
+            }
+            *reinterpret_cast<u32x2*>(C + t * 4) = u32x2{pack2<T>(y[0], y[1]), pack2<T>(y[2], y[3])};
             return;
         }
 #pragma unroll
@@ -464,7 +498,14 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int n = t * 4 + c;
-                if (n < N) store_out<T>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+                if (n >= N) continue;
+                if (resid) {                                  // one row: residual add as a third rounded operation
+                    float y = Act<T>::round(acc[m][c]);
+                    if (bias) y = Act<T>::round(y + Act<T>::load(bias + n));
+                    Act<T>::store(C + n, y + Act<T>::load(resid + n));
+                } else {
+                    store_out<T>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+                }
             }
         }
     }
@@ -602,6 +643,7 @@ struct PackedArgs {
     int64_t lda, ldc;
     bool strict;
     hipStream_t st;
+    const void* resid = nullptr;   // one-row residual epilogue (w4_packed_residual)
 };
 
 #ifdef QL_DEV_VARIANTS
@@ -671,7 +713,8 @@ static int launch_16(const PackedArgs& p) {
     }
 #endif
     w4_packed_gemv_16_kernel<T, MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, nullptr, nullptr, p.N, p.K, p.M,
-                                                                               (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0);
+                                                                               (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0,
+                                                                               (const T*)p.resid);
     return finish_launch();
 }
 
@@ -756,10 +799,12 @@ int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, cons
     const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
     if (dtype == QL_DTYPE_F16) {
         if (kind == PRO_SILU) return launch_16_pro_any<f16, PRO_SILU>(p, pro);
-        if (kind == PRO_ADDNORM) return launch_16_pro_any<f16, PRO_ADDNORM>(p, pro);
+        if (kind == PRO_ADDNORM)
+            return !delta && !hout ? launch_16_pro_any<f16, PRO_NORM>(p, pro) : launch_16_pro_any<f16, PRO_ADDNORM>(p, pro);
     } else if (dtype == QL_DTYPE_BF16) {
         if (kind == PRO_SILU) return launch_16_pro_any<__bf16, PRO_SILU>(p, pro);
-        if (kind == PRO_ADDNORM) return launch_16_pro_any<__bf16, PRO_ADDNORM>(p, pro);
+        if (kind == PRO_ADDNORM)
+            return !delta && !hout ? launch_16_pro_any<__bf16, PRO_NORM>(p, pro) : launch_16_pro_any<__bf16, PRO_ADDNORM>(p, pro);
     } else {
         return QL_ERR_BAD_DTYPE;
     }
@@ -790,6 +835,16 @@ void w4_gemv_blocks(int64_t N, int64_t K, int64_t* w_block_bytes, int64_t* s_blo
     *s_block_bytes = (int64_t)qw * G * 8;                     // 16-bit scales: 4 per (quad, group)
     *s_offset = Npad * G * 16;
     *blocks = (quads + qw - 1) / qw;
+}
+
+// one-row forward whose output is added to the residual stream: C = round(y + resid), y = rounded sum (+ bias)
+int w4_packed_residual(int dtype, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
+                       int64_t K, hipStream_t st) {
+    PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, false, st};
+    p.resid = resid;
+    if (dtype == QL_DTYPE_F16) return launch_16_any<f16, false>(p);
+    if (dtype == QL_DTYPE_BF16) return launch_16_any<__bf16, false>(p);
+    return QL_ERR_UNSUPPORTED;
 }
 
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {

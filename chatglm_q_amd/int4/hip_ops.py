@@ -194,6 +194,23 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     return c
 
 
+def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, residual: Tensor) -> Tensor:
+    """One-row forward added to the residual stream in the kernel's epilogue: round(y + residual), y = the layer's
+    rounded output (``qlinear_w4g32_fwd_packed_residual``)."""
+    lib = _lib.get_lib()
+    if a.numel() != a.shape[-1] or residual.numel() != n_out:
+        raise ValueError("the residual epilogue serves exactly one row")
+    a = a.contiguous()
+    residual = residual.contiguous()
+    c = torch.empty((*a.shape[:-1], n_out), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_packed_residual(a.data_ptr(), packed.data_ptr(), _lib.ptr(bias), residual.data_ptr(),
+                                                   c.data_ptr(), n_out, a.shape[-1], _lib.dtype_code(a.dtype),
+                                                   _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w4g32_fwd_packed_residual")
+    return c
+
+
 def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
     """Same contract as the reference wrapper (chatglm_q/int4/triton_ops.py:90-139).
 

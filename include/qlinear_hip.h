@@ -165,6 +165,13 @@ int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t 
 int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
+ * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
+ * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then
+ * runs without delta / hout (one operand less to stage in every workgroup).  C may alias residual.  fp16 / bf16. */
+int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
+                                      int64_t N, int64_t K, int dtype, void* stream);
+
 /* One-row (decode) int8 forward with the add + RMSNorm PROLOGUE (QL_PRO_ADDNORM) and optionally the SiLU * gate
  * EPILOGUE (| QL_EPI_SILU_GATE: the N rows of W - and S, bias - come in (h_2t, h_2t+1, gate_2t, gate_2t+1) quads,
  * C receives N / 2 values): the int8 twin of qlinear_w4g32_fwd_packed_fused, same rounding sequence.

@@ -247,6 +247,39 @@ def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatc
     assert ((a - r).norm(dim=-1) <= 4 * tol * r.norm(dim=-1) + 1e-3).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("nk", [(4096, 4096), (4096, 13696), (250, 96), (8, 64)])
+def test_residual_epilogue_and_norm_prologue_equal_separate_ops(dtype, bias, nk):
+    """qlinear_w4g32_fwd_packed_residual = layer(x) + h (three rounded operations, chatglm_q/model.py:243,245), and the
+    RMSNorm prologue without delta = layer(rmsnorm(h)): bit for bit, also for ragged column quads."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    N, K = nk
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    layer = DynamicQuantizeLinear(K, N, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+    h = torch.randn(1, 1, N, device=DEV, generator=g).to(dtype)
+    packed = layer.prepare()._packed
+    with torch.no_grad():
+        want = layer(x) + h
+    got = H4.w4_forward_residual(x, packed, N, layer.bias, h)
+    assert torch.equal(got, want)
+    got_alias = h.clone()
+    got_alias = H4.w4_forward_residual(x, packed, N, layer.bias, got_alias)
+    assert torch.equal(got_alias, want)
+    w = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+    got_n = H4.w4_forward_fused(_lib.PRO_ADDNORM, x, packed, N, layer.bias, None, w, None, 1e-5)
+    with torch.no_grad():
+        want_n = layer(F_.rmsnorm(x, w, 1e-5))
+    assert torch.equal(got_n, want_n)
+
+
 @pytest.mark.parametrize("kind", ["int4", "int8"])
 @pytest.mark.parametrize("nk", [(4096, 4096), (1000, 512), (36, 64)])
 def test_attention_prefetch_workgroups_change_nothing(kind, nk):
