@@ -75,6 +75,7 @@ EXPORTS = {
     "qlinear_decode_attention_split_bytes": (c_size_t, [c_int64] * 4),
     "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w4g32_fwd_packed_residual": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w8_fwd_residual": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_decode_attention_rope_prefetch": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p, c_int,
                                                         c_int64, c_int64, c_void_p]),
     "qlinear_greedy_advance": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -149,6 +149,15 @@ int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const v
     return w4_packed_residual(dtype, A, packed, bias, residual, C, N, K, (hipStream_t)stream);
 }
 
+int qlinear_w8_fwd_residual(const void* A, const int8_t* W, const void* S, const void* bias, const void* residual, void* C,
+                            int64_t N, int64_t K, int64_t ldw, int dtype, void* stream) {
+    if (!A || !W || !S || !C || !residual) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || N <= 0 || K <= 0 || ldw < K) return QL_ERR_BAD_SHAPE;
+    if (!aligned(A, 16) || !aligned(W, 16) || ldw % 16 != 0) return QL_ERR_MISALIGNED;
+    return w8_gemv_residual(dtype, A, W, S, bias, residual, C, N, K, ldw, (hipStream_t)stream);
+}
+
 int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, int dtype, int flags,
                    void* workspace, size_t workspace_bytes, void* stream) {

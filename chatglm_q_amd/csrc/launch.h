@@ -84,6 +84,8 @@ int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C
 int w8_generic(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,
                int64_t N, int64_t K, int64_t ldw_k, int64_t ldw_n, int64_t lda, int64_t ldc, hipStream_t st);
 // one decode row, fp16, K % 16 == 0: add + RMSNorm prologue, optional SiLU * gate epilogue (rows of W in (h, h, gate, gate) quads)
+int w8_gemv_residual(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, const void* resid, void* C,
+                     int64_t N, int64_t K, int64_t ldw, hipStream_t st);
 int w8_gemv_fused(int dtype, bool gate_epilogue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
                   int64_t K, int64_t ldw, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M,

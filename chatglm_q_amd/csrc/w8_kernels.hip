@@ -100,12 +100,15 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
                                                           const void* pro_delta, const void* pro_ln_weight, int N, int K,
                                                           int M, int ldw32, int lda32, const f16* __restrict__ S,
                                                           const f16* __restrict__ bias, f16* __restrict__ C, int64_t ldc,
-                                                          void* pro_hout, float pro_eps, int pro_gate) {
+                                                          void* pro_hout, float pro_eps, int pro_gate,
+                                                          const f16* __restrict__ resid = nullptr) {
+    // resid (one row, nullable): residual stream added in the epilogue, out = round(y + resid) - see w4_packed.hip
     // (argument order: the leading 14 dwords - all that the first loads need - are preloaded into SGPRs at wave
     // launch, see w4_packed_gemv_16_kernel)
     const int64_t ldw = ldw32, lda = lda32;
     const Prologue pro{pro_delta, pro_ln_weight, pro_hout, pro_eps, pro_gate};
-    static_assert(PRO == PRO_NONE || (PRO == PRO_ADDNORM && MB == 1 && ACH > 0), "prologue: one LDS-staged row");
+    static_assert(PRO == PRO_NONE || ((PRO == PRO_ADDNORM || PRO == PRO_NORM) && MB == 1 && ACH > 0), "prologue: one LDS-staged row");
+    constexpr bool kNorm = PRO == PRO_ADDNORM || PRO == PRO_NORM;
     constexpr bool A_LDS = ACH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     for (int m = 0; m < MB; ++m) arow[m] = A + (int64_t)((m0 + m < M) ? (m0 + m) : (M - 1)) * lda;
 
     u32x4 areg[A_LDS ? ACH : 1];
-    u32x4 xreg[PRO == PRO_ADDNORM ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // ln weight, residual delta
+    u32x4 xreg[kNorm ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // ln weight, residual delta
     if constexpr (A_LDS) {
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
@@ -136,16 +139,21 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
             const int c = min(tid + i * 256, MB * ppr - 1);
             const int m = MB == 1 ? 0 : c / ppr, cc = c - m * ppr;
             areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
-            if constexpr (PRO == PRO_ADDNORM) {
-                xreg[i] = *reinterpret_cast<const u32x4*>((const f16*)pro.ln_weight + cc * 8);
+            if constexpr (kNorm) xreg[i] = *reinterpret_cast<const u32x4*>((const f16*)pro.ln_weight + cc * 8);
+            if constexpr (PRO == PRO_ADDNORM)
                 yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const f16*)pro.delta : arow[0]) + cc * 8);
-            }
         }
     }
 
     const int8_t* wrow[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[c] = W + (int64_t)((nb + c < N) ? (nb + c) : (N - 1)) * ldw;
+
+    // epilogue operands of the wave's channel quad requested now (see w4_packed.hip): no global round trip in the tail
+    const bool quad_early = MB == 1 && nb + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
+    const int nq = quad_early ? nb : 0;
+    const u32x2 bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : S) + nq);
+    const u32x2 resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : S) + nq);
 
     auto load_tile = [&](int it) {
         W8Tile<MB, A_LDS> tl;
@@ -171,25 +179,29 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     if (iters > 0) t0 = load_tile(0);
     if (iters > 1) t1 = load_tile(1);
 
-    if constexpr (PRO == PRO_ADDNORM) {
+    if constexpr (kNorm) {
         // hnew = round(x + delta), written once (block 0); staged row = round(round(hnew * r) * ln_weight)
         float* nred = reinterpret_cast<float*>(smem + (((size_t)kvec * sizeof(f16) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float));
         float hv[ACH][8];
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            float d[8];
             unpack8<f16>(areg[i], hv[i]);
-            unpack8<f16>(yreg[i], d);
             const int c = tid + i * 256;
-            if (pro.delta) {
+            if constexpr (PRO == PRO_ADDNORM) {
+                if (pro.delta) {
+                    float d[8];
+                    unpack8<f16>(yreg[i], d);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hv[i][e] = Act<f16>::round(hv[i][e] + d[e]);
+                    for (int e = 0; e < 8; ++e) hv[i][e] = Act<f16>::round(hv[i][e] + d[e]);
+                }
             }
             if (c < ppr) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[i][e], hv[i][e], ss);
-                if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((f16*)pro.hout + c * 8) = pack8<f16>(hv[i]);
+                if constexpr (PRO == PRO_ADDNORM) {
+                    if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((f16*)pro.hout + c * 8) = pack8<f16>(hv[i]);
+                }
             }
         }
         ss = wave_sum(ss);
@@ -363,17 +375,35 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     }
 
     if (wave_active && ks == 0 && lane == 0) {
+        float bq[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (quad_early) {
+            unpack2<f16>(bias_q[0], bq[0], bq[1]);
+            unpack2<f16>(bias_q[1], bq[2], bq[3]);
+            unpack2<f16>(resid_q[0], rq[0], rq[1]);
+            unpack2<f16>(resid_q[1], rq[2], rq[3]);
+        }
         if (PRO != PRO_NONE && pro.gate_epilogue) {
             // rows of W come in (h, h, gate, gate) quads: C gets N / 2 values (chatglm_q/model.py:200-201)
             float y[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 y[c] = Act<f16>::round(acc[0][c]);
-                if (bias) y[c] = Act<f16>::round(y[c] + Act<f16>::load(bias + nb + c));
+                if (bias) y[c] = Act<f16>::round(y[c] + (quad_early ? bq[c] : Act<f16>::load(bias + nb + c)));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 Act<f16>::store(C + (nb >> 1) + i, Act<f16>::round(Act<f16>::round(y[i] / (1.0f + __expf(-y[i]))) * y[i + 2]));
+            return;
+        }
+        if (quad_early) {                                     // one row, whole quad: one 8-byte store
+            float y[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                y[c] = Act<f16>::round(acc[0][c]);
+                if (bias) y[c] = resid ? Act<f16>::round(y[c] + bq[c]) : y[c] + bq[c];
+                if (resid) y[c] = y[c] + rq[c];
+            }
+            *reinterpret_cast<u32x2*>(C + nb) = u32x2{pack2<f16>(y[0], y[1]), pack2<f16>(y[2], y[3])};
             return;
         }
 #pragma unroll
@@ -382,7 +412,14 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int n = nb + c;
-                if (n < N) store_out<f16>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+                if (n >= N) continue;
+                if (resid) {
+                    float y = Act<f16>::round(acc[m][c]);
+                    if (bias) y = Act<f16>::round(y + Act<f16>::load(bias + n));
+                    Act<f16>::store(C + n, y + Act<f16>::load(resid + n));
+                } else {
+                    store_out<f16>(C + (int64_t)(m0 + m) * ldc + n, acc[m][c], bias ? bias + n : nullptr);
+                }
             }
         }
     }
@@ -732,6 +769,7 @@ struct W8Args {
     int M, N, K;
     int64_t ldw, lda, ldc;
     hipStream_t st;
+    const void* resid = nullptr;   // one-row residual epilogue (w8_gemv_residual)
 };
 
 template <typename T, int MB>
@@ -753,11 +791,11 @@ static int launch_w8_gemv_f16(const W8Args& p) {
     if (p.ldw > 0x7fffffff || p.lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;   // strides travel as 32 bits
     w8_gemv_f16_kernel<MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, nullptr, nullptr, p.N, p.K, p.M, (int)p.ldw,
                                                           (int)p.lda, (const f16*)p.S, (const f16*)p.bias, (f16*)p.C, p.ldc,
-                                                          nullptr, 0.f, 0);
+                                                          nullptr, 0.f, 0, (const f16*)p.resid);
     return finish_launch();
 }
 
-template <int ACH, int KS>
+template <int ACH, int KS, int PRO = PRO_ADDNORM>
 static int launch_w8_gemv_fused(const W8Args& p, const Prologue& pro) {
     const int quads = (p.N + 3) / 4;
     constexpr int QW = 4 / KS;
@@ -765,7 +803,7 @@ static int launch_w8_gemv_fused(const W8Args& p, const Prologue& pro) {
     // staged row, K-slice sums, the four per-wave partial sums of squares
     const size_t lds = (((size_t)(p.K & ~15) * sizeof(f16) + 15) & ~(size_t)15) + (size_t)4 * 4 * sizeof(float) + 4 * sizeof(float);
     if (p.ldw > 0x7fffffff || p.lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;
-    w8_gemv_f16_kernel<1, ACH, KS, false, PRO_ADDNORM><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, pro.delta, pro.ln_weight, p.N,
+    w8_gemv_f16_kernel<1, ACH, KS, false, PRO><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, pro.delta, pro.ln_weight, p.N,
                                                                                 p.K, 1, (int)p.ldw, (int)p.lda, (const f16*)p.S,
                                                                                 (const f16*)p.bias, (f16*)p.C, p.ldc, pro.hout,
                                                                                 pro.eps, pro.gate_epilogue);
@@ -930,14 +968,27 @@ int w8_gemv_fused(int dtype, bool gate_epilogue, const void* A, const int8_t* W,
     const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
     const int64_t quads = (N + 3) / 4;
     const bool split = (K >> 4) >= 128 && quads / 2 < 1024;    // the unfused kernel's rule
+    const bool plain_norm = !delta && !hout;                   // nothing to add, nothing to write back
+#define QL_W8_FUSED(ACH_, KS_) \
+    return plain_norm ? launch_w8_gemv_fused<ACH_, KS_, PRO_NORM>(p, pro) : launch_w8_gemv_fused<ACH_, KS_, PRO_ADDNORM>(p, pro);
     if (split) {
-        if (pieces <= 2 * 256) return launch_w8_gemv_fused<2, 2>(p, pro);
-        if (pieces <= 4 * 256) return launch_w8_gemv_fused<4, 2>(p, pro);
-        return launch_w8_gemv_fused<8, 2>(p, pro);
+        if (pieces <= 2 * 256) { QL_W8_FUSED(2, 2) }
+        if (pieces <= 4 * 256) { QL_W8_FUSED(4, 2) }
+        QL_W8_FUSED(8, 2)
     }
-    if (pieces <= 2 * 256) return launch_w8_gemv_fused<2, 1>(p, pro);
-    if (pieces <= 4 * 256) return launch_w8_gemv_fused<4, 1>(p, pro);
-    return launch_w8_gemv_fused<8, 1>(p, pro);
+    if (pieces <= 2 * 256) { QL_W8_FUSED(2, 1) }
+    if (pieces <= 4 * 256) { QL_W8_FUSED(4, 1) }
+    QL_W8_FUSED(8, 1)
+#undef QL_W8_FUSED
+}
+
+// one-row fp16 forward whose output is added to the residual stream: C = round(y + resid)
+int w8_gemv_residual(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, const void* resid, void* C,
+                     int64_t N, int64_t K, int64_t ldw, hipStream_t st) {
+    if (dtype != QL_DTYPE_F16) return QL_ERR_BAD_DTYPE;
+    W8Args p{false, A, W, S, bias, C, 1, (int)N, (int)K, ldw, K, N, st};
+    p.resid = resid;
+    return launch_w8_gemv_f16_mb<1>(p);
 }
 int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
                       hipStream_t st) {

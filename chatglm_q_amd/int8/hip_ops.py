@@ -133,6 +133,23 @@ def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, b
     return c
 
 
+def w8_forward_residual(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None, residual: Tensor) -> Tensor:
+    """One-row fp16 forward added to the residual stream in the kernel's epilogue (``qlinear_w8_fwd_residual``)."""
+    lib = _lib.get_lib()
+    N, K = weight_nk.shape
+    if a.numel() != K or residual.numel() != N:
+        raise ValueError("the residual epilogue serves exactly one row")
+    a = a.contiguous()
+    residual = residual.contiguous()
+    c = torch.empty((*a.shape[:-1], N), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd_residual(a.data_ptr(), weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias),
+                                         residual.data_ptr(), c.data_ptr(), N, K, weight_nk.stride(0),
+                                         _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w8_fwd_residual")
+    return c
+
+
 def w8_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
     """Shapes / dtypes served by qlinear_w8_bwd_input (everything else takes the dense torch formula)."""
     return (grad_out.is_cuda and grad_out.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == grad_out.dtype

@@ -290,38 +290,30 @@ class ChatGLM2Model(nn.Module):
             w, sc, bias = mod.gated(gate_hidden) if gate_hidden else (mod.weight, mod.weight_scale, mod.bias)
             return H8.w8_forward_fused(flags, x, w, sc, bias, delta, ln.weight, hout, ln.eps)
 
-        if kind == "int4":
-            # int4: the residual adds run in the EPILOGUES of o_proj / w_out (round(y + h)), so the RMSNorm prologues
-            # of qkv_proj / w_in / lm_head stage two operands instead of three in every workgroup
-            for i, layer in enumerate(self.layers):
-                at, ff = layer.attn, layer.ffn
-                qkv = norm_linear(at.qkv_proj, h, None, layer.attn_ln, None)
-                nxt = (at.o_proj.prepare()._packed, _lib.NEXT_W4G32_PACKED, at.o_proj.out_features, at.o_proj.in_features)
-                att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i],
-                                               mask, H, G, D, prefetch=nxt)
-                h = H4.w4_forward_residual(att, at.o_proj.prepare()._packed, at.o_proj.out_features, at.o_proj.bias, h)
-                y = norm_linear(ff.w_in, h, None, layer.ffn_ln, None, gate_hidden=ff.hidden_dim)
-                h = H4.w4_forward_residual(y, ff.w_out.prepare()._packed, ff.w_out.out_features, ff.w_out.bias, h)
-            return norm_linear(self.lm_head, h, None, self.final_ln, None)
-        delta = None
+        # The residual adds run in the EPILOGUES of o_proj / w_out (round(y + h)), so the RMSNorm prologues of qkv_proj /
+        # w_in / lm_head stage two operands instead of three in every workgroup.  SiLU * gate runs in w_in's EPILOGUE on a
+        # gate-interleaved copy of its weights (each wave owns (h, h, gate, gate) column quads), so the (1, 2 * hidden)
+        # intermediate is never written.  (As a PROLOGUE of w_out it measured +6 us: every one of w_out's ~1000 blocks
+        # redid the 13696 exponentials.)  The attention launch is a chain of round trips on B * G workgroups: its spare
+        # workgroups read o_proj's weights into the caches meanwhile.
+        def residual_linear(mod, x, resid):
+            if kind == "int4":
+                return H4.w4_forward_residual(x, mod.prepare()._packed, mod.out_features, mod.bias, resid)
+            return H8.w8_forward_residual(x, mod.weight, mod.weight_scale, mod.bias, resid)
+
         for i, layer in enumerate(self.layers):
             at, ff = layer.attn, layer.ffn
-            hn = torch.empty_like(h)
-            qkv = norm_linear(at.qkv_proj, h, delta, layer.attn_ln, hn)
-            h = hn
-            # the attention launch is a chain of round trips on B * G workgroups: its spare workgroups read o_proj's
-            # weights into the caches meanwhile
-            nxt = (at.o_proj.weight, _lib.NEXT_W8_ROWS, at.o_proj.out_features, at.o_proj.in_features)
-            o = at.o_proj(F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i],
-                                                   cache.v[i], mask, H, G, D, prefetch=nxt))
-            hn = torch.empty_like(h)
-            # SiLU * gate runs in w_in's EPILOGUE on a gate-interleaved copy of its weights (each wave owns
-            # (h, h, gate, gate) column quads), so the (1, 2 * hidden) intermediate is never written.  (As a
-            # PROLOGUE of w_out it measured +6 us: every one of w_out's ~1000 blocks redid the 13696 exponentials.)
-            y = norm_linear(ff.w_in, h, o, layer.ffn_ln, hn, gate_hidden=ff.hidden_dim)
-            h = hn
-            delta = ff.w_out(y)
-        return norm_linear(self.lm_head, h, delta, self.final_ln, None)
+            qkv = norm_linear(at.qkv_proj, h, None, layer.attn_ln, None)
+            if kind == "int4":
+                nxt = (at.o_proj.prepare()._packed, _lib.NEXT_W4G32_PACKED, at.o_proj.out_features, at.o_proj.in_features)
+            else:
+                nxt = (at.o_proj.weight, _lib.NEXT_W8_ROWS, at.o_proj.out_features, at.o_proj.in_features)
+            att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i],
+                                           mask, H, G, D, prefetch=nxt)
+            h = residual_linear(at.o_proj, att, h)
+            y = norm_linear(ff.w_in, h, None, layer.ffn_ln, None, gate_hidden=ff.hidden_dim)
+            h = residual_linear(ff.w_out, y, h)
+        return norm_linear(self.lm_head, h, None, self.final_ln, None)
 
     # -- reference-shaped call ----------------------------------------------------------------------
     def forward(self, input_ids: Optional[Tensor] = None, input_embeddings: Optional[Tensor] = None,

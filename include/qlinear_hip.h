@@ -172,6 +172,10 @@ int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const 
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
                                       int64_t N, int64_t K, int dtype, void* stream);
 
+/* The int8 twin (fp16 activations, K-contiguous weight rows of stride ldw, per-channel scales S). */
+int qlinear_w8_fwd_residual(const void* A, const int8_t* W, const void* S, const void* bias, const void* residual, void* C,
+                            int64_t N, int64_t K, int64_t ldw, int dtype, void* stream);
+
 /* One-row (decode) int8 forward with the add + RMSNorm PROLOGUE (QL_PRO_ADDNORM) and optionally the SiLU * gate
  * EPILOGUE (| QL_EPI_SILU_GATE: the N rows of W - and S, bias - come in (h_2t, h_2t+1, gate_2t, gate_2t+1) quads,
  * C receives N / 2 values): the int8 twin of qlinear_w4g32_fwd_packed_fused, same rounding sequence.

@@ -384,6 +384,14 @@ def test_int8_fused_prologue_and_gate_epilogue(bias):
                 want = layer(x)
             assert torch.equal(hout, want_h)
             assert O.rel_l2(t2n(got), t2n(want)) < 2e-3
+        # no delta, nothing to write back (the PRO_NORM kernels): bit-equal to the delta=None call above
+        got_n = H8.w8_forward_fused(_lib.PRO_ADDNORM, h, layer.weight, layer.weight_scale, layer.bias, None, w, None, 1e-5)
+        assert torch.equal(got_n, got)
+        # residual epilogue: layer(x) + r as three rounded operations, bit for bit
+        r = torch.randn(1, 1, N, device=DEV, generator=g).half()
+        with torch.no_grad():
+            want_r = layer(h) + r
+        assert torch.equal(H8.w8_forward_residual(h, layer.weight, layer.weight_scale, layer.bias, r), want_r)
         hidden = N // 2
         gw, gs, gb = layer.gated(hidden)
         hout = torch.empty_like(h)
