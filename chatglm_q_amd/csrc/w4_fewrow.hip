@@ -51,6 +51,13 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
         wtile[t] = Wm + (int64_t)ct * ksteps * 64 + lane;
         stile[t] = Sm + (int64_t)ct * ksteps * 64 + lane;
     }
+    // bias of the lane's column(s), requested now: fetched in the epilogue it is a global round trip in the wave's tail
+    float bias_t[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n_base + 32 * t;
+        bias_t[t] = Act<T>::load((bias ? bias : Sm) + (bias && n < N ? n : 0));
+    }
     constexpr int ATILE = 4096 * MT;                          // one A tile: 32 MT rows x 128 bytes
     char* abuf = smem + wave * (2 * ATILE);                   // two tiles, private to the wave
 
@@ -193,15 +200,19 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     for (int t = 0; t < NT; ++t) {
         const int n_raw = n_base + 32 * t;
         if (n_raw >= N) continue;
-        const T* bn = bias ? bias + n_raw : nullptr;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
                 if (m >= M) continue;
-                if (part) part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[mt][t][i];
-                else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[mt][t][i], bn);
+                if (part) {
+                    part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[mt][t][i];
+                } else {                                      // store_out's sequence with the preloaded bias
+                    float y = Act<T>::round(acc[mt][t][i]);
+                    if (bias) y = y + bias_t[t];
+                    Act<T>::store(C + (int64_t)m * ldc + n_raw, y);
+                }
             }
     }
 }

@@ -408,6 +408,8 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kb = lane >> 5;
     const int n_raw = blockIdx.x * 32 + j;
+    // bias of the lane's channel, requested now instead of in the wave's tail
+    const float bias_j = Act<T>::load((bias ? bias : S) + (bias && n_raw < N ? n_raw : 0));
     const int ksteps = (K + 63) >> 6;
     const int slice = blockIdx.y * KW + wave;
     const int k0 = slice * per;
@@ -517,13 +519,17 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] += red[((w - 1) * 16 + i) * 64 + lane];
     if (n_raw >= N) return;
-    const T* bn = bias ? bias + n_raw : nullptr;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int m = (i & 3) + 8 * (i >> 2) + 4 * kb;
         if (m >= M) continue;
-        if (part) part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[i];
-        else store_out<T>(C + (int64_t)m * ldc + n_raw, acc[i], bn);
+        if (part) {
+            part[((int64_t)blockIdx.y * M + m) * N + n_raw] = acc[i];
+        } else {                                              // store_out's sequence with the preloaded bias
+            float y = Act<T>::round(acc[i]);
+            if (bias) y = y + bias_j;
+            Act<T>::store(C + (int64_t)m * ldc + n_raw, y);
+        }
     }
 }
 
