@@ -215,14 +215,6 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
         }
     }
 
-    // Epilogue operands of this wave's column quad (bias, residual) requested NOW, behind the staging loads: fetched
-    // at the end they are a global round trip in the tail of every wave (the residual epilogue measured no gain that
-    // way).  Unconditional loads from a safe address; used only when the quad is whole and the rows are 8-byte aligned.
-    const bool quad_early = MB == 1 && t * 4 + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
-    const int tq = quad_early ? t * 4 : 0;
-    const u32x2 bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : (const T*)Sp) + tq);
-    const u32x2 resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : (const T*)Sp) + tq);
-
     const u32x4* wbase = Wt + (int64_t)t * 4 * G;
     const T* sbase = Sp + (int64_t)t * G * 4;
 
@@ -247,6 +239,19 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     PackedTile16<MB, A_LDS> t0 = load_tile(0);
     PackedTile16<MB, A_LDS> t1;
     if (iters > 1) t1 = load_tile(1);          // wave-uniform branch around the whole tile
+
+    // Epilogue operands of this wave's column quad (bias, residual) requested behind the weight tiles: fetched at
+    // the end they are a global round trip in the tail of every wave (the residual epilogue measured no gain that way);
+    // in front of the tiles, their pointers - late kernel arguments - would put a scalar-load wait before the first
+    // weight load of every wave (plain forward 3.97 -> 4.41 us).  Unconditional loads from a safe address; used only when the quad is whole and the rows are 8-byte aligned.
+    const bool quad_early = MB == 1 && t * 4 + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
+    const int tq = quad_early ? t * 4 : 0;
+    u32x2 bias_q = {0u, 0u}, resid_q = {0u, 0u};
+    if (bias || resid) {                                      // kernel-uniform: plain forwards issue no extra loads
+        bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : (const T*)Sp) + tq);
+        resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : (const T*)Sp) + tq);
+    }
+
 
     // (3) stage the activations (waits only for the staging loads, which are older than the tiles)
     if constexpr (PRO == PRO_SILU) {

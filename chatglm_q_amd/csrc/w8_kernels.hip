@@ -149,12 +149,6 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[c] = W + (int64_t)((nb + c < N) ? (nb + c) : (N - 1)) * ldw;
 
-    // epilogue operands of the wave's channel quad requested now (see w4_packed.hip): no global round trip in the tail
-    const bool quad_early = MB == 1 && nb + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
-    const int nq = quad_early ? nb : 0;
-    const u32x2 bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : S) + nq);
-    const u32x2 resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : S) + nq);
-
     auto load_tile = [&](int it) {
         W8Tile<MB, A_LDS> tl;
 #pragma unroll
@@ -178,6 +172,16 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     W8Tile<MB, A_LDS> t0, t1;
     if (iters > 0) t0 = load_tile(0);
     if (iters > 1) t1 = load_tile(1);
+
+    // epilogue operands of the wave's channel quad requested behind the weight tiles (see w4_packed.hip)
+    const bool quad_early = MB == 1 && nb + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
+    const int nq = quad_early ? nb : 0;
+    u32x2 bias_q = {0u, 0u}, resid_q = {0u, 0u};
+    if (bias || resid) {                                      // kernel-uniform: plain forwards issue no extra loads
+        bias_q = *reinterpret_cast<const u32x2*>((bias && quad_early ? bias : S) + nq);
+        resid_q = *reinterpret_cast<const u32x2*>((resid && quad_early ? resid : S) + nq);
+    }
+
 
     if constexpr (kNorm) {
         // hnew = round(x + delta), written once (block 0); staged row = round(round(hnew * r) * ln_weight)
