@@ -51,13 +51,6 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
         wtile[t] = Wm + (int64_t)ct * ksteps * 64 + lane;
         stile[t] = Sm + (int64_t)ct * ksteps * 64 + lane;
     }
-    // bias of the lane's column(s), requested now: fetched in the epilogue it is a global round trip in the wave's tail
-    float bias_t[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n_base + 32 * t;
-        bias_t[t] = Act<T>::load((bias ? bias : Sm) + (bias && n < N ? n : 0));
-    }
     constexpr int ATILE = 4096 * MT;                          // one A tile: 32 MT rows x 128 bytes
     char* abuf = smem + wave * (2 * ATILE);                   // two tiles, private to the wave
 
@@ -141,11 +134,27 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
         }
     };
 
+    // bias of the lane's column(s): requested behind the first weight loads (its pointer is a late kernel argument) and
+    // not in the epilogue, where it would be a global round trip in the wave's tail
+    float bias_t[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_t[t] = 0.f;
+    auto load_bias = [&]() {
+        if (bias) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n_base + 32 * t;
+                bias_t[t] = Act<T>::load(bias + (n < N ? n : 0));
+            }
+        }
+    };
+    if (nst == 0) load_bias();
     if (nst > 0) {
         // two steps in flight; loads unconditional (a step past the end re-reads the last one: never stored)
         Stage st0, st1;
         load_stage(k0, st0);
         load_stage(k0 + (nst > 1 ? 1 : 0), st1);
+        load_bias();
         int t = 0;
         for (; t + 2 < nst; t += 2) {
             store_a(0, st0);

@@ -408,8 +408,6 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kb = lane >> 5;
     const int n_raw = blockIdx.x * 32 + j;
-    // bias of the lane's channel, requested now instead of in the wave's tail
-    const float bias_j = Act<T>::load((bias ? bias : S) + (bias && n_raw < N ? n_raw : 0));
     const int ksteps = (K + 63) >> 6;
     const int slice = blockIdx.y * KW + wave;
     const int k0 = slice * per;
@@ -479,10 +477,14 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
         }
     };
 
+    // bias of the lane's channel: requested behind the first weight loads (late kernel argument), not in the wave's tail
+    float bias_j = 0.f;
+    if (nst == 0 && bias) bias_j = Act<T>::load(bias + (n_raw < N ? n_raw : 0));
     if (nst > 0) {
         Stage st0, st1;
         load_stage(k0, st0);
         load_stage(k0 + (nst > 1 ? 1 : 0), st1);
+        if (bias) bias_j = Act<T>::load(bias + (n_raw < N ? n_raw : 0));
         int t = 0;
         for (; t + 2 < nst; t += 2) {
             store_a(0, st0);
