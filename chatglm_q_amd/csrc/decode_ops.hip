@@ -493,11 +493,12 @@ template <> struct AttMma<__bf16> {
 template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
                                                                          const int64_t* __restrict__ widx, T* Kc, T* Vc,
-                                                                         int H, int G, int cap_full, int ldq32,
+                                                                         int hg, int att_blocks, int cap_full, int ldq32,
                                                                          const T* __restrict__ table,
                                                                          const float* __restrict__ mask, float sqrt_d,
                                                                          T* __restrict__ Out, float* __restrict__ split_out,
-                                                                         Prefetch next, int att_blocks) {
+                                                                         Prefetch next) {
+    const int H = hg & 0xFFFF, G = hg >> 16;                  // packed: the preloaded argument dwords are all taken
     // Workgroups past the attention ones (blockIdx.y == 0 only) warm the caches for the next launch: see Prefetch.
     if ((int)blockIdx.x >= att_blocks) {
         if (blockIdx.y == 0) prefetch_blocks(next, (int)blockIdx.x - att_blocks, (int)gridDim.x - att_blocks, att_blocks);
@@ -960,21 +961,22 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
         // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_ATTENTION_MFMA=0: per-head kernels)
         const char* mfma_env = getenv("QLINEAR_ATTENTION_MFMA");
         const bool one_window = capacity <= kAttnWindow;
-        if (D == 128 && H == 16 * G && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
+        if (D == 128 && H == 16 * G && H < 65536 && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
             // prefetch workgroups: about one per CU (they only issue loads); none without a descriptor, none when the
             // attention itself fills the chip (windows of a long context, large batches: measured slower)
             const int att_blocks = (int)(B * G);
+            const int hg = (int)H | ((int)G << 16);
             const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < 256 ? ((pf.blocks + 7) & ~7) : 256) : 0;
             dim3 gridg((unsigned)(att_blocks + npf), (unsigned)(one_window ? 1 : nwin));
             static const int waves = [] { const char* e = getenv("QLINEAR_ATTENTION_WAVES"); return e ? atoi(e) : 8; }();
             if (waves == 4)
-                decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
+                decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws, pf, att_blocks);
+                                                                         (T*)Out, one_window ? nullptr : split_ws, pf);
             else
-                decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, (int)H, (int)G,
+                decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws, pf, att_blocks);
+                                                                         (T*)Out, one_window ? nullptr : split_ws, pf);
             const int rc = finish_launch();
             if (rc != 0 || one_window) return rc;
             attention_combine_kernel<T, 128><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);
