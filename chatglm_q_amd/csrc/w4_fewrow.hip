@@ -148,7 +148,6 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
             }
         }
     };
-    if (nst == 0) load_bias();
     if (nst > 0) {
         // two steps in flight; loads unconditional (a step past the end re-reads the last one: never stored)
         Stage st0, st1;
@@ -183,6 +182,8 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
             mma_step(1, k0 + t + 1, st1.w, st1.s);
         }
     }
+
+    if (nst == 0) load_bias();                                // (a wave without K steps still writes its tile when it is wave 0)
 
     // sum the KW slices: every wave parks its accumulator in LDS, wave 0 adds them up and writes the 32 x 32 tile
     __syncthreads();

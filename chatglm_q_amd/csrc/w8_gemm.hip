@@ -479,7 +479,6 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
 
     // bias of the lane's channel: requested behind the first weight loads (late kernel argument), not in the wave's tail
     float bias_j = 0.f;
-    if (nst == 0 && bias) bias_j = Act<T>::load(bias + (n_raw < N ? n_raw : 0));
     if (nst > 0) {
         Stage st0, st1;
         load_stage(k0, st0);
@@ -507,6 +506,8 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
             mma_step(1, st1.w);
         }
     }
+
+    if (nst == 0 && bias) bias_j = Act<T>::load(bias + (n_raw < N ? n_raw : 0));
 
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);

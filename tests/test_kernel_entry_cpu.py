@@ -70,6 +70,8 @@ def _body_after_preload_prologue(lines):
     (r"w4_packed_gemv_16_kernelIDF16bLi1ELi\dELi\dELb0ELi0ELi[03]E", "int4g32 one-row forward, bf16"),
     (r"w8_gemv_f16_kernelILi1ELi\dELi\dELb0ELi0E", "int8 one-row forward (plain / residual)"),
     (r"w8_gemv_f16_kernelILi1ELi\dELi\dELb0ELi[23]E", "int8 one-row forward with the RMSNorm prologues"),
+    (r"w4_fewrow_kernelIDF16", "int4g32 few-row forward"),
+    (r"w8_fewrow_kernelIDF16", "int8 few-row forward"),
 ])
 def test_no_scalar_load_wait_before_the_first_weight_load(pattern, what, tmp_path):
     kernels = _disassemble(pattern, tmp_path)
