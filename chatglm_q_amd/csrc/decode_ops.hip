@@ -573,6 +573,10 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
     const T* cs = table + pos[b] * D;
 #pragma unroll
     for (int k = 0; k < QPT; ++k) cq[k] = *reinterpret_cast<const u32*>(cs + 2 * ((tid + NTH * k) & 63));
+    // xk / xv are used under `tid < 64` / `tid < 80` only: left alone, the compiler sinks their loads into those
+    // branches, where they are a fresh global round trip behind a queue drain in front of the first barrier
+    u32 xk_p = xk, xv0 = xv[0], xv1 = xv[1], xv2 = xv[2], xv3 = xv[3];
+    asm volatile("" : "+v"(xk_p), "+v"(xv0), "+v"(xv1), "+v"(xv2), "+v"(xv3));
 
     // rotary: 16 heads x 64 pairs (QPT per thread), the group's key pair (threads 0..63), the value row (threads 64..79)
 #pragma unroll
@@ -587,12 +591,12 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
     }
     if (tid < 64) {
         float x0, x1, c0, c1, y0, y1;
-        unpack2<T>(xk, x0, x1);
+        unpack2<T>(xk_p, x0, x1);
         unpack2<T>(cq[0], c0, c1);                            // idx = tid: pair tid
         rope_pair(x0, x1, c0, c1, y0, y1);
         reinterpret_cast<u32*>(knew)[tid] = pack2<T>(y0, y1);
     } else if (tid < 80) {
-        reinterpret_cast<u32x4*>(vnew)[tid - 64] = xv;
+        reinterpret_cast<u32x4*>(vnew)[tid - 64] = u32x4{xv0, xv1, xv2, xv3};
     }
     __syncthreads();
     if (has_new && tid < 32) {                                // the cache row of this step (read back from LDS by nobody else)
