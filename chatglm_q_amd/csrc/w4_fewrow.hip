@@ -139,13 +139,11 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
     float bias_t[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_t[t] = 0.f;
-    auto load_bias = [&]() {
-        if (bias) {
+    auto load_bias = [&]() {                                  // unconditional (a load under `if (bias)` drains the queue)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = n_base + 32 * t;
-                bias_t[t] = Act<T>::load(bias + (n < N ? n : 0));
-            }
+        for (int t = 0; t < NT; ++t) {
+            const int n = n_base + 32 * t;
+            bias_t[t] = Act<T>::load((bias ? bias : Sm) + (bias && n < N ? n : 0));
         }
     };
     if (nst > 0) {

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
         Stage st0, st1;
         load_stage(k0, st0);
         load_stage(k0 + (nst > 1 ? 1 : 0), st1);
-        if (bias) bias_j = Act<T>::load(bias + (n_raw < N ? n_raw : 0));
+        bias_j = Act<T>::load((bias ? bias : S) + (bias && n_raw < N ? n_raw : 0));   // unconditional: no queue drain
         int t = 0;
         for (; t + 2 < nst; t += 2) {
             store_a(0, st0);
