@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     W8Tile<MB, A_LDS> t0, t1;
     if (iters > 0) t0 = load_tile(0);
     if (iters > 1) t1 = load_tile(1);
+    // per-channel scales of the quad: requested behind the weight tiles (S is a late kernel argument).  After the
+    // staging barrier - where they used to be - they were a dependent global round trip once all tiles had landed.
+    f16 s_raw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s_raw[c] = S[(nb + c < N) ? (nb + c) : (N - 1)];
 
     // epilogue operands of the wave's channel quad requested behind the weight tiles (see w4_packed.hip)
     const bool quad_early = MB == 1 && nb + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
@@ -248,7 +253,11 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     h2 s2[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const f16 sh = S[(nb + c < N) ? (nb + c) : (N - 1)];
+        // first use pinned HERE, behind the staging barrier: hoisted in front of it, the wait for these loads - the
+        // youngest in the queue - kept the barrier back until every weight tile had landed
+        uint16_t bits = __builtin_bit_cast(uint16_t, s_raw[c]);
+        asm volatile("" : "+v"(bits));
+        const f16 sh = __builtin_bit_cast(f16, bits);
         s2[c] = h2{sh, sh};
     }
 
