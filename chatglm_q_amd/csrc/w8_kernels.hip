@@ -169,14 +169,18 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
         return tl;
     };
 
-    W8Tile<MB, A_LDS> t0, t1;
-    if (iters > 0) t0 = load_tile(0);
-    if (iters > 1) t1 = load_tile(1);
-    // per-channel scales of the quad: requested behind the weight tiles (S is a late kernel argument).  After the
-    // staging barrier - where they used to be - they were a dependent global round trip once all tiles had landed.
+    // tile 0 unconditionally (addresses are clamped; K >= 16 is the launcher's business): under `if (iters > 0)` the
+    // compiler has to place the staging waits as if no tile load were outstanding, i.e. the activation staging, the
+    // RMSNorm barriers and the LDS write all waited for the weight tiles to arrive from HBM
+    W8Tile<MB, A_LDS> t0 = load_tile(0), t1;
+    // per-channel scales of the quad: requested between the two tiles - behind tile 0 because S is a late kernel
+    // argument, in front of tile 1 because tile 0's math needs them (loads return in order).  After the staging
+    // barrier - where they used to be - they were a dependent global round trip once all tiles had landed.
+    __builtin_amdgcn_sched_barrier(0);         // (the scheduler otherwise hoists them, and the wait for S, to the top)
     f16 s_raw[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) s_raw[c] = S[(nb + c < N) ? (nb + c) : (N - 1)];
+    if (iters > 1) t1 = load_tile(1);
 
     // epilogue operands of the wave's channel quad requested behind the weight tiles (see w4_packed.hip)
     const bool quad_early = MB == 1 && nb + 3 < N && (((uintptr_t)bias | (uintptr_t)resid | (uintptr_t)C) & 7) == 0;
@@ -255,9 +259,8 @@ __global__ __launch_bounds__(256) void w8_gemv_f16_kernel(const f16* __restrict_
     for (int c = 0; c < 4; ++c) {
         // first use pinned HERE, behind the staging barrier: hoisted in front of it, the wait for these loads - the
         // youngest in the queue - kept the barrier back until every weight tile had landed
-        uint16_t bits = __builtin_bit_cast(uint16_t, s_raw[c]);
-        asm volatile("" : "+v"(bits));
-        const f16 sh = __builtin_bit_cast(f16, bits);
+        f16 sh = s_raw[c];
+        asm volatile("" : "+v"(sh));
         s2[c] = h2{sh, sh};
     }
 
@@ -860,6 +863,11 @@ void w8_gemv_blocks(int64_t N, int64_t K, int64_t ldw, int64_t* w_block_bytes, i
 static int launch_w8_gemv_any(int dtype, const W8Args& p) {
     switch (dtype) {
     case QL_DTYPE_F16:
+        if (p.K < 16) {                                       // no 16-byte unit in a row: the per-byte kernel
+            if (p.M == 1) return launch_w8_gemv_generic<f16, 1>(p);
+            if (p.M == 2) return launch_w8_gemv_generic<f16, 2>(p);
+            return launch_w8_gemv_generic<f16, 4>(p);
+        }
         if (p.M == 1) return launch_w8_gemv_f16_mb<1>(p);
         if (p.M == 2) return launch_w8_gemv_f16_mb<2>(p);
         return launch_w8_gemv_f16_mb<4>(p);
