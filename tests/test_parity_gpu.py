@@ -257,6 +257,9 @@ W8_SHAPES = [
     (2, 13696, 512, "f16", False),
     (4, 1000, 260, "f16", True),        # K % 16 != 0 tail, N % 4 == 0
     (3, 136, 37, "f16", False),         # ragged N
+    (1, 8, 20, "f16", True),            # K < 16: no 16-byte unit in a row (per-byte kernel)
+    (2, 24, 12, "f16", False),          # one unit per row: K slices without tiles, tail of 8
+    (1, 16, 4100, "f16", True),         # one unit per row, many channels
     (6, 512, 128, "bf16", True),
     (1, 4096, 1024, "bf16", False),
     (5, 512, 96, "f32", True),
