@@ -27,6 +27,7 @@ PRO_SILU = 1
 PRO_ADDNORM = 2
 NEXT_W4G32_PACKED, NEXT_W8_ROWS = 1, 2     # qlinear_decode_attention_rope_prefetch
 EPI_SILU_GATE = 0x100
+ERR_UNSUPPORTED = -7            # QL_ERR_UNSUPPORTED
 
 OP_W4G32_FWD = 1
 OP_W4G32_FWD_PACKED = 2
@@ -74,6 +75,7 @@ EXPORTS = {
     "qlinear_decode_attention": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_decode_attention_split_bytes": (c_size_t, [c_int64] * 4),
     "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_fwd_packed_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed_residual": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w8_fwd_residual": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_decode_attention_rope_prefetch": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p, c_int,

@@ -140,6 +140,20 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
     return w4_packed_fused(dtype, prologue, gate, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
 }
 
+int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || N % 4 != 0 || lda < K ||
+        ldc < N / 2)
+        return QL_ERR_BAD_SHAPE;
+    if (!aligned(packed, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
+    // the epilogue lives in the few-row kernel without K slabs (wide first MLP projections, 3..32 rows)
+    if (!w4_rows_use_gemm(M, N, K) || !w4_fewrow_supported(M, N, K) || w4_fewrow_workspace_bytes(M, N, K) != 0 || N % 32 != 0)
+        return QL_ERR_UNSUPPORTED;
+    return w4_fewrow(dtype, A, packed, bias, C, M, N, K, lda, ldc, nullptr, 0, (hipStream_t)stream, true);
+}
+
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
                                       int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !packed || !C || !residual) return QL_ERR_NULL_POINTER;

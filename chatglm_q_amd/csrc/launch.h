@@ -74,7 +74,7 @@ size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K);   // of which
 bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K);
 size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // w4_packed.hip: GEMV or GEMM for this row count
+              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate = false);   // w4_packed.hip: GEMV or GEMM for this row count
 
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,

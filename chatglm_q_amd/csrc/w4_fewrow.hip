@@ -23,7 +23,7 @@ template <typename T, int KW, int NT, int MT>
 __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wm,
                                                             const T* __restrict__ Sm, int M, int N, int K, int G, int64_t lda,
                                                             int per, const T* __restrict__ bias, T* __restrict__ C,
-                                                            int64_t ldc, float* __restrict__ part) {
+                                                            int64_t ldc, float* __restrict__ part, int gate) {
     // (argument order: the leading 14 dwords - what the first loads need - are preloaded into SGPRs at wave launch)
     typedef Mma<T> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // KW x 2 x 4 KB A tiles; reused for the reduction
@@ -207,6 +207,23 @@ __global__ __launch_bounds__(KW * 64) void w4_fewrow_kernel(const T* __restrict_
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n_raw = n_base + 32 * t;
+        if (gate) {
+            // SiLU * gate epilogue (chatglm_q/model.py:200-201) on gate-interleaved columns: lanes j % 4 = 0, 1 hold
+            // h, lanes 2, 3 the gate of the same output pair; C gets N / 2 columns.  N % 32 == 0, no K slabs.
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float y = Act<T>::round(acc[mt][t][i]);
+                    if (bias) y = Act<T>::round(y + bias_t[t]);
+                    const float yg = __shfl_down(y, 2);       // every lane takes part
+                    const int m = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                    if (m < M && (j & 2) == 0)
+                        Act<T>::store(C + (int64_t)m * ldc + ((n_raw >> 2) << 1) + (j & 1),
+                                      Act<T>::round(Act<T>::round(y / (1.0f + __expf(-y))) * yg));
+                }
+            continue;
+        }
         if (n_raw >= N) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -261,7 +278,7 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 
 template <typename T, int NT, int MT>
 static int launch_fewrow_nt(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                            int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+                            int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
     constexpr int KW = kFewRowWaves;
     const FewRowPlan plan = fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     const W4Layout L = w4_layout(N, K, sizeof(T));
@@ -269,11 +286,12 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
     const u32x4* Wt = (const u32x4*)((const char*)packed + L.off_wm);
     const T* Sp = (const T*)((const char*)packed + L.off_sm);
     float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
+    if (gate && (part || N % 32 != 0)) return QL_ERR_UNSUPPORTED;   // the gate epilogue lives in this kernel only
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
     constexpr size_t lds = (size_t)KW * 8192 * MT;
     static_assert((KW - 1) * MT * NT * 16 * 64 * 4 <= KW * 8192 * MT, "reduction scratch fits in the A buffers");
     w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
-                                                            (const T*)bias, (T*)C, ldc, part);
+                                                            (const T*)bias, (T*)C, ldc, part, gate ? 1 : 0);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
@@ -283,15 +301,15 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
 
 template <typename T>
 static int launch_fewrow(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                         int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    return launch_fewrow_nt<T, 1, 1>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+                         int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
+    return launch_fewrow_nt<T, 1, 1>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
 }
 
 int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
     switch (dtype) {
-    case QL_DTYPE_F16: return launch_fewrow<f16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st);
-    case QL_DTYPE_BF16: return launch_fewrow<__bf16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_F16: return launch_fewrow<f16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
+    case QL_DTYPE_BF16: return launch_fewrow<__bf16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

@@ -194,6 +194,26 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     return c
 
 
+def w4_forward_gated(a: Tensor, gated_packed: Tensor, n_out: int, bias: Tensor | None) -> Tensor | None:
+    """Few rows (3..32) through a gate-interleaved first MLP projection with SiLU * gate in the kernel's epilogue
+    (``qlinear_w4g32_fwd_packed_gated``): (..., K) -> (..., n_out / 2).  None when the library does not serve the
+    shape that way (the caller then runs the projection and ``silu_mul`` separately)."""
+    lib = _lib.get_lib()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8:
+        a2 = a2.contiguous()
+    c = torch.empty((a2.shape[0], n_out // 2), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_packed_gated(a2.data_ptr(), gated_packed.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                                a2.shape[0], n_out, K, a2.stride(0), n_out // 2,
+                                                _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w4g32_fwd_packed_gated")
+    return c.reshape(*a.shape[:-1], n_out // 2)
+
+
 def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, residual: Tensor) -> Tensor:
     """One-row forward added to the residual stream in the kernel's epilogue: round(y + residual), y = the layer's
     rounded output (``qlinear_w4g32_fwd_packed_residual``)."""

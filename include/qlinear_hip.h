@@ -165,6 +165,14 @@ int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t 
 int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Few rows (batched decode: 3..32) through a first MLP projection with the SiLU * gate EPILOGUE: `packed` holds the
+ * gate-interleaved column order (h_2t, h_2t+1, gate_2t, gate_2t+1), C gets N / 2 columns,
+ * C[m, 2t+i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias, rounded) - chatglm_q/model.py:200-201.
+ * QL_ERR_UNSUPPORTED when the shape is not served by the few-row kernel without K slabs (N % 32 != 0, narrow
+ * matrices, other row counts): run qlinear_w4g32_fwd_packed + qlinear_silu_mul instead.  fp16 / bf16. */
+int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldc, int dtype, void* stream);
+
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
  * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then

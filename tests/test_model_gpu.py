@@ -249,6 +249,37 @@ def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatc
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [3, 8, 32])
+def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
+    """qlinear_w4g32_fwd_packed_gated (few rows, SiLU * gate in the MFMA kernel's epilogue) against the projection
+    followed by silu_mul: same sums, same rounding sequence - bit for bit; unsupported shapes report None."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(7 + M)
+    K, hidden = 4096, 13696
+    layer = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(M, 1, K, device=DEV, generator=g).to(dtype)
+    gp, gb = layer.gated_packed(hidden)
+    got = H4.w4_forward_gated(x, gp, 2 * hidden, gb)
+    with torch.no_grad():
+        want = F_.silu_mul(layer(x), hidden)
+    assert got is not None and got.shape == (M, 1, hidden)
+    assert torch.equal(got, want)
+    # narrow matrices take K slabs + a reduce launch: not served
+    small = DynamicQuantizeLinear(4096, 512, bias=False, dtype=dtype, device=DEV)
+    small.weight.copy_(torch.randint(0, 256, small.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    small.weight_scale.fill_(0.01)
+    sp, _ = small.gated_packed(256)
+    assert H4.w4_forward_gated(x, sp, 512, None) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("nk", [(4096, 4096), (4096, 13696), (250, 96), (8, 64)])
 def test_residual_epilogue_and_norm_prologue_equal_separate_ops(dtype, bias, nk):
     """qlinear_w4g32_fwd_packed_residual = layer(x) + h (three rounded operations, chatglm_q/model.py:243,245), and the
