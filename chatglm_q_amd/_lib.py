@@ -94,12 +94,26 @@ class QLinearLibraryMissing(RuntimeError):
 
 _lib = None
 _load_error: Exception | None = None
+_load_stamp = None      # (exists, mtime) of LIB_PATH when the last attempt failed
+
+
+def _lib_stamp():
+    try:
+        return (True, os.stat(LIB_PATH).st_mtime_ns)
+    except OSError:
+        return (False, 0)
 
 
 def _try_load():
-    global _lib, _load_error
-    if _lib is not None or _load_error is not None:
+    """dlopen once; a FAILED attempt is retried when the file appears or changes (e.g. the package was imported
+    before ``__graft_entry__.build()`` ran in the same process)."""
+    global _lib, _load_error, _load_stamp
+    if _lib is not None:
         return
+    stamp = _lib_stamp()
+    if _load_error is not None and stamp == _load_stamp:
+        return
+    _load_error, _load_stamp = None, stamp
     try:
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
@@ -156,3 +170,24 @@ def stream_ptr(device: torch.device) -> int:
 
 def ptr(t: torch.Tensor | None):
     return None if t is None else t.data_ptr()
+
+
+def buffer_key(*tensors):
+    """Identity + version of the canonical buffers a derived (non-persistent) layout was built from.
+
+    ``Tensor._version`` notices every in-place op that goes through autograd's bookkeeping - the reference loader's
+    ``state_dict()[k].copy_(...)`` (chatglm_q/loader.py:103), ``apply_weights_``, ``.to()`` (new storage).  It does NOT
+    notice writes through ``.data`` / raw pointers, and inference tensors (created under ``torch.inference_mode()``) have
+    no version counter at all: for those the key falls back to identity only, and whoever rewrites such a buffer in
+    place must call the module's ``invalidate()``."""
+    key = []
+    for t in tensors:
+        if t is None:
+            key.append(None)
+            continue
+        try:
+            ver = t._version
+        except RuntimeError:            # "Inference tensors do not track version counter"
+            ver = -1
+        key.append((t.data_ptr(), ver, t.dtype, t.device, tuple(t.shape)))
+    return tuple(key)

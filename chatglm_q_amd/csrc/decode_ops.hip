@@ -900,7 +900,7 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const T* __restric
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-        tok[blockIdx.x] = besti;
+        tok[blockIdx.x] = besti == 0x7fffffff ? 0 : besti;    // an all-NaN row compares false everywhere: stay in range
         pos[blockIdx.x] += 1;
         if (blockIdx.x == 0) {                       // the shared write index and every row's mask: one writer, no race
             const int64_t nw = write_index[0] + 1;

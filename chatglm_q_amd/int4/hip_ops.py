@@ -43,6 +43,23 @@ def _check_w4_args(a: Tensor, b: Tensor, b_scale: Tensor):
         raise AssertionError(f"b_scale.device={b_scale.device}, a.device={a.device}")
 
 
+def _check_row_operands(what: str, a: Tensor, K: int, **operands: Tensor | None):
+    """Checks of the internal fast paths that bypass ``_check_w4_args`` / ``_check_w8_args`` (derived layouts, fused
+    one-row launches): the kernels reinterpret scale / bias / residual / norm-weight memory in the ACTIVATION dtype, so
+    a dtype or device mismatch would silently compute garbage (the reference asserts the same, triton_ops.py:104-111)."""
+    if a.get_device() < 0:
+        raise AssertionError(f"{what}: activations must be on a GPU")
+    if a.shape[-1] != K:
+        raise AssertionError(f"{what}: K mismatch: activations have {a.shape[-1]}, weights {K}")
+    for name, t in operands.items():
+        if t is None:
+            continue
+        if t.dtype != a.dtype:
+            raise AssertionError(f"{what}: {name} dtype {t.dtype} != activation dtype {a.dtype}")
+        if t.device != a.device:
+            raise AssertionError(f"{what}: {name}.device={t.device}, a.device={a.device}")
+
+
 def _rows(a: Tensor) -> Tensor:
     """Flatten leading dims to (M, K) with unit inner stride (the C ABI takes lda explicitly)."""
     a2 = a.reshape(-1, a.shape[-1])
@@ -83,6 +100,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     ``strict`` (default: env QLINEAR_STRICT) asks for the reference's per-weight rounding bit for bit
     (the canonical-layout kernel always rounds that way)."""
     _check_w4_args(a, b, b_scale)
+    _check_row_operands("w4_forward", a, a.shape[-1], bias=bias)
     lib = _lib.get_lib()
     out_shape = (*a.shape[:-1], b.shape[1])
     a2 = _rows(a)
@@ -184,6 +202,9 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     K = a.shape[-1] // 2 if (kind & 0xFF) == _lib.PRO_SILU else a.shape[-1]
     if a.numel() != a.shape[-1]:
         raise ValueError("fused prologues serve exactly one activation row")
+    _check_row_operands("w4_forward_fused", a, a.shape[-1], bias=bias, delta=delta, ln_weight=ln_weight, hout=hout)
+    if packed.device != a.device or packed.numel() < packed_nbytes(n_out, K, a.dtype):
+        raise AssertionError("w4_forward_fused: packed buffer on another device or too small for (n_out, K)")
     a = a.contiguous()
     c = torch.empty((*a.shape[:-1], n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out), device=a.device, dtype=a.dtype)
     with torch.cuda.device(a.device):
@@ -200,6 +221,9 @@ def w4_forward_gated(a: Tensor, gated_packed: Tensor, n_out: int, bias: Tensor |
     shape that way (the caller then runs the projection and ``silu_mul`` separately)."""
     lib = _lib.get_lib()
     K = a.shape[-1]
+    _check_row_operands("w4_forward_gated", a, K, bias=bias)
+    if gated_packed.device != a.device or gated_packed.numel() < packed_nbytes(n_out, K, a.dtype):
+        raise AssertionError("w4_forward_gated: packed buffer on another device or too small for (n_out, K)")
     a2 = a.reshape(-1, K)
     if a2.stride(1) != 1 or a2.stride(0) % 8:
         a2 = a2.contiguous()
@@ -220,6 +244,9 @@ def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | No
     lib = _lib.get_lib()
     if a.numel() != a.shape[-1] or residual.numel() != n_out:
         raise ValueError("the residual epilogue serves exactly one row")
+    _check_row_operands("w4_forward_residual", a, a.shape[-1], bias=bias, residual=residual)
+    if packed.device != a.device or packed.numel() < packed_nbytes(n_out, a.shape[-1], a.dtype):
+        raise AssertionError("w4_forward_residual: packed buffer on another device or too small for (n_out, K)")
     a = a.contiguous()
     residual = residual.contiguous()
     c = torch.empty((*a.shape[:-1], n_out), device=a.device, dtype=a.dtype)

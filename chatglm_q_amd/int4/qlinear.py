@@ -110,11 +110,26 @@ class DynamicQuantizeLinear(nn.Module):
         # never registered, never saved (SURVEY.md 8b "Buffer ownership")
         self._packed: Tensor | None = None
         self._packed_key = None
+        self._gated, self._gated_key = None, None
 
     # -- derived layout -----------------------------------------------------------------------
     def _canonical_key(self):
-        w, s = self.weight, self.weight_scale
-        return (w.data_ptr(), w._version, s.data_ptr(), s._version, s.dtype, w.device)
+        return _lib.buffer_key(self.weight, self.weight_scale)
+
+    def invalidate(self):
+        """Drop every derived layout; the next GPU forward rebuilds them from the canonical buffers.  Needed only
+        after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
+        self._packed, self._packed_key = None, None
+        self._gated, self._gated_key = None, None
+        return self
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): new storage (whose address may be a reused one)
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def _packed_supported(self) -> bool:
         return (W4_LAYOUT != "canonical" and self.group_size == 32 and self.weight.is_cuda
@@ -140,7 +155,7 @@ class DynamicQuantizeLinear(nn.Module):
         ``_packed`` and never part of the state_dict."""
         if self.out_features != 2 * hidden or not self._packed_supported():
             raise ValueError("gated layout needs a supported (K, 2 * hidden) int4g32 weight")
-        key = self._canonical_key()
+        key = (self._canonical_key(), _lib.buffer_key(self.bias))
         if getattr(self, "_gated", None) is None or self._gated_key != key:
             perm = hip_ops.gate_interleave(hidden, self.weight.device)
             packed = hip_ops.repack_w4g32(self.weight.index_select(1, perm), self.weight_scale.index_select(1, perm))
@@ -174,6 +189,7 @@ class DynamicQuantizeLinear(nn.Module):
         self.weight_scale.copy_(scale)
         if bias is not None:
             self.bias.copy_(bias)
+        self.invalidate()
 
     def extra_repr(self) -> str:
         return "in_features={}, out_features={}, group_size={}, bias={}".format(

@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from .. import _lib
-from ..int4.hip_ops import _rows
+from ..int4.hip_ops import _check_row_operands, _rows
 
 
 def check_input(a: Tensor) -> bool:
@@ -44,6 +44,7 @@ def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     """``a @ (b * b_scale) (+ bias)``; ``b`` is the logical (K, N) int8 matrix with ANY strides - the
     module passes ``weight.t()`` (strides (1, K)), the reference test a contiguous (K, N)."""
     _check_w8_args(a, b, b_scale)
+    _check_row_operands("w8_forward", a, a.shape[-1], bias=bias)
     lib = _lib.get_lib()
     out_shape = (*a.shape[:-1], b.shape[1])
     a2 = _rows(a)
@@ -101,6 +102,11 @@ def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias
     lib = _lib.get_lib()
     a2 = _rows(a)
     M, K = a2.shape
+    _check_row_operands("w8_forward_tiled", a, K, w_scale=w_scale, bias=bias)
+    if w_scale.shape != (n_out,) or (bias is not None and bias.shape != (n_out,)):
+        raise AssertionError(f"w8_forward_tiled: scale / bias must have shape ({n_out},)")
+    if tiled.device != a.device or tiled.numel() != int(lib.qlinear_w8_tiled_bytes(n_out, K)):
+        raise AssertionError(f"w8_forward_tiled: tiled copy does not belong to a ({n_out}, {K}) weight on {a.device}")
     c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
     if bias is not None:
         bias = bias.contiguous()
@@ -123,6 +129,9 @@ def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, b
     N, K = weight_nk.shape
     if a.numel() != K:
         raise ValueError("fused prologues serve exactly one activation row")
+    _check_row_operands("w8_forward_fused", a, K, w_scale=w_scale, bias=bias, delta=delta, ln_weight=ln_weight, hout=hout)
+    if weight_nk.dtype != torch.int8 or weight_nk.device != a.device or w_scale.numel() != N:
+        raise AssertionError("w8_forward_fused: weight must be int8 (N, K) on the activations' device with N scales")
     a = a.contiguous()
     c = torch.empty((*a.shape[:-1], N // 2 if kind & _lib.EPI_SILU_GATE else N), device=a.device, dtype=a.dtype)
     with torch.cuda.device(a.device):
@@ -139,6 +148,9 @@ def w8_forward_residual(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Ten
     N, K = weight_nk.shape
     if a.numel() != K or residual.numel() != N:
         raise ValueError("the residual epilogue serves exactly one row")
+    _check_row_operands("w8_forward_residual", a, K, w_scale=w_scale, bias=bias, residual=residual)
+    if weight_nk.dtype != torch.int8 or weight_nk.device != a.device or w_scale.numel() != N:
+        raise AssertionError("w8_forward_residual: weight must be int8 (N, K) on the activations' device with N scales")
     a = a.contiguous()
     residual = residual.contiguous()
     c = torch.empty((*a.shape[:-1], N), device=a.device, dtype=a.dtype)

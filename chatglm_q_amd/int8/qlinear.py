@@ -68,6 +68,23 @@ class DynamicQuantizeLinear(nn.Module):
         else:
             self.register_buffer("bias", None)
         self.act_quant = False
+        self._tiled, self._tiled_key = None, None
+        self._gated, self._gated_key = None, None
+
+    def invalidate(self):
+        """Drop the derived copies (tile-major weights, gate-interleaved rows); rebuilt on the next GPU forward.  Needed
+        only after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
+        self._tiled, self._tiled_key = None, None
+        self._gated, self._gated_key = None, None
+        return self
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): new storage (whose address may be a reused one)
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, input: Tensor):
         if check_input(input) and not (input.requires_grad and torch.is_grad_enabled()):
@@ -86,8 +103,8 @@ class DynamicQuantizeLinear(nn.Module):
     @torch.no_grad()
     def prepare(self):
         """Build (or refresh) the tile-major derived copy now, e.g. before capturing a HIP graph."""
-        key = (self.weight.data_ptr(), self.weight._version)
-        if getattr(self, "_tiled", None) is None or self._tiled_key != key:
+        key = _lib.buffer_key(self.weight)
+        if self._tiled is None or self._tiled_key != key:
             self._tiled = hip_ops.tile_w8(self.weight) if self.weight.is_cuda and self.in_features % 16 == 0 else None
             self._tiled_key = key
         return self
@@ -99,9 +116,8 @@ class DynamicQuantizeLinear(nn.Module):
         QL_EPI_SILU_GATE).  Cached, keyed on the buffers' identity and version; never part of the state_dict."""
         if self.out_features != 2 * hidden:
             raise ValueError("gated layout needs out_features == 2 * hidden")
-        key = (self.weight.data_ptr(), self.weight._version, self.weight_scale.data_ptr(), self.weight_scale._version,
-               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
-        if getattr(self, "_gated", None) is None or self._gated_key != key:
+        key = _lib.buffer_key(self.weight, self.weight_scale, self.bias)
+        if self._gated is None or self._gated_key != key:
             from ..int4.hip_ops import gate_interleave
             perm = gate_interleave(hidden, self.weight.device)
             self._gated = (self.weight.index_select(0, perm).contiguous(), self.weight_scale.index_select(0, perm).contiguous(),
@@ -115,6 +131,7 @@ class DynamicQuantizeLinear(nn.Module):
         self.weight_scale.copy_(scale)
         if bias is not None:
             self.bias.copy_(bias)
+        self.invalidate()
 
     def extra_repr(self) -> str:
         return "in_features={}, out_features={}, bias={}".format(

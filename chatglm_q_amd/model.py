@@ -133,17 +133,28 @@ class ChatGLM2Attention(nn.Module):
         # V are strided VIEWS of the cache (batch stride D, leading dimension G*D: what BLAS takes as-is), so no
         # transposed / broadcast copies are made, and the fp32 softmax takes the cast inside its kernel
         qh = (q / math.sqrt(D)).permute(0, 2, 3, 1, 4).reshape(B, G, Hg * S, D)
-        out = torch.empty((B, G, Hg * S, D), device=q.device, dtype=x_dtype)
+        # autograd (labels -> loss -> backward, chatglm_q/model.py:384-390): the fused softmax is a raw launch with no
+        # graph and bmm(out=) cannot be differentiated - those are inference-only shortcuts
+        grad = torch.is_grad_enabled() and (q.requires_grad or k_all.requires_grad or v_all.requires_grad)
+        fused = (FUSED_DECODE_OPS and not grad and q.is_cuda and q.dtype in (torch.float16, torch.bfloat16)
+                 and q.dtype == x_dtype)
+        out = None if grad else torch.empty((B, G, Hg * S, D), device=q.device, dtype=x_dtype)
+        rows = []
         for b in range(B):
             qk = torch.bmm(qh[b], k_all[b].permute(1, 2, 0)).view(G, Hg, S, T)
-            if FUSED_DECODE_OPS and qk.is_cuda and qk.dtype in (torch.float16, torch.bfloat16) and qk.dtype == x_dtype:
+            if fused:
                 from . import fused_ops
                 p = fused_ops.masked_softmax(qk, None if mask is None else mask[b]).view(G, Hg * S, T)   # add + softmax + cast
             else:
                 if mask is not None:
                     qk = qk + mask[b][None, None]
                 p = F.softmax(qk, dim=-1, dtype=torch.float32).to(x_dtype).view(G, Hg * S, T)
-            torch.bmm(p, v_all[b].permute(1, 0, 2), out=out[b])
+            if grad:
+                rows.append(torch.bmm(p, v_all[b].permute(1, 0, 2)))
+            else:
+                torch.bmm(p, v_all[b].permute(1, 0, 2), out=out[b])
+        if grad:
+            out = torch.stack(rows)
         return out.view(B, G, Hg, S, D).permute(0, 3, 1, 2, 4).reshape(B, S, G * Hg * D)
 
 

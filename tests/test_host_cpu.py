@@ -179,3 +179,48 @@ def test_gpu_tensor_without_library_raises(monkeypatch):
     monkeypatch.setattr(_lib, "_load_error", OSError("simulated missing library"))
     with pytest.raises(_lib.QLinearLibraryMissing):
         _lib.get_lib()
+
+
+def test_derived_layout_keys_survive_inference_tensors_and_invalidate():
+    """Tensor._version raises on inference tensors and misses .data writes; the cache key must not."""
+    from chatglm_q_amd import _lib
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear as Q4
+    from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear as Q8
+    with torch.inference_mode():
+        l4 = Q4(64, 32, bias=True, dtype=torch.float16)
+        l8 = Q8(64, 32, bias=True, dtype=torch.float16)
+        l4.weight.zero_(); l4.weight_scale.fill_(1); l4.bias.zero_()
+        l8.weight.zero_(); l8.weight_scale.fill_(1); l8.bias.zero_()
+    k4 = l4._canonical_key()                 # must not raise "Inference tensors do not track version counter"
+    k8 = _lib.buffer_key(l8.weight, l8.weight_scale, l8.bias)
+    assert k4 == l4._canonical_key() and k8 == _lib.buffer_key(l8.weight, l8.weight_scale, l8.bias)
+    n4 = Q4(64, 32, bias=True, dtype=torch.float16)
+    before = n4._canonical_key()
+    n4.weight.copy_(torch.ones_like(n4.weight))
+    assert n4._canonical_key() != before     # the loader's in-place copy_ is seen
+    # explicit invalidation exists on both modules and is what load_state_dict / apply_weights_ / .to() trigger
+    for mod in (n4, Q8(64, 32, dtype=torch.float16)):
+        mod._gated, mod._gated_key = ("stale",), "k"
+        mod.invalidate()
+        assert mod._gated is None and mod._gated_key is None
+        mod._gated = ("stale",)
+        mod.load_state_dict(mod.state_dict())
+        assert mod._gated is None
+        mod._gated = ("stale",)
+        mod.to(torch.float16)
+        assert mod._gated is None
+
+
+def test_lib_load_is_retried_when_the_file_changes(tmp_path, monkeypatch):
+    """a failed dlopen must not be cached forever (package imported before build())."""
+    from chatglm_q_amd import _lib
+    real = _lib.LIB_PATH
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_load_error", None)
+    monkeypatch.setattr(_lib, "_load_stamp", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    assert not _lib.available()
+    with pytest.raises(_lib.QLinearLibraryMissing):
+        _lib.get_lib()
+    monkeypatch.setattr(_lib, "LIB_PATH", real)          # "the build finished": path now resolves, stamp differs
+    assert _lib.available()

@@ -107,3 +107,24 @@ def test_generate_greedy_equals_reference_shaped_loop():
     stop = next(i for i, t in enumerate(want) if i > 0 and t not in want[:i])
     dec_eos = ChatGLMDecoder(None, model, eos_token_id=want[stop])
     assert list(dec_eos.generate_ids(prefix, max_generated_tokens=10, greedy=True)) == want[:stop + 1]
+
+
+def test_reference_training_contract_labels_loss_backward():
+    """chatglm_q/model.py:384-390: forward(labels=...) returns a loss that backpropagates (P-tuning / LoRA through the
+    frozen quantized weights).  The inference shortcuts of the attention core (bmm(out=), fused softmax launch) must
+    step aside when autograd is recording."""
+    model, cfg = build("f32")
+    model.train()
+    ids = torch.from_numpy(Z["f32/ids"])
+    loss, logits, kv = model(input_ids=ids, labels=ids)
+    assert loss.requires_grad and torch.isfinite(loss)
+    loss.backward()
+    g = model.layers[0].attn_ln.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    emb = model.word_embedding(ids).detach().requires_grad_(True)
+    loss2, _, _ = model(input_embeddings=emb, labels=ids)
+    loss2.backward()
+    assert emb.grad is not None and emb.grad.abs().sum() > 0
+    with torch.no_grad():
+        _, ref_logits, _ = model(input_ids=ids)
+    assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)      # same function with and without the graph
