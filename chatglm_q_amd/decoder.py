@@ -64,34 +64,54 @@ class DecodeSession:
         self.write_index = torch.zeros(1, dtype=torch.long, device=dev)
         self.pos = torch.zeros(batch, 1, dtype=torch.long, device=dev)
         self.mask = torch.full((batch, 1, capacity), -1e10, dtype=torch.float32, device=dev)
+        self.pad_cols = torch.zeros(batch, capacity, dtype=torch.bool, device=dev)   # left-padding columns (never attended)
+        self.n_tokens = torch.zeros(batch, dtype=torch.long, device=dev)             # real tokens per sequence so far
         self.logits: Optional[Tensor] = None
         self.graph = None
         self.length = 0
 
     # -- prefill -------------------------------------------------------------------------------------
     @torch.no_grad()
-    def prefill(self, ids: Tensor, chunk: Optional[int] = None) -> Tensor:
-        """ids (batch, S).  Returns the last position's logits (batch, vocab)."""
+    def prefill(self, ids: Tensor, chunk: Optional[int] = None, attention_mask: Optional[Tensor] = None) -> Tensor:
+        """ids (batch, S).  Returns the last position's logits (batch, vocab).
+
+        ``attention_mask`` (batch, S), 1 = token / 0 = pad, follows the reference's convention for batches of unequal
+        length (chatglm_q/model.py:297-318): sequences are LEFT padded, a pad column is masked for every query
+        (``causal | ~attention_mask``) and a token's rotary position is its count among the real tokens
+        (``cumsum(attention_mask)``: 1-based, pads get 0).  The pad columns stay masked through later chunks and
+        decode steps."""
         B, S = ids.shape
         if S + self.length > self.capacity:
             raise ValueError(f"sequence {S + self.length} exceeds the cache capacity {self.capacity}")
         ids = ids.to(self.device)
+        if attention_mask is None:
+            valid = torch.ones(B, S, dtype=torch.bool, device=self.device)
+        else:
+            if attention_mask.shape != ids.shape:
+                raise ValueError(f"attention_mask {tuple(attention_mask.shape)} != ids {tuple(ids.shape)}")
+            valid = attention_mask.to(self.device).bool()
+        self.pad_cols[:, self.length:self.length + S] = ~valid
+        positions = self.n_tokens[:, None] + torch.cumsum(valid.long(), dim=1)       # 1-based among real tokens
+        positions = torch.where(valid, positions, torch.zeros_like(positions))       # cumsum of a left pad is 0
         chunk = chunk or S
         t = torch.arange(self.capacity, device=self.device)
         logits = None
         for s0 in range(0, S, chunk):
             s1 = min(S, s0 + chunk)
             rows = torch.arange(self.length + s0, self.length + s1, device=self.device)
-            mask = ((t[None, :] > rows[:, None]).float() * -1e10)[None].expand(B, -1, -1)
-            logits = self.model.step(ids[:, s0:s1], self.cache, rows, (rows + 1)[None].expand(B, -1), mask,
+            blocked = (t[None, None, :] > rows[None, :, None]) | self.pad_cols[:, None, :]
+            mask = blocked.float() * -1e10
+            logits = self.model.step(ids[:, s0:s1], self.cache, rows, positions[:, s0:s1], mask,
                                      last_only=True, kv_len=self.length + s1)
         self.length += S
         self.cache.length = self.length
+        self.n_tokens += valid.long().sum(dim=1)
         # arm the decode-step state
         self.write_index.fill_(self.length)
-        self.pos.fill_(self.length + 1)                         # positions are 1-based (model.py:308)
+        self.pos.copy_((self.n_tokens + 1)[:, None])            # positions are 1-based (model.py:308)
         self.mask.fill_(-1e10)
         self.mask[:, :, : self.length + 1] = 0.0                # incl. the position the next step writes
+        self.mask.masked_fill_(self.pad_cols[:, None, :], -1e10)
         return logits[:, -1]
 
     # -- one decode step -------------------------------------------------------------------------------

@@ -45,3 +45,45 @@ def to_torch(arr, dtype: str):
     if arr.dtype in (np.uint8, np.int8, np.int32, np.int64):
         return torch.from_numpy(np.ascontiguousarray(arr))
     return torch.from_numpy(np.ascontiguousarray(arr).astype(np.float32)).to(tdt)
+
+
+# ---- real-dimension ChatGLM2 fixture (tests/golden/real_model.npz) --------------------------------------------
+# ChatGLM2-6B layer geometry (hidden 4096, FFN 13696, 32 heads x 128, 2 key/value groups) with 2 layers and a
+# 1024-token vocabulary.  The int4g32 buffers are ~410 MB, so the fixture stores NO weights: both the generator
+# (tests/golden/make_golden.py, which fills the REFERENCE model) and the tests (which fill the build's model) call
+# fill_seeded_() - every buffer is a pure function of (seed, its state_dict key, shape, dtype) drawn from a CPU
+# torch.Generator, independent of iteration order.
+REAL_DIM_CONFIG = dict(hidden_size=4096, inner_hidden_size=13696, head_hidden_size=128, num_multi_query_groups=2,
+                       num_attention_heads=32, num_layers=2, vocab_size=1024, max_sequence_length=2304)
+REAL_DIM_SEED = 8100
+
+
+def fill_seeded_(state_dict, seed: int = REAL_DIM_SEED):
+    """In-place synthetic int4g32 weights: nibbles uniform over 1..15, i.e. q = n - 8 uniform over -7..7 and ZERO MEAN
+    (uniform 0..15 gives every weight matrix a rank-one mean component that swamps the input-dependent part of the
+    logits and would make a logit comparison insensitive), scales sized so activations stay O(1)."""
+    import math
+    import zlib
+
+    import torch
+    with torch.no_grad():
+        for key in sorted(state_dict.keys()):
+            buf = state_dict[key]
+            gen = torch.Generator().manual_seed(seed + zlib.crc32(key.encode()))
+            if buf.dtype == torch.uint8:
+                lo = torch.randint(1, 16, buf.shape, dtype=torch.uint8, generator=gen)
+                val = lo | (torch.randint(1, 16, buf.shape, dtype=torch.uint8, generator=gen) << 4)
+            elif key.endswith("weight_scale"):
+                if key.startswith("word_embedding"):
+                    amp = 0.25                                    # embedding rows ~ unit variance
+                else:
+                    amp = 1.0 / (4.32 * math.sqrt(buf.shape[0] * 32))  # q uniform over -7..7 has std 4.32
+                val = (torch.rand(buf.shape, generator=gen) * 0.5 + 0.75) * amp
+            elif key.endswith("bias"):
+                val = torch.randn(buf.shape, generator=gen) * 0.05
+            elif "ln" in key:
+                val = 1.0 + 0.1 * torch.randn(buf.shape, generator=gen)
+            else:
+                raise KeyError(f"unexpected state_dict entry {key}")
+            buf.copy_(val.to(buf.dtype))
+    return state_dict

@@ -345,6 +345,99 @@ def gen_model():
     np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **d)
 
 
+def gen_model_real():
+    """ChatGLM2-6B LAYER DIMENSIONS (hidden 4096, FFN 13696, 32 heads x 128, 2 groups; 2 layers, vocab 1024), fp16,
+    through the reference model on CPU.  Weights come from tests/_golden.py::fill_seeded_ (a pure function of the
+    state_dict keys) so that only ids / logits / cache samples are stored.  Cases:
+      b1   batch 1: prefill of 9 ids, then 3 cached decode steps (BASELINE config 4's call pattern)
+      b4   batch 4, LEFT padded (chatglm_q/model.py:297-318), chunked prefill 3 x 8 positions, 2 decode steps
+      big  batch 4 x 2048 positions, left padded, chunked prefill 4 x 512 (BASELINE config 5's workload)"""
+    sys.path.insert(0, os.path.dirname(OUT))                        # tests/
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))       # repo root (tests/_golden.py imports oracle/)
+    import _golden as G
+    from chatglm_q import model as refm
+    from chatglm_q import loader as refl
+    cfg = refm.ChatGLM2Config(**G.REAL_DIM_CONFIG)
+    torch.set_num_threads(8)
+    m = refl.create_quant_int4_model(cfg, dtype=torch.float16)
+    G.fill_seeded_(m.state_dict())
+    m.eval()
+    d = {}
+    gen = torch.Generator().manual_seed(8200)
+    V = cfg.vocab_size
+
+    def run(ids, attn, chunks, past=None):
+        """Feed ids[:, c0:c1] chunk by chunk with the growing attention mask; returns (list of logits, kv)."""
+        outs, n0 = [], 0 if past is None else past[0][0].shape[1]
+        for c0, c1 in chunks:
+            with torch.no_grad():
+                _, lg, past = m(input_ids=ids[:, c0:c1], attention_mask=None if attn is None else attn[:, : n0 + c1],
+                                past_key_values=past)
+            outs.append(lg)
+        return outs, past
+
+    # ---- b1 ---------------------------------------------------------------------------------------------------
+    ids = torch.randint(0, V, (1, 9), generator=gen)
+    nxt = torch.randint(0, V, (3,), generator=gen)
+    (lg,), kv = run(ids, None, [(0, 9)])
+    d["b1/ids"] = ids.numpy(); d["b1/next_ids"] = nxt.numpy()
+    put(d, "b1/prefill_logits", lg)
+    for t in range(3):
+        with torch.no_grad():
+            _, lg, kv = m(input_ids=nxt[t].view(1, 1), past_key_values=kv)
+        put(d, f"b1/decode_logits_{t}", lg[:, -1])
+    put(d, "b1/kv1_k", kv[1][0]); put(d, "b1/kv1_v", kv[1][1])           # (1, 12, 2, 1, 128) each
+    print("b1 done")
+
+    # ---- b4: left padded, chunked ------------------------------------------------------------------------------
+    S, lens = 24, [24, 17, 9, 21]
+    ids = torch.randint(0, V, (4, S), generator=gen)
+    attn = torch.zeros(4, S + 2, dtype=torch.long)
+    for b, n in enumerate(lens):
+        attn[b, S - n:] = 1
+        ids[b, : S - n] = 0
+    outs, kv = run(ids, attn, [(0, 8), (8, 16), (16, 24)])
+    (full,), _ = run(ids, attn, [(0, 24)])
+    print("b4 chunked-vs-full last-logit rel", (outs[-1][:, -1].float() - full[:, -1].float()).norm().item()
+          / full[:, -1].float().norm().item())
+    d["b4/ids"] = ids.numpy(); d["b4/attention_mask"] = attn.numpy()
+    put(d, "b4/last_chunk_logits", outs[-1])                              # (4, 8, 1024)
+    nxt = torch.randint(0, V, (2, 4), generator=gen)
+    d["b4/next_ids"] = nxt.numpy()
+    for t in range(2):
+        with torch.no_grad():
+            _, lg, kv = m(input_ids=nxt[t].view(4, 1), attention_mask=attn[:, : S + t + 1], past_key_values=kv)
+        put(d, f"b4/decode_logits_{t}", lg[:, -1])
+    put(d, "b4/kv1_k", kv[1][0]); put(d, "b4/kv1_v", kv[1][1])           # (4, 26, 2, 1, 128)
+    print("b4 done")
+
+    # ---- big: config 5's workload -------------------------------------------------------------------------------
+    S, lens = 2048, [2048, 1900, 1024, 2048]
+    ids = torch.randint(0, V, (4, S), generator=gen)
+    attn = torch.zeros(4, S, dtype=torch.long)
+    for b, n in enumerate(lens):
+        attn[b, S - n:] = 1
+        ids[b, : S - n] = 0
+    import time
+    t0 = time.time()
+    outs, kv = run(ids, attn, [(0, 512), (512, 1024), (1024, 1536), (1536, 2048)])
+    print("big done in", time.time() - t0, "s")
+    d["big/ids"] = ids.numpy().astype(np.int16); d["big/lens"] = np.array(lens)
+    put(d, "big/last_logits", outs[-1][:, -1])                            # (4, 1024)
+    rows = torch.tensor([0, 100, 255, 511])
+    d["big/sample_rows"] = rows.numpy()
+    put(d, "big/chunk1_logits", outs[1][:, rows])                         # positions 512 + rows: (4, 4, 1024)
+    put(d, "big/chunk3_logits", outs[3][:, rows])
+    pos = torch.tensor([0, 1023, 1024, 2047])
+    d["big/kv_positions"] = pos.numpy()
+    put(d, "big/kv1_k", kv[1][0][:, pos]); put(d, "big/kv1_v", kv[1][1][:, pos])
+    d["config"] = np.array([G.REAL_DIM_CONFIG[k] for k in ("hidden_size", "inner_hidden_size", "head_hidden_size",
+                                                           "num_multi_query_groups", "num_attention_heads", "num_layers",
+                                                           "vocab_size", "max_sequence_length")])
+    d["seed"] = np.array([G.REAL_DIM_SEED])
+    np.savez_compressed(os.path.join(OUT, "real_model.npz"), **d)
+
+
 def gen_backward():
     """grad_A of both quantized matmuls through the reference's own autograd functions (CPU route:
     chatglm_q/int4/qlinear.py:53-64, chatglm_q/int8/qlinear.py:41-52)."""
@@ -400,11 +493,11 @@ def gen_loader():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "backward", "loader"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "backward", "loader"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model, "backward": gen_backward, "loader": gen_loader}[w]()
+         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "backward": gen_backward, "loader": gen_loader}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
