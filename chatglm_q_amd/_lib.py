@@ -13,12 +13,14 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqlinear_hip.so")
+# QLINEAR_LIB_PATH: developer override (tools/: ablation builds of the same library); the package default is the in-tree build
+LIB_PATH = os.environ.get("QLINEAR_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip.so")
 ABI_VERSION = 1
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 FLAG_STRICT_ROUNDING = 1
+FLAG_ACT_PER_TENSOR = 2
 
 # QLINEAR_STRICT=1: reproduce the reference's per-weight rounding bit for bit in every kernel
 STRICT_DEFAULT = os.environ.get("QLINEAR_STRICT", "0") not in ("0", "", "false", "False")
@@ -34,6 +36,7 @@ OP_W4G32_FWD_PACKED = 2
 OP_W8_FWD = 3
 OP_W8A8_FWD = 4
 OP_W8_FWD_TILED = 5
+OP_W8A8_LINEAR_TILED = 6
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -62,6 +65,9 @@ EXPORTS = {
     "qlinear_w8_bwd_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                      c_int, c_void_p]),
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_act_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "qlinear_w8a8_fwd_tiled": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
+    "qlinear_w8a8_linear_tiled": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_qembedding_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,

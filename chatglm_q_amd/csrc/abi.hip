@@ -66,6 +66,8 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
         return (M > 2 && K % 16 == 0) ? w8_tiled_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8A8_FWD:             // optional too: int32 split-K slabs for shapes with few row tiles
         return K % 16 == 0 ? w8a8_workspace_bytes(M, N, K) : 0;
+    case QL_OP_W8A8_LINEAR_TILED:    // required: Aq (M x K int8, padded to 16 bytes) + a_scale (M floats)
+        return (((size_t)M * (size_t)K + 15) & ~(size_t)15) + (size_t)M * sizeof(float);
     default: return 0;
     }
 }
@@ -241,7 +243,43 @@ int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int6
     if (!A || !Aq || !a_scale) return QL_ERR_NULL_POINTER;
     if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(K) || lda < K) return QL_ERR_BAD_SHAPE;
-    return act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (hipStream_t)stream);
+    return act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, false, (hipStream_t)stream);
+}
+
+int qlinear_act_quant_i8(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda, int dtype, int flags,
+                         void* stream) {
+    if (!A || !Aq || !a_scale) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(K) || lda < K) return QL_ERR_BAD_SHAPE;
+    if (flags & ~QL_FLAG_ACT_PER_TENSOR) return QL_ERR_UNSUPPORTED;
+    return act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (flags & QL_FLAG_ACT_PER_TENSOR) != 0, (hipStream_t)stream);
+}
+
+int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                           int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+    if (!Aq || !a_scale || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (K % 16 != 0) return QL_ERR_UNSUPPORTED;     /* rows are read in 16-byte units */
+    if (!aligned(Aq, 16) || !aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    return w8a8_gemm_tiled(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
+}
+
+int qlinear_w8a8_linear_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                              int64_t K, int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    if (!A || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (K % 16 != 0 || (flags & ~QL_FLAG_ACT_PER_TENSOR)) return QL_ERR_UNSUPPORTED;
+    if (!workspace || !aligned(workspace, 16) || workspace_bytes < qlinear_workspace_bytes(QL_OP_W8A8_LINEAR_TILED, M, N, K, 0))
+        return QL_ERR_WORKSPACE;
+    if (!aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    int8_t* Aq = (int8_t*)workspace;
+    float* a_scale = (float*)((char*)workspace + (((size_t)M * (size_t)K + 15) & ~(size_t)15));
+    const int rc = act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (flags & QL_FLAG_ACT_PER_TENSOR) != 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return w8a8_gemm_tiled(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
 }
 
 int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,

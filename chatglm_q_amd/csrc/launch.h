@@ -139,8 +139,11 @@ int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, con
                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 int w8_gemm_scale_k(int dtype, const void* A, const int8_t* W, const void* S, void* C, int64_t M, int64_t N, int64_t K,
                     int64_t ldw, int64_t lda, int64_t ldc, hipStream_t st);
-int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
+// w8a8.hip
+int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda, bool per_tensor,
                       hipStream_t st);
+int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
+                    int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st);
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
               void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);

@@ -7,8 +7,9 @@
 //   w8_generic_kernel        any strides (incl. the (K, N)-contiguous form the reference test uses)
 //   w8_gemv_kernel           module layout: W (N, K) row-major, K contiguous; one wave owns 4 output
 //                            channels and streams their rows with 16-byte loads (decode shapes)
-//   act_quant_rowwise_kernel row-wise symmetric int8 activation quantisation (fp32 arithmetic)
-//   w8a8_mfma_kernel         i8 x i8 -> i32 on v_mfma_i32_32x32x32_i8, rank-1 scale epilogue
+//   w8a8_mfma_kernel         i8 x i8 -> i32 on v_mfma_i32_32x32x32_i8, rank-1 scale epilogue, weights in the
+//                            module's (N, K) row-major buffer (both operands through LDS); the tile-major
+//                            kernel and the activation quantiser live in w8a8.hip
 #include <stdlib.h>
 
 // developer ablation switches for tools/microbench/w8a8_ablate.hip (always 0 in the library): 1 no MFMA, 2 no
@@ -543,34 +544,6 @@ __global__ __launch_bounds__(256) void w8_gemv_kernel(const T* __restrict__ A, c
 }
 
 // =============================================================================================
-// row-wise int8 activation quantisation (quantize_int8, chatglm_q/int8/quantizer.py:11-19),
-// evaluated in fp32: true divisions and round-half-even so the integers match the oracle exactly.
-// =============================================================================================
-template <typename T>
-__global__ __launch_bounds__(256) void act_quant_rowwise_kernel(const T* __restrict__ A, int8_t* __restrict__ Aq,
-                                                                float* __restrict__ a_scale, int K, int64_t lda) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    const T* a = A + (int64_t)m * lda;
-    float mx = 0.f;
-    for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(Act<T>::load(a + k)));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float s = mx / 127.0f;
-    s = fmaxf(s, 1e-10f);
-    if (tid == 0) a_scale[m] = s;
-    int8_t* q = Aq + (int64_t)m * K;
-    for (int k = tid; k < K; k += 256) {
-        float v = rintf(Act<T>::load(a + k) / s);
-        v = fminf(fmaxf(v, -127.f), 127.f);
-        q[k] = (int8_t)v;
-    }
-}
-
-// =============================================================================================
 // W8A8: C = round(acc_i32 * (a_scale[m] * w_scale[n])) (+ bias), acc = Aq (M,K) . W (N,K)^T
 //   A true int8 x int8 dense GEMM on v_mfma_i32_32x32x32_i8 (exact int32 accumulation).
 //   Both operands are K-contiguous int8.  Block = 4 waves side by side in N (128 output channels) x
@@ -883,13 +856,6 @@ static int launch_w8_gemv_any(int dtype, const W8Args& p) {
     }
 }
 
-template <typename T>
-static int launch_act_quant(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
-                            hipStream_t st) {
-    act_quant_rowwise_kernel<T><<<(unsigned)M, 256, 0, st>>>((const T*)A, Aq, a_scale, (int)K, lda);
-    return finish_launch();
-}
-
 // split-K epilogue of the W8A8 GEMM: exact int32 sum of the slabs, then the rank-1 scale, one rounding, bias
 template <typename T>
 __global__ __launch_bounds__(256) void w8a8_splitk_reduce_kernel(const int* __restrict__ part, const float* __restrict__ a_scale,
@@ -1010,10 +976,6 @@ int w8_gemv_residual(int dtype, const void* A, const int8_t* W, const void* S, c
     W8Args p{false, A, W, S, bias, C, 1, (int)N, (int)K, ldw, K, N, st};
     p.resid = resid;
     return launch_w8_gemv_f16_mb<1>(p);
-}
-int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
-                      hipStream_t st) {
-    QL_DISPATCH_DTYPE(dtype, launch_act_quant, A, Aq, a_scale, M, K, lda, st)
 }
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
               void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {

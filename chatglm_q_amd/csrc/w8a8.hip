@@ -1,0 +1,551 @@
+// int8 activations x int8 weights on the matrix cores (gfx950): BASELINE config 3's path, round 2.
+//
+//   act_quant_rows_kernel     row-wise (or per-tensor) symmetric int8 activation quantisation in ONE pass over the
+//                             row: 16-byte loads, the row stays in registers between the max and the quantise,
+//                             16-byte stores (quantize_int8, chatglm_q/int8/quantizer.py:11-19; per-tensor:
+//                             DynamicQuantizeMatMul.symbolic branch 2, chatglm_q/int8/qlinear.py:64-70)
+//   w8a8_tiled_kernel         acc_i32 = Aq (M,K) . W (N,K)^T on v_mfma_i32_32x32x32_i8, rank-1 scale epilogue
+//                             (chatglm_q/int8/qlinear.py:60-62), with the weights read from the tile-major derived
+//                             copy (qlinear_w8_tile): a lane's 16 bytes ARE its MFMA B fragment, so W never touches
+//                             LDS - only the (shared) activation tile does.
+//
+// Why this shape (numbers for 512 x 4096 x 4096, the configuration the metric is quoted on): one 64 x 128 output tile
+// per CU is the only decomposition that fills 256 CUs without split-K slabs (8 MB of int32 each); it needs
+// (64 + 128) x 4096 = 768 KB per CU through the CU's 64 B/clk vector-memory path, i.e. >= 12.3 k cycles against 8.2 k
+// cycles of MFMA work - the kernel is bound by operand delivery, and everything that is not a load (LDS traffic,
+// barriers, address arithmetic) has to hide behind it.  Round 1's kernel staged BOTH operands through LDS with one
+// wave per SIMD and a block barrier per 128-byte K step (20.7 us).  Here:
+//   * W goes global -> VGPR -> MFMA, 4 KB contiguous per wave and K step, 3-4 steps in flight;
+//   * 8 waves per block = two K-parity groups of 4 waves: group g owns the K steps t = g, g + 2, ...  (int32 partial
+//     sums add exactly; they are combined through LDS once, at the end).  Two waves per SIMD at different phases of
+//     their step fill each other's barrier / LDS-latency gaps - the same total MFMA work, twice the latency hiding;
+//   * the A tile is staged global -> VGPR -> LDS one step ahead, XOR-swizzled so that fragment reads are conflict-free.
+#include <type_traits>
+
+// developer ablation switches for tools/w8a8_ablate.sh (always 0 in the shipped library): 1 no MFMA, 2 no steady-state W
+// loads, 4 no steady-state A loads, 8 no LDS fragment reads, 16 no block barriers in the K loop, 32 no LDS stores
+#ifndef QL_W8A8_ABLATE
+#define QL_W8A8_ABLATE 0
+#endif
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// =============================================================================================
+// activation quantisation
+// =============================================================================================
+// MODE 0: row-wise, scale from this row's maximum, written to a_scale[m]
+// MODE 1: maxima only: a_scale[m] = max_k |A[m,k]| (no quantisation)         - per-tensor pass 1
+// MODE 2: quantise with the scale derived from max(tensor_rowmax[0..M))      - per-tensor pass 2 (a_scale untouched)
+// One block per row, thread t owns VPT adjacent 16-byte vectors (8 values each) of the row.
+template <typename T, int VPT, int MODE>
+__global__ __launch_bounds__(256) void act_quant_rows_kernel(const T* __restrict__ A, int8_t* __restrict__ Aq,
+                                                             float* __restrict__ a_scale, int K, int64_t lda,
+                                                             const float* __restrict__ tensor_rowmax, int M) {
+    static_assert(sizeof(T) == 2, "16-bit activations (fp32 takes the two-pass kernel)");
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int nvec = K >> 3;
+    const u32x4* src = reinterpret_cast<const u32x4*>(A + (int64_t)m * lda);
+    u32x4 r[VPT];
+    float v[VPT][8];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int vi = tid * VPT + u;
+        r[u] = src[vi < nvec ? vi : nvec - 1];                    // clamped: every load unconditional
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        unpack8<T>(r[u], v[u]);
+        if (tid * VPT + u < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[u][e]));
+        }
+    }
+    float s;
+    if constexpr (MODE == 2) {
+        float tm = 0.f;
+        for (int i = tid; i < M; i += 256) tm = fmaxf(tm, tensor_rowmax[i]);
+        mx = tm;
+    }
+    mx = wave_max_dpp(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if constexpr (MODE == 1) {
+        if (tid == 0) a_scale[m] = mx;
+        return;
+    }
+    s = fmaxf(mx / 127.0f, 1e-10f);                               // quantizer.py:18 (clamp keeps 0 / 0 out)
+    if (MODE == 0 && tid == 0) a_scale[m] = s;
+    int8_t* dst = Aq + (int64_t)m * K;
+    u32 packed[VPT][2];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32 w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float q = rintf(v[u][4 * h + e] / s);             // true division, round half to even: bit-exact vs torch
+                q = fminf(fmaxf(q, -127.f), 127.f);
+                w |= ((u32)(int)q & 0xFFu) << (8 * e);
+            }
+            packed[u][h] = w;
+        }
+    }
+    if constexpr (VPT % 2 == 0) {
+#pragma unroll
+        for (int u = 0; u < VPT; u += 2) {
+            const int vi = tid * VPT + u;
+            if (vi + 1 < nvec) {
+                *reinterpret_cast<u32x4*>(dst + (int64_t)vi * 8) = u32x4{packed[u][0], packed[u][1], packed[u + 1][0], packed[u + 1][1]};
+            } else if (vi < nvec) {
+                *reinterpret_cast<u32x2*>(dst + (int64_t)vi * 8) = u32x2{packed[u][0], packed[u][1]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int vi = tid * VPT + u;
+            if (vi < nvec) *reinterpret_cast<u32x2*>(dst + (int64_t)vi * 8) = u32x2{packed[u][0], packed[u][1]};
+        }
+    }
+}
+
+// fp32 activations / rows too long for the register-resident kernel / misaligned rows: two passes over the row
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_quant_rows_generic_kernel(const T* __restrict__ A, int8_t* __restrict__ Aq,
+                                                                     float* __restrict__ a_scale, int K, int64_t lda,
+                                                                     const float* __restrict__ tensor_rowmax, int M) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const T* a = A + (int64_t)m * lda;
+    float mx = 0.f;
+    if constexpr (MODE == 2) {
+        for (int i = tid; i < M; i += 256) mx = fmaxf(mx, tensor_rowmax[i]);
+    } else {
+        for (int k = tid; k < K; k += 256) mx = fmaxf(mx, fabsf(Act<T>::load(a + k)));
+    }
+    mx = wave_max_dpp(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if constexpr (MODE == 1) {
+        if (tid == 0) a_scale[m] = mx;
+        return;
+    }
+    const float s = fmaxf(mx / 127.0f, 1e-10f);
+    if (MODE == 0 && tid == 0) a_scale[m] = s;
+    int8_t* q = Aq + (int64_t)m * K;
+    for (int k = tid; k < K; k += 256) {
+        float v = rintf(Act<T>::load(a + k) / s);
+        v = fminf(fmaxf(v, -127.f), 127.f);
+        q[k] = (int8_t)v;
+    }
+}
+
+// per-tensor pass 3: every a_scale[m] = the one scale (computed from the row maxima BEFORE any of them is overwritten)
+__global__ __launch_bounds__(256) void act_scale_broadcast_kernel(float* __restrict__ a_scale, int M) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (int i = tid; i < M; i += 256) mx = fmaxf(mx, a_scale[i]);
+    mx = wave_max_dpp(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();                                              // every read of a_scale precedes every write
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s = fmaxf(mx / 127.0f, 1e-10f);
+    for (int i = tid; i < M; i += 256) a_scale[i] = s;
+}
+
+template <typename T, int MODE>
+static int launch_act_quant_mode(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda,
+                                 const float* rowmax, hipStream_t st) {
+    const bool vec = sizeof(T) == 2 && K % 8 == 0 && (lda % 8 == 0 || M == 1) && ((uintptr_t)A & 15) == 0 &&
+                     ((uintptr_t)Aq & 15) == 0 && K <= 256 * 8 * 8;
+    if constexpr (sizeof(T) == 2) {
+        if (vec) {
+            const int64_t nvec = K / 8;
+#define QL_AQ(VPT_) act_quant_rows_kernel<T, VPT_, MODE><<<(unsigned)M, 256, 0, st>>>((const T*)A, Aq, a_scale, (int)K, lda, rowmax, (int)M)
+            if (nvec <= 256) QL_AQ(1);
+            else if (nvec <= 512) QL_AQ(2);
+            else if (nvec <= 1024) QL_AQ(4);
+            else QL_AQ(8);
+#undef QL_AQ
+            return finish_launch();
+        }
+    }
+    act_quant_rows_generic_kernel<T, MODE><<<(unsigned)M, 256, 0, st>>>((const T*)A, Aq, a_scale, (int)K, lda, rowmax, (int)M);
+    return finish_launch();
+}
+
+template <typename T>
+static int launch_act_quant(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda, bool per_tensor,
+                            hipStream_t st) {
+    if (!per_tensor) return launch_act_quant_mode<T, 0>(A, Aq, a_scale, M, K, lda, nullptr, st);
+    // per-tensor symmetric (ONNX branch 2): row maxima -> quantise every row with the tensor's scale -> broadcast the scale
+    int rc = launch_act_quant_mode<T, 1>(A, Aq, a_scale, M, K, lda, nullptr, st);
+    if (rc) return rc;
+    rc = launch_act_quant_mode<T, 2>(A, Aq, a_scale, M, K, lda, a_scale, st);
+    if (rc) return rc;
+    act_scale_broadcast_kernel<<<1, 256, 0, st>>>(a_scale, (int)M);
+    return finish_launch();
+}
+
+int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda, bool per_tensor,
+                      hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_act_quant<float>(A, Aq, a_scale, M, K, lda, per_tensor, st);
+    case QL_DTYPE_F16: return launch_act_quant<f16>(A, Aq, a_scale, M, K, lda, per_tensor, st);
+    case QL_DTYPE_BF16: return launch_act_quant<__bf16>(A, Aq, a_scale, M, K, lda, per_tensor, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// =============================================================================================
+// W8A8 GEMM on the tile-major weights
+//   Wm[ct][kt][lane][32 B] (w8_tile_kernel, w8_gemm.hip): lane = 32 kb + j holds bytes k = 64 kt + 32 kb + 0..31 of
+//   output channel 32 ct + j, zero padded.  One 32-deep MFMA sub-step consumes 16 of them: sub-step (u, h) of a
+//   128-byte K step (u = which 64-byte unit, h = which half) uses k = 128 t + 64 u + 32 kb + 16 h + 0..15, so the
+//   A fragment of lane (i, kb) is the 16-byte chunk 4 u + 2 kb + h of row i's 128-byte line (any K assignment that
+//   is the same for both operands is valid: the contraction is a sum over k).
+//   Block = 8 waves: wave w serves column tile (w & 3) of the block's 128 columns and K-parity group (w >> 2).
+//   LDS: per group two A-tile buffers of BM x 128 bytes, chunk c of row r at chunk position 8 r + (c ^ ((r >> 1) & 7)).
+// =============================================================================================
+template <typename T, int MT, int S, int DEPTH>
+__global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
+                                                         int N, int K, int nbx, int rotate, const float* __restrict__ a_scale,
+                                                         const T* __restrict__ S_, const T* __restrict__ bias,
+                                                         T* __restrict__ C, int64_t ldc) {
+    // One loop iteration of a K-parity group covers a CHUNK of BK = 128 S bytes of K (S 128-byte steps = 2 S tile-major
+    // units = 4 S MFMA sub-steps): S = 2 halves the barriers per byte; MT = 4 keeps S = 1 (LDS).
+    constexpr int BM = 32 * MT;
+    constexpr int BK = 128 * S;
+    constexpr int CPR = 8 * S;                         // 16-byte chunks per tile row
+    constexpr int NCH = BM * CPR;                      // chunks per tile
+    constexpr int ACH = (NCH + 255) / 256;             // ... staged per thread (of a group) per iteration
+    constexpr bool kAllStage = NCH % 256 == 0;
+    constexpr int BUF = BM * BK;                       // one A-tile buffer
+    constexpr int NS = 4 * S;                          // MFMA sub-steps per chunk
+    const T* __restrict__ Sc = S_;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
+    const int grp = wave >> 2, wv = wave & 3;                     // tests and the buffer bases then live in SGPRs
+    const int j = lane & 31, kb = lane >> 5;
+    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int ksteps64 = (K + 63) >> 6;                // tile-major units per column tile
+    const int nchunks = (K + BK - 1) / BK;
+    const int niter = (nchunks + 1) >> 1;              // both groups run the same number of iterations (barriers!)
+    const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile.x * 4 + wv;
+    const int8_t* wbase = Wm + ((int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 64 + lane) * 32;
+    char* lds_a = smem + grp * (3 * BUF);
+
+    // swizzle: chunk c of row r sits at chunk position CPR r + (c ^ x(r)); 128-byte rows: x = (r >> 1) & 7, 256-byte
+    // rows (one row = all 64 banks): x = r & 15 - fragment reads (16 lanes = 16 rows, one chunk index) conflict-free
+    auto swz = [](int r) { return S == 1 ? ((r >> 1) & 7) : (r & 15); };
+    const int8_t* a_src[ACH];
+    int a_dst[ACH];
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+        const int q = tg + u * 256, r = (q / CPR) % BM, c = q % CPR;
+        a_src[u] = Aq + (int64_t)((m0 + r < M) ? (m0 + r) : (M - 1)) * K + c * 16;
+        a_dst[u] = (r * CPR + (c ^ swz(r))) * 16;
+    }
+    const int c_mine = tg % CPR;                       // (tg + 256 u) % CPR is the same for every u
+    const int klast = K - 16;                          // last in-bounds 16-byte chunk start (K % 16 == 0)
+    // fragment read offsets: sub-step s = (step, unit, half) reads chunk 8 step + 4 unit + 2 kb + half of row mt * 32 + j;
+    // swz(mt * 32 + j) does not depend on mt, so ONE offset per sub-step serves every row tile (+ mt * 32 rows: immediate)
+    int a_rd[NS];
+#pragma unroll
+    for (int sub = 0; sub < NS; ++sub) {
+        const int c = 8 * (sub >> 2) + 4 * ((sub >> 1) & 1) + 2 * kb + (sub & 1);
+        a_rd[sub] = (j * CPR + (c ^ swz(j))) * 16;
+    }
+
+    i32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0;
+
+    struct Stage {
+        i32x4 a[ACH];                                  // A chunk of iteration (slot's iteration + 2): see below
+        i32x4 w[NS];                                   // W fragments of the slot's iteration
+    };
+    Stage st[DEPTH];
+    // K ROTATION (see the header): block (x, y) starts at phase (2 y + x mod 4) of its K walk.  Measured neutral at
+    // 512 x 4096 x 4096 (19.2 vs 19.4 us) - kept behind QLINEAR_W8A8_ROTATE=1 for experiments, default off.
+    const int phases = niter < 16 ? niter : 16;
+    const int rot = rotate ? ((2 * tile.y + (tile.x & 3)) % phases) * (niter / phases) : 0;
+    auto chunk_of = [&](int i) {                       // K chunk of loop iteration i (i may run past niter: clamped by users)
+        int r = i + rot;
+        r = r >= niter ? r - niter : r;
+        return 2 * r + grp;
+    };
+    auto load_w = [&](int i, Stage& sg) {
+        int t = chunk_of(i < niter ? i : niter - 1);
+        t = t < nchunks ? t : nchunks - 1;
+#pragma unroll
+        for (int u = 0; u < 2 * S; ++u) {
+            int ua = 2 * S * t + u;
+            ua = ua < ksteps64 ? ua : ksteps64 - 1;
+            const int8_t* w0 = wbase + (int64_t)ua * 2048;
+            sg.w[2 * u] = *reinterpret_cast<const i32x4*>(w0);
+            sg.w[2 * u + 1] = *reinterpret_cast<const i32x4*>(w0 + 16);
+        }
+    };
+    auto load_a = [&](int i, i32x4 (&dst)[ACH]) {
+        int t = chunk_of(i < niter ? i : niter - 1);
+        t = t < nchunks ? t : nchunks - 1;
+        const int off = t * BK + c_mine * 16 <= klast ? t * BK : klast - c_mine * 16;
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) dst[u] = *reinterpret_cast<const i32x4*>(a_src[u] + off);
+    };
+    auto store_a = [&](int buf, const i32x4 (&src)[ACH]) {
+#pragma unroll
+        for (int u = 0; u < ACH; ++u)
+            if (!(QL_W8A8_ABLATE & 32) && (kAllStage || tg + u * 256 < NCH))
+                *reinterpret_cast<i32x4*>(lds_a + buf * BUF + a_dst[u]) = src[u];
+    };
+    auto read_a = [&](int buf, int sub, i32x4 (&fr)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (QL_W8A8_ABLATE & 8) fr[mt] = i32x4{a_rd[sub], buf, mt, sub};
+            else fr[mt] = *reinterpret_cast<const i32x4*>(lds_a + buf * BUF + mt * 32 * BK + a_rd[sub]);
+        }
+    };
+    auto mma = [&](const i32x4 (&fa)[MT], const i32x4& w) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (QL_W8A8_ABLATE & 1) acc[mt][0] += fa[mt][0] ^ fa[mt][1] ^ w[0] ^ w[3];
+            else acc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mt], w, acc[mt], 0, 0, 0);
+        }
+    };
+    // Fragments run ONE SUB-STEP AHEAD, across the iteration boundary too: the A tile of iteration i + 1 is complete in
+    // LDS since the barrier that ended iteration i - 1 (three buffers), so its first fragments are requested before the
+    // barrier that ends iteration i and the MFMAs of i + 1 start without an LDS round trip behind the barrier.
+    // (Two sub-steps of lookahead were measured too: 20.9 against 18.9 us at 512 x 4096 x 4096 - the registers cost more
+    // than the LDS latency they hide.)
+    i32x4 fa[2][MT];
+    auto mma_chunk_full = [&](int buf, int nbuf, const i32x4 (&w)[NS]) {
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) {
+            if (sub + 1 < NS) read_a(buf, sub + 1, fa[(sub + 1) & 1]);
+            else read_a(nbuf, 0, fa[0]);
+            mma(fa[sub & 1], w[sub]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);            // next sub-step's DS reads first
+            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);            // then this sub-step's MFMAs
+        }
+    };
+    // last chunk of K (or none left for this group): only `units` of its 2 S tile-major units exist
+    auto mma_chunk_partial = [&](int buf, int nbuf, const i32x4 (&w)[NS], int units) {
+#pragma unroll
+        for (int u = 0; u < 2 * S; ++u) {
+            if (u < units) {                                               // wave-uniform
+                i32x4 f1[MT];
+                if (u > 0) read_a(buf, 2 * u, fa[0]);
+                read_a(buf, 2 * u + 1, f1);
+                mma(fa[0], w[2 * u]);
+                mma(f1, w[2 * u + 1]);
+            }
+        }
+        read_a(nbuf, 0, fa[0]);
+    };
+    auto mma_chunk = [&](int i, int buf, int nbuf, const i32x4 (&w)[NS]) {
+        const int t = chunk_of(i);
+        int units = ksteps64 - 2 * S * t;
+        units = t >= nchunks ? 0 : units;
+        if (units >= 2 * S) mma_chunk_full(buf, nbuf, w);
+        else mma_chunk_partial(buf, nbuf, w, units);
+    };
+
+    // prologue: A tiles of iterations 0 and 1 into LDS, ring slot d <- W of iteration d and A of iteration d + 2.
+    // Request order = need order: the first MFMA needs A(0) and W(0) only.
+    {
+        i32x4 a0[ACH], a1[ACH];
+        load_a(0, a0);
+        load_w(0, st[0]);
+        load_a(1, a1);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (d > 0) load_w(d, st[d]);
+            load_a(d + 2, st[d].a);
+        }
+        store_a(0, a0);
+        store_a(1, a1);
+    }
+    __syncthreads();
+    read_a(0, 0, fa[0]);
+
+    // main loop, unrolled so that ring slot and LDS buffers are compile-time constants.  Iteration i: the A chunk of
+    // iteration i + 2 (in this slot since DEPTH iterations) goes to buffer (i + 2) % 3; MFMAs on buffer i % 3 with the
+    // slot's W fragments; THEN the slot is re-loaded with W of i + DEPTH and A of i + DEPTH + 2 (loading first would need
+    // a register copy of the pending tile, for which hipcc drains vmcnt(0) - seen in the ISA); one barrier.
+    constexpr int U = DEPTH % 3 == 0 ? DEPTH : 3 * DEPTH;
+    int it = 0;
+    for (; it + U + DEPTH + 2 <= niter; it += U) {     // every prefetch issued here is one the loop will consume
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+            store_a(wbuf, st[slot].a);
+            mma_chunk_full(buf, nbuf, st[slot].w);
+            load_w(it + d + DEPTH, st[slot]);
+            load_a(it + d + DEPTH + 2, st[slot].a);
+            if (!(QL_W8A8_ABLATE & 16)) __syncthreads();
+        }
+    }
+    // tail: prefetches only while there is something left to fetch; chunks may be partial / absent
+#pragma unroll
+    for (int d = 0; d < U + DEPTH + 1; ++d) {
+        const int i = it + d;
+        if (i < niter) {                               // block-uniform
+            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;   // `it` is a multiple of U
+            if (i + 2 < niter) store_a(wbuf, st[slot].a);
+            mma_chunk(i, buf, nbuf, st[slot].w);
+            if (i + DEPTH < niter) load_w(i + DEPTH, st[slot]);
+            if (i + DEPTH + 2 < niter) load_a(i + DEPTH + 2, st[slot].a);
+            __syncthreads();
+        }
+    }
+
+    // epilogue operands requested NOW: their global round trip overlaps the exchange below instead of sitting in the
+    // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
+    const int n = n0 + wv * 32 + j;
+    const float ws = Act<T>::load(Sc + (n < N ? n : N - 1));
+    constexpr int OWN = MT == 1 ? 1 : MT / 2;                              // row tiles this group finishes
+    float asc[OWN][16];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int mt = MT == 1 ? 0 : 2 * o + grp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+            asc[o][i] = a_scale[m < M ? m : M - 1];
+        }
+    }
+
+    // ---- combine the two K-parity groups through LDS (exact: int32), then the rank-1 scale epilogue ----------
+    // row tile mt is finished by group (mt & 1) (MT == 1: group 0): each group hands the OTHER group's tiles over
+    // as 16-byte pieces [tile slot][piece q][lane] - consecutive lanes, consecutive 16 bytes: conflict-free
+    constexpr int SLOTS = (MT + 1) / 2;                                    // tiles a group receives
+    i32x4* xch = reinterpret_cast<i32x4*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner != grp) {
+            const int slot = mt >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
+                    i32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner == grp) {
+            const int slot = mt >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+            }
+        }
+    }
+    __syncthreads();                                                       // LDS is reused for the output tiles below
+
+    if (QL_W8A8_ABLATE & 64) {                         // no epilogue: one store keeps the accumulators alive
+        int x = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x ^= acc[mt][i];
+        if (x == 0x12345678) C[0] = (T)1.f;
+        return;
+    }
+    const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;     // 2 KB per wave (16 KB <= the A buffers)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner != grp) continue;
+        const int o = mt >> 1;
+        if constexpr (sizeof(T) == 2) {
+            if (wide) {
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
+                                    [&](int i) { return (float)acc[mt][i] * (asc[o][i] * ws); });
+                continue;
+            }
+        }
+        if (n < N) {
+            const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][i] * (asc[o][i] * ws), bn);
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int S, int DEPTH>
+static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* Sc, const void* bias, void* C,
+                                int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    constexpr int BM = 32 * MT;
+    const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
+    constexpr int kLds = 6 * BM * 128 * S < 16384 ? 16384 : 6 * BM * 128 * S;   // two groups x three buffers (epilogue: 2 KB per wave)
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    }();
+    (void)attr_set;
+    static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch
+    w8a8_tiled_kernel<T, MT, S, DEPTH><<<(unsigned)(nbx * nby), 512, kLds, st>>>(
+        Aq, Wm, (int)M, (int)N, (int)K, xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, a_scale, (const T*)Sc,
+        (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+template <typename T>
+static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
+                             int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W8A8_MT"); return e ? atoi(e) : 0; }();
+    static const int variant = [] { const char* e = getenv("QLINEAR_W8A8_VARIANT"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    const int64_t nb = (N + 127) / 128;
+    // tallest row tile that still gives every CU a block
+    int mt = 1;
+    for (int t = 4; t > 1; t >>= 1)
+        if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 256) { mt = t; break; }
+    if (mt == 1 && M > 32) mt = 2;
+    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
+    if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    if (mt == 2) {
+        if (variant == 1) return launch_w8a8_tiled_mt<T, 2, 1, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+        return launch_w8a8_tiled_mt<T, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    }
+    return launch_w8a8_tiled_mt<T, 1, 2, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+}
+
+int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
+                    int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w8a8_tiled<float>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    case QL_DTYPE_F16: return launch_w8a8_tiled<f16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    case QL_DTYPE_BF16: return launch_w8a8_tiled<__bf16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql

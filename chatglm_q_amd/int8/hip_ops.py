@@ -200,9 +200,10 @@ def dynamic_quant_matmul_transposed(a: Tensor, b_T: Tensor, b_scale: Tensor, all
     return w8_grad_input(a, b_T, b_scale)
 
 
-def act_quant_rowwise(a: Tensor):
-    """Row-wise symmetric int8 quantisation of activations in fp32 arithmetic.
-    Returns (a_q (M, K) int8, a_scale (M,) float32)."""
+def act_quant_rowwise(a: Tensor, per_tensor: bool = False):
+    """Symmetric int8 quantisation of activations in fp32 arithmetic: one scale per row (``quantize_int8``,
+    chatglm_q/int8/quantizer.py:11-19) or, with ``per_tensor``, one scale for the whole tensor (the ONNX export's
+    second branch, chatglm_q/int8/qlinear.py:64-70).  Returns (a_q (M, K) int8, a_scale (M,) float32)."""
     lib = _lib.get_lib()
     a2 = _rows(a)
     M, K = a2.shape
@@ -210,11 +211,52 @@ def act_quant_rowwise(a: Tensor):
     a_s = torch.empty((M,), device=a.device, dtype=torch.float32)
     if M:
         with torch.cuda.device(a.device):
-            st = lib.qlinear_act_quant_i8_rowwise(a2.data_ptr(), a_q.data_ptr(), a_s.data_ptr(), M, K,
-                                                  a2.stride(0) if M > 1 else K, _lib.dtype_code(a.dtype),
-                                                  _lib.stream_ptr(a.device))
-        _lib.check(st, "qlinear_act_quant_i8_rowwise")
+            st = lib.qlinear_act_quant_i8(a2.data_ptr(), a_q.data_ptr(), a_s.data_ptr(), M, K,
+                                          a2.stride(0) if M > 1 else K, _lib.dtype_code(a.dtype),
+                                          _lib.FLAG_ACT_PER_TENSOR if per_tensor else 0, _lib.stream_ptr(a.device))
+        _lib.check(st, "qlinear_act_quant_i8")
     return a_q, a_s
+
+
+def w8a8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None,
+                       per_tensor: bool = False) -> Tensor:
+    """The int8-activation linear on the tile-major copy of the weights (``tile_w8``): activation quantisation + i8 x i8
+    MFMA GEMM in one library call (``qlinear_w8a8_linear_tiled``)."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    _check_row_operands("w8a8_forward_tiled", a, K, w_scale=w_scale, bias=bias)
+    if w_scale.shape != (n_out,) or (bias is not None and bias.shape != (n_out,)):
+        raise AssertionError(f"w8a8_forward_tiled: scale / bias must have shape ({n_out},)")
+    if tiled.device != a.device or tiled.numel() != int(lib.qlinear_w8_tiled_bytes(n_out, K)):
+        raise AssertionError(f"w8a8_forward_tiled: tiled copy does not belong to a ({n_out}, {K}) weight on {a.device}")
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    if M:
+        if bias is not None:
+            bias = bias.contiguous()
+        with torch.cuda.device(a.device):
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8A8_LINEAR_TILED, M, n_out, K, 0))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+            st = lib.qlinear_w8a8_linear_tiled(a2.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(), _lib.ptr(bias),
+                                               c.data_ptr(), M, n_out, K, a2.stride(0) if M > 1 else K, n_out,
+                                               _lib.dtype_code(a.dtype), _lib.FLAG_ACT_PER_TENSOR if per_tensor else 0,
+                                               ws.data_ptr(), ws_bytes, _lib.stream_ptr(a.device))
+        _lib.check(st, "qlinear_w8a8_linear_tiled")
+    return c.reshape(*a.shape[:-1], n_out)
+
+
+def w8a8_gemm_tiled(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """Second step alone (``qlinear_w8a8_fwd_tiled``): pre-quantised int8 rows x tile-major int8 weights."""
+    lib = _lib.get_lib()
+    M, K = a_q.shape
+    c = torch.empty((M, n_out), device=a_q.device, dtype=w_scale.dtype)
+    if M:
+        with torch.cuda.device(a_q.device):
+            st = lib.qlinear_w8a8_fwd_tiled(a_q.data_ptr(), a_s.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(),
+                                            _lib.ptr(bias), c.data_ptr(), M, n_out, K, n_out, _lib.dtype_code(w_scale.dtype),
+                                            _lib.stream_ptr(a_q.device))
+        _lib.check(st, "qlinear_w8a8_fwd_tiled")
+    return c
 
 
 def w8a8_forward(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:

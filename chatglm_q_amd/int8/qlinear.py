@@ -89,6 +89,11 @@ class DynamicQuantizeLinear(nn.Module):
     def forward(self, input: Tensor):
         if check_input(input) and not (input.requires_grad and torch.is_grad_enabled()):
             if self.act_quant:
+                if self.in_features % 16 == 0:
+                    # tile-major weights straight into the i8 MFMA operands; act_quant == "per_tensor": one scale for the
+                    # whole activation tensor (chatglm_q/int8/qlinear.py:64-70) instead of one per row
+                    return hip_ops.w8a8_forward_tiled(input, self.prepare()._tiled, self.out_features, self.weight_scale,
+                                                      self.bias, per_tensor=self.act_quant == "per_tensor")
                 return hip_ops.w8a8_forward(input, self.weight, self.weight_scale, self.bias)
             if hip_ops.w8_tiled_supported(input, self.weight):
                 # >= 3 rows: MFMA kernels on the tile-major derived copy (built lazily, keyed on the buffer's version)

@@ -65,12 +65,19 @@ extern "C" {
                                       closer to real arithmetic and differs from the reference only by that
                                       per-weight rounding (~2e-4 relative in fp16; within the 1e-3 bar). */
 
+#define QL_FLAG_ACT_PER_TENSOR 2    /* activation quantisation: ONE scale max|A| / 127 for the whole (M, K) tensor - the per-tensor
+                                      symmetric variant of DynamicQuantizeMatMul.symbolic's second branch
+                                      (chatglm_q/int8/qlinear.py:64-70: ReduceMax(Abs(A)) / 127, QuantizeLinear with zero
+                                      point 0) - instead of one scale per row (quantize_int8, chatglm_q/int8/quantizer.py:
+                                      11-19).  a_scale still has M entries (all equal), so the GEMM epilogue is unchanged. */
+
 /* operations, for qlinear_workspace_bytes */
 #define QL_OP_W4G32_FWD 1
 #define QL_OP_W4G32_FWD_PACKED 2
 #define QL_OP_W8_FWD 3
 #define QL_OP_W8A8_FWD 4
 #define QL_OP_W8_FWD_TILED 5
+#define QL_OP_W8A8_LINEAR_TILED 6  /* REQUIRED by qlinear_w8a8_linear_tiled: the int8 activations and their scales */
 
 int qlinear_abi_version(void);
 const char* qlinear_status_string(int status);
@@ -207,10 +214,28 @@ int qlinear_w8_bwd_input(const void* Gout, const int8_t* Wkn, const void* S, voi
  * (quantize_int8, chatglm_q/int8/quantizer.py:11-19).  Aq is (M, K) contiguous. */
 int qlinear_act_quant_i8_rowwise(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K,
                                  int64_t lda, int dtype, void* stream);
+/* The same with `flags`: 0 = row-wise (identical to qlinear_act_quant_i8_rowwise), QL_FLAG_ACT_PER_TENSOR = one scale
+ * for the whole tensor, a_scale[m] = max(max_{m,k} |A[m,k]| / 127, 1e-10) for every m (the clamp keeps the 0 / 0 of an
+ * all-zero tensor out - the NaN the reference's comment at qlinear.py:65 mentions); rounding = round half to even,
+ * saturated to [-127, 127] (ONNX QuantizeLinear; |x / scale| <= 127 by construction, so -128 never occurs). */
+int qlinear_act_quant_i8(const void* A, int8_t* Aq, float* a_scale, int64_t M, int64_t K, int64_t lda, int dtype,
+                         int flags, void* stream);
 /* C[m,n] = round(acc_i32[m,n] * (a_scale[m] * w_scale[n])) (+ bias); W is (N, K) row-major. */
 int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
                      void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* The same contraction with the weights in the tile-major derived copy of qlinear_w8_tile (a lane's 16 bytes are its
+ * MFMA operand: W bypasses LDS; two K-parity wave groups per block).  K % 16 == 0.  No workspace. */
+int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias,
+                           void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
+/* Both steps of the int8-activation linear in ONE call (two launches): quantise A (M, K) row-wise (or per tensor:
+ * flags & QL_FLAG_ACT_PER_TENSOR) into the workspace, then the tile-major GEMM.  workspace: qlinear_workspace_bytes(
+ * QL_OP_W8A8_LINEAR_TILED, M, N, K, 0) bytes, 16-byte aligned; it holds Aq (M * K bytes) followed by a_scale (M floats)
+ * and may be inspected afterwards. */
+int qlinear_w8a8_linear_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M,
+                              int64_t N, int64_t K, int64_t lda, int64_t ldc, int dtype, int flags, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- quantised embedding gathers ("next" row N3) -------------------------------------------
  * ids: (count) int64 token ids.  int4: Wq (V/2, D) packs along the vocabulary axis, S (V/group, D).

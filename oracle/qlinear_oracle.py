@@ -265,6 +265,19 @@ def act_quant_rowwise(a: np.ndarray):
     return q, scale[:, 0].astype(np.float32)
 
 
+def act_quant_per_tensor(a: np.ndarray):
+    """Per-TENSOR symmetric activation quantisation in float32 arithmetic: the second branch of
+    DynamicQuantizeMatMul.symbolic (chatglm_q/int8/qlinear.py:64-70):
+    ``A_scale = ReduceMax(Abs(A)) / 127``; ``QuantizeLinear(A, A_scale, zero_point=0)`` = saturate(round-half-even(
+    A / A_scale)) to int8.  The reference never executes this in PyTorch (ONNX export only; its comment says it NaNs
+    on CUDA: an all-zero tensor gives 0 / 0) - the scale floor of quantize_int8 (1e-10) is applied to keep that out.
+    Returns (int8 (M, K), float32 (M,) - the one scale repeated per row, the layout the GEMM epilogue takes)."""
+    a32 = np.asarray(a).astype(np.float32).reshape(-1, a.shape[-1])
+    scale = np.maximum((np.abs(a32).max() / np.float32(MAX_Q_INT8)).astype(np.float32), np.float32(SCALE_FLOOR))
+    q = np.clip(np.rint((a32 / scale).astype(np.float32)), -MAX_Q_INT8, MAX_Q_INT8).astype(np.int8)
+    return q, np.full((a32.shape[0],), scale, dtype=np.float32)
+
+
 def w8a8_acc_i32(a_q: np.ndarray, w_nk: np.ndarray) -> np.ndarray:
     """Exact integer contraction: (M, K) int8 x (N, K) int8 -> (M, N) int32
     (MatMulInteger of the ONNX symbolic, chatglm_q/int8/qlinear.py:60,68)."""
@@ -272,13 +285,13 @@ def w8a8_acc_i32(a_q: np.ndarray, w_nk: np.ndarray) -> np.ndarray:
 
 
 def w8a8_matmul(a: np.ndarray, w_nk: np.ndarray, w_scale: np.ndarray,
-                bias: np.ndarray | None = None, dtype: str | None = None) -> np.ndarray:
+                bias: np.ndarray | None = None, dtype: str | None = None, per_tensor: bool = False) -> np.ndarray:
     """fp in -> row-wise int8 act-quant -> i8 x i8 -> i32 -> ``acc * a_scale[m] *
     w_scale[n]`` in float32 -> act dtype (+ bias after the cast).  Epilogue shape
     follows chatglm_q/int8/qlinear.py:61-62 (Cast then Mul by A_scale*b_scale)."""
     dt = dtype_of(w_scale, dtype)
     lead = a.shape[:-1]
-    a_q, a_s = act_quant_rowwise(a)
+    a_q, a_s = act_quant_per_tensor(a) if per_tensor else act_quant_rowwise(a)
     acc = w8a8_acc_i32(a_q, w_nk).astype(np.float32)
     comb = (a_s[:, None] * np.asarray(w_scale).astype(np.float32)[None, :]).astype(np.float32)
     out = round_to((acc * comb).astype(np.float32), dt)

@@ -257,6 +257,15 @@ def gen_w8a8():
     a16 = a.half()
     aq16, as16 = refq8.quantize_int8(a16.float())
     put(d, "a_f16", a16); d["a_q_f16"] = to_np(aq16); put(d, "a_scale_f16", as16)
+    # per-tensor symmetric variant: the formula of DynamicQuantizeMatMul.symbolic's second branch
+    # (chatglm_q/int8/qlinear.py:64-70) written with torch ops - the reference itself only emits it as ONNX nodes
+    # (ReduceMax(Abs(A)) / 127 -> QuantizeLinear zero point 0 -> MatMulInteger -> Cast -> Mul) and no ONNX runtime exists
+    # here; QuantizeLinear rounds half to even and saturates, as torch.round + clamp do
+    a_scale_t = (a.abs().max() / 127.0).float()
+    aq_t = torch.clamp(torch.round(a / a_scale_t), -128, 127).to(torch.int8)
+    acc_t = aq_t.to(torch.int32) @ wq.to(torch.int32).t()
+    d["pt_a_q"] = to_np(aq_t); put(d, "pt_a_scale", a_scale_t.reshape(1)); d["pt_acc_i32"] = to_np(acc_t)
+    put(d, "pt_out", acc_t.float() * (a_scale_t * ws[None, :]))
     np.savez_compressed(os.path.join(OUT, "w8a8.npz"), **d)
 
 

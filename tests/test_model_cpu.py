@@ -30,7 +30,10 @@ def t2n(t):
     return t.detach().float().cpu().numpy()
 
 
-TOL = {"f32": 2e-4, "f16": 2e-2}
+# The CPU branch runs the reference's own torch formula: measured 0.0 (fp16, bit-identical) and 2.3e-7 (fp32) in the
+# build container.  The bars leave room only for a different BLAS summation order on another host: one fp16 rounding of
+# a dot product per layer output (~1e-3, the same bar as the real-dimension fixture), fp32 roundoff.
+TOL = {"f32": 2e-5, "f16": 2e-3}
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16"])

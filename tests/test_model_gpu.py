@@ -12,6 +12,10 @@ from chatglm_q_amd.decoder import ChatGLMDecoder  # noqa: E402
 from test_model_cpu import Z, build, t2n  # noqa: E402
 
 DEV = "cuda:0"
+# hidden-128 model against the reference's logits.  fp16: measured 2.0e-3 / 2.4e-3 on MI355X (round 2; a tiny model's
+# logits are ~0.05 in magnitude with fp16 activations ~1, so its relative error is larger than the real-dimension
+# fixture's 1e-3, tests/test_model_real_gpu.py); the bar is 2x the measurement.
+TINY_TOL = {"f32": 2e-4, "f16": 5e-3}
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16"])
@@ -24,9 +28,11 @@ def test_tiny_model_logits_through_hip_kernels(dt):
         _, logits, kv = model(input_ids=ids)
         _, logits2, _ = model(input_ids=nxt, past_key_values=kv)
     assert _lib.launch_count() - before >= 2 * (4 * cfg.num_layers + 2)     # every QLinear + QEmbedding call
-    tol = {"f32": 2e-4, "f16": 2e-2}[dt]
-    assert O.rel_l2(t2n(logits), Z[f"{dt}/prefill_logits"].astype(np.float32)) < tol
-    assert O.rel_l2(t2n(logits2), Z[f"{dt}/decode_logits"].astype(np.float32)) < tol
+    tol = TINY_TOL[dt]
+    e1 = O.rel_l2(t2n(logits), Z[f"{dt}/prefill_logits"].astype(np.float32))
+    e2 = O.rel_l2(t2n(logits2), Z[f"{dt}/decode_logits"].astype(np.float32))
+    print(f"[tiny parity] {dt}: prefill {e1:.3e} decode {e2:.3e}")
+    assert e1 < tol and e2 < tol
 
 
 def test_graph_decode_equals_eager_and_cpu():
@@ -62,7 +68,9 @@ def test_fused_decode_ops_match_the_torch_graph(dt, monkeypatch):
         outs[fused] = torch.stack([l.float() for l in logits])
     tol = {"f32": 1e-5, "f16": 5e-3}[dt]
     assert O.rel_l2(t2n(outs[True]), t2n(outs[False])) < tol
-    assert O.rel_l2(t2n(outs[True][1]), Z[f"{dt}/decode_logits"].astype(np.float32)[0]) < {"f32": 2e-4, "f16": 2e-2}[dt]
+    e = O.rel_l2(t2n(outs[True][1]), Z[f"{dt}/decode_logits"].astype(np.float32)[0])
+    print(f"[tiny parity] {dt}: fused step decode {e:.3e}")
+    assert e < TINY_TOL[dt]
 
 
 def test_fused_ops_unit_shapes():

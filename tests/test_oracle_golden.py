@@ -116,3 +116,17 @@ def test_grad_input_matches_reference_autograd(entry):
         got = O.w8_matmul_grad_input(c["grad_out"], c["weight_nk"].T, c["scale"], dtype=dt)
     assert got.shape == c["grad_a"].shape
     _close(got, c["grad_a"], dt)
+
+
+def test_act_quant_per_tensor_matches_formula_fixture():
+    """Per-tensor symmetric variant (chatglm_q/int8/qlinear.py:64-70): the fixture holds the formula evaluated with
+    torch ops (the reference only emits it as ONNX nodes)."""
+    z = G.load("w8a8.npz")
+    q, s = O.act_quant_per_tensor(z["a"])
+    assert np.array_equal(q, z["pt_a_q"])
+    assert np.all(s == z["pt_a_scale"][0]) and s.shape == (z["a"].shape[0],)
+    assert np.array_equal(O.w8a8_acc_i32(q, z["weight_nk"]), z["pt_acc_i32"])
+    out = O.w8a8_matmul(z["a"], z["weight_nk"], z["w_scale"], per_tensor=True)
+    assert np.allclose(out, z["pt_out"], rtol=1e-6, atol=1e-6)
+    zq, zs = O.act_quant_per_tensor(np.zeros((3, 16), np.float32))          # the 0 / 0 case the reference's comment mentions
+    assert not zq.any() and np.all(zs == np.float32(1e-10))

@@ -166,6 +166,25 @@ def test_int4_vs_oracle(M, K, N, dt, has_bias, layout):
         assert O.rel_l2(t2n(out), ref) <= 1.5e-4, O.rel_l2(t2n(out), ref)
 
 
+@pytest.mark.parametrize("layout", ["packed", "packed_strict"])
+@pytest.mark.parametrize("M,K,N", [(8192, 4096, 4096), (8192, 13696, 4096)])
+def test_int4_config5_gemm_shapes(M, K, N, layout):
+    """BASELINE config 5's QLinear calls (seq 2048 x batch 4 = 8192 rows) at o_proj / w_out size.  The whole product
+    runs on the GPU; the fp64 oracle checks every 13th row (rows are independent, every 128-row tile contributes ~10)
+    so that the CPU side stays at seconds."""
+    qw, sc = _rand_w4(K, N, "f16", seed=K * 7 + N)
+    g = torch.Generator().manual_seed(M + 13)
+    a = torch.randn((M, K), generator=g).half()
+    qd, sd = qw.to(DEV), sc.to(DEV)
+    out = h4.w4_forward(a.to(DEV), qd, sd, None, h4.repack_w4g32(qd, sd), strict=layout.endswith("strict"))
+    rows = torch.arange(0, M, 13)
+    ref = O.w4_matmul(t2n(a[rows]), qw.numpy(), t2n(sc), None, dtype="f16")
+    got = t2n(out[rows.to(DEV)])
+    assert_close(got, ref, "f16", f"{M}x{K}x{N}")
+    assert O.rel_l2(got, ref) <= 1.5e-4, O.rel_l2(got, ref)        # the MFMA GEMM keeps the reference's per-weight rounding
+    assert torch.isfinite(out).all()
+
+
 def test_int4_group_sizes_other_than_32():
     for group in (16, 64, 128):
         K, N, M = 256, 40, 3
@@ -349,6 +368,104 @@ def test_w8a8_vs_oracle(M, K, N, dt):
     # reported, not claimed: distance to the weight-only result
     ref16 = O.w8_matmul(t2n(a), np.ascontiguousarray(w.numpy().T), t2n(sc), t2n(bias), dtype=dt)
     assert O.rel_l2(y, ref16) < 5e-2
+
+
+def _exact_acc(a_q, w, fn):
+    """Unit scales + fp32 output: the kernel's output IS its int32 accumulator (exact while |acc| < 2^24)."""
+    M, N = a_q.shape[0], w.shape[0]
+    ones_n = torch.ones(N, device=DEV)
+    ones_m = torch.ones(M, device=DEV)
+    return fn(a_q, ones_m, ones_n).cpu().numpy().astype(np.int64)
+
+
+def test_w8a8_tiled_integer_stage_exact_and_epilogue():
+    """The tile-major kernel (w8a8.hip) against the reference-generated fixture: quantised rows, scales and the int32
+    accumulators bit-exact; per-tensor variant against the formula fixture."""
+    z = G.load("w8a8.npz")
+    w = torch.from_numpy(z["weight_nk"]).to(DEV)
+    ws = torch.from_numpy(z["w_scale"]).to(DEV)
+    tiled = h8.tile_w8(w)
+    N, K = w.shape
+    for key_a, key_q, key_s in (("a", "a_q", "a_scale"), ("a_f16", "a_q_f16", "a_scale_f16")):
+        a = torch.from_numpy(z[key_a]).to(DEV)
+        a_q, a_s = h8.act_quant_rowwise(a)
+        assert np.array_equal(a_q.cpu().numpy(), z[key_q]) and np.array_equal(a_s.cpu().numpy(), z[key_s])
+    a = torch.from_numpy(z["a"]).to(DEV)
+    a_q, a_s = h8.act_quant_rowwise(a)
+    acc = _exact_acc(a_q, w, lambda q, sm, sn: h8.w8a8_gemm_tiled(q, sm, tiled, N, sn))
+    assert np.array_equal(acc, z["acc_i32"].astype(np.int64))
+    out = h8.w8a8_forward_tiled(a, tiled, N, ws)
+    assert np.allclose(out.cpu().numpy(), z["out_w8a8"], rtol=1e-6, atol=1e-6)
+    # per-tensor symmetric (chatglm_q/int8/qlinear.py:64-70)
+    q_t, s_t = h8.act_quant_rowwise(a, per_tensor=True)
+    assert np.array_equal(q_t.cpu().numpy(), z["pt_a_q"])
+    assert np.all(s_t.cpu().numpy() == z["pt_a_scale"][0])
+    acc_t = _exact_acc(q_t, w, lambda q, sm, sn: h8.w8a8_gemm_tiled(q, sm, tiled, N, sn))
+    assert np.array_equal(acc_t, z["pt_acc_i32"].astype(np.int64))
+    out_t = h8.w8a8_forward_tiled(a, tiled, N, ws, per_tensor=True)
+    assert np.allclose(out_t.cpu().numpy(), z["pt_out"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,K", [(512, 4096), (3, 4096), (70, 1024), (33, 8), (5, 13696), (9, 16384), (4, 208), (2, 4104),
+                                 (6, 20000), (3, 100)])
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_tensor", [False, True])
+def test_act_quant_bit_exact_vs_oracle(M, K, dt, per_tensor):
+    """One-pass register-resident quantiser (16-bit rows up to 16384 values) and the two-pass fallback: rows, scales
+    bit-exact, incl. ties (x.5 multiples of the scale), an all-zero row and a strided input."""
+    g = torch.Generator().manual_seed(M * 31 + K)
+    a = torch.randn((M, K + 8), generator=g)
+    a[0, :K] = 0                                                     # scale floor 1e-10
+    if M > 1:
+        a[1, :K] = torch.arange(K).float() % 255 - 127 + 0.5         # ties everywhere once scale = 1 (max 127.5 -> not 1: still fine)
+        a[1, 0] = 127.0
+    a = a.to(TDT[dt])
+    view = a[:, :K]                                                  # row stride K + 8: lda != K
+    fn = O.act_quant_per_tensor if per_tensor else O.act_quant_rowwise
+    q_ref, s_ref = fn(t2n(view))
+    q, s = h8.act_quant_rowwise(a.to(DEV)[:, :K], per_tensor=per_tensor)      # strided on the device too
+    assert np.array_equal(q.cpu().numpy(), q_ref)
+    assert np.array_equal(s.cpu().numpy(), s_ref)
+
+
+W8A8_TILED_SHAPES = [(512, 4096, 4096, "f16"), (70, 1024, 200, "f16"), (33, 512, 96, "bf16"), (64, 256, 64, "f32"),
+                     (1, 4096, 256, "f16"), (130, 13696, 136, "f16"), (300, 208, 130, "f32"), (2048, 1024, 512, "bf16"),
+                     (513, 4160, 264, "f16"), (8192, 4096, 512, "f16"), (40, 64, 40, "f16"), (96, 16, 32, "f16"),
+                     (1000, 1088, 1000, "bf16")]
+
+
+@pytest.mark.parametrize("M,K,N,dt", W8A8_TILED_SHAPES)
+def test_w8a8_tiled_vs_oracle(M, K, N, dt):
+    """K % 128 in {0, 16, 64, 80}, odd step counts (the two K-parity groups get unequal work), ragged M / N, every row-tile
+    height (MT = 1, 2, 4).  Integer stage exact (unit scales, fp32 out, values bounded so |acc| < 2^24), epilogue vs oracle."""
+    g = torch.Generator().manual_seed(M + K + N)
+    w = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)
+    sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(TDT[dt])
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt])
+    wd = w.to(DEV)
+    tiled = h8.tile_w8(wd)
+    ref = O.w8a8_matmul(t2n(a), w.numpy(), t2n(sc), t2n(bias), dtype=dt)
+    before = launches()
+    out = h8.w8a8_forward_tiled(a.to(DEV), tiled, N, sc.to(DEV), bias.to(DEV))
+    assert launches() - before == 2                                  # quantiser + GEMM, nothing else
+    assert O.rel_l2(t2n(out), ref) <= {"f32": 1e-6, "f16": 3e-4, "bf16": 2e-3}[dt]
+    # exact accumulators: small-magnitude operands keep |acc| < 2^24 for every K here
+    small_a = torch.randint(-15, 16, (M, K), dtype=torch.int8, generator=g)
+    small_w = torch.randint(-15, 16, (N, K), dtype=torch.int8, generator=g)
+    acc = _exact_acc(small_a.to(DEV), small_w, lambda q, sm, sn: h8.w8a8_gemm_tiled(q, sm, h8.tile_w8(small_w.to(DEV)), N, sn))
+    assert np.array_equal(acc, O.w8a8_acc_i32(small_a.numpy(), small_w.numpy()).astype(np.int64))
+    # the module route
+    layer = q8.DynamicQuantizeLinear(K, N, bias=True, dtype=TDT[dt])
+    layer.apply_weights_(w, sc, bias)
+    layer = layer.to(DEV)
+    layer.act_quant = True
+    with torch.no_grad():
+        assert torch.equal(layer(a.to(DEV)), out)
+    ref_t = O.w8a8_matmul(t2n(a), w.numpy(), t2n(sc), t2n(bias), dtype=dt, per_tensor=True)
+    layer.act_quant = "per_tensor"
+    with torch.no_grad():
+        assert O.rel_l2(t2n(layer(a.to(DEV))), ref_t) <= {"f32": 1e-6, "f16": 3e-4, "bf16": 2e-3}[dt]
 
 
 def test_qembedding_golden():
