@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void w4_tile_kernel(const u32x4* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // Two arithmetic modes, selected per call (QL_FLAG_STRICT_ROUNDING):
 //
-//  strict (fp16 only): every dequantised weight (n - 8) * s is rounded to fp16 before it meets the
+//  strict: every dequantised weight (n - 8) * s is rounded to the activation dtype before it meets the
 //      activation - bit-for-bit the reference's rounding sequence (chatglm_q/int4/triton_ops.py:72-73).
-//      Per 8 weights: 1 shift, 4 v_and_or, 4 exact offset removals, 4 v_pk_mul_f16, 4 v_dot2c.
+//      fp16, per 8 weights: 1 shift, 4 v_and_or, 4 exact offset removals, 4 v_pk_mul_f16, 4 v_dot2c.
+//      bf16 (no packed bf16 multiply): exact fp32 product per weight, v_cvt_pk_bf16_f32, 4 v_dot2c per 8 weights.
 //
 //  exact-dequant (default): the offset form produced by the exponent splice is fed to v_dot2c AS IS
 //      and the group's affine correction is applied once per (column, group) in fp32:
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     const int64_t lda = lda32;
     const Prologue pro{pro_delta, pro_ln_weight, pro_hout, pro_eps, pro_gate};
     static_assert(PRO == PRO_NONE || (MB == 1 && ACH > 0), "prologues exist for the one-row LDS-staged kernel");
-    static_assert(!STRICT || Act<T>::code == QL_DTYPE_F16, "strict rounding mode exists for fp16 only");
     constexpr bool A_LDS = ACH > 0;
     typedef Splice<T> SP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -352,7 +352,27 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
                                         0x3fffffffu);
             return;
         }
-        if constexpr (STRICT) {
+        if constexpr (STRICT && Act<T>::code == QL_DTYPE_BF16) {
+            // bf16 strict: (n - 8) * s evaluated exactly in fp32 (a small integer times a bf16 value) and rounded ONCE to
+            // bf16 - torch's `int8 * bf16` product, the reference's per-weight rounding (chatglm_q/int4/triton_ops.py:72-73,
+            // chatglm_q/int4/qlinear.py:30-32) - then v_dot2c_f32_bf16 with fp32 accumulation.  2^23 | n is the exact float
+            // 8388608 + n: one v_and_or and one subtraction per weight instead of an integer conversion.
+            const float sc[4] = {SP::lo(sv[0]), SP::hi(sv[0]), SP::lo(sv[1]), SP::hi(sv[1])};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32 w = tl.w[c][j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {                        // pair i: k = 8 j + 2 i (bits 4 i), + 1 (bits 16 + 4 i)
+                        const float qe = u32_as_f32(((w >> (4 * i)) & 0xFu) | 0x4B000000u) - 8388616.0f;
+                        const float qo = u32_as_f32(((w >> (16 + 4 * i)) & 0xFu) | 0x4B000000u) - 8388616.0f;
+                        const u32 pr = pack2<__bf16>(qe * sc[c], qo * sc[c]);
+#pragma unroll
+                        for (int m = 0; m < MB; ++m) acc[m][c] = SP::dot(pr, av[m][4 * j + i], acc[m][c]);
+                    }
+                }
+        } else if constexpr (STRICT) {
             const h2 k1032 = {(f16)1032.0f, (f16)1032.0f};
             const h2 kInv16 = {(f16)0.0625f, (f16)0.0625f};
             const h2 kM72 = {(f16)-72.0f, (f16)-72.0f};
@@ -878,10 +898,7 @@ int w4_packed(int dtype, const void* A, const void* packed, const void* bias, vo
     case QL_DTYPE_F16:
         return strict ? launch_16_any<f16, true>(p) : launch_16_any<f16, false>(p);
     case QL_DTYPE_BF16:
-        if (!strict) return launch_16_any<__bf16, false>(p);
-        if (M == 1) return launch_generic_mb<__bf16, 1>(p);
-        if (M == 2) return launch_generic_mb<__bf16, 2>(p);
-        return launch_generic_mb<__bf16, 4>(p);
+        return strict ? launch_16_any<__bf16, true>(p) : launch_16_any<__bf16, false>(p);
     case QL_DTYPE_F32:      // fp32 products are already exact-dequant: one kernel serves both modes
         if (M == 1) return launch_generic_mb<float, 1>(p);
         if (M == 2) return launch_generic_mb<float, 2>(p);

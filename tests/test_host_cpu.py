@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INT4 = G.load("int4_matmul.npz")
 INT8 = G.load("int8_matmul.npz")
 TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
-REL = {"f32": 1e-5, "f16": 1e-3, "bf16": 4e-3}
+REL = {"f32": 1e-5, "f16": 1e-3, "bf16": 1e-3}
 
 
 def t2n(t):

@@ -8,8 +8,9 @@ import pytest
 import _golden as G
 from oracle import qlinear_oracle as O
 
-# fp32: the reference's own bar (tests/test_triton_ops_int4.py:22); fp16/bf16: north_star's 1e-3.
-REL_TOL = {"f32": 1e-5, "f16": 1e-3, "bf16": 4e-3}
+# fp32: the reference's own bar (tests/test_triton_ops_int4.py:22); fp16 / bf16: north_star's 1e-3 (measured: 0.0 on
+# every bf16 fixture - the oracle reproduces the reference's rounding sequence).
+REL_TOL = {"f32": 1e-5, "f16": 1e-3, "bf16": 1e-3}
 
 
 def _close(y, ref, dt):

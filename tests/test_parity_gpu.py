@@ -1,8 +1,13 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden fixtures.
 
 Tolerances: fp32 atol = rtol = 1e-4 (the reference's own bar, tests/test_triton_ops_int4.py:22);
-fp16 / bf16 relative L2 error <= 1e-3 / 4e-3 of the oracle (north_star: 1e-3 for fp16; bf16 has 3 fewer
-mantissa bits so its output rounding alone is ~2e-3); integer stages exact.
+fp16 AND bf16 relative L2 error <= 1e-3 of the oracle (north_star / SURVEY 8c) for every kernel that keeps the
+reference's rounding sequence - the canonical-layout kernel, the MFMA kernels and the GEMVs in strict mode
+(QL_FLAG_STRICT_ROUNDING); integer stages exact.
+One documented exception, REL_DEFAULT_BF16 = 4e-3: the one / two-row bf16 GEMV in its DEFAULT "exact-dequant" mode skips
+the reference's per-weight rounding to bf16 (chatglm_q/int4/triton_ops.py:72-73), which is worth 2^-9 / sqrt(3) = 1.1e-3
+relative on a random-sign dot product by construction; it is closer to real arithmetic, not to the reference.  fp16's
+default mode stays inside 1e-3 (measured 1.6e-4).
 """
 import numpy as np
 import pytest
@@ -21,7 +26,8 @@ from chatglm_q_amd.int8 import qlinear as q8  # noqa: E402
 
 DEV = "cuda:0"
 TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
-REL = {"f32": 2e-6, "f16": 1e-3, "bf16": 4e-3}
+REL = {"f32": 2e-6, "f16": 1e-3, "bf16": 1e-3}
+REL_DEFAULT_BF16 = 4e-3
 
 
 def t2n(t: torch.Tensor):
@@ -29,13 +35,18 @@ def t2n(t: torch.Tensor):
     return t.float().numpy() if t.dtype == torch.bfloat16 else t.numpy()
 
 
-def assert_close(y, ref, dt, what=""):
+def assert_close(y, ref, dt, what="", tol=None):
     y = t2n(y) if isinstance(y, torch.Tensor) else y
     assert y.shape == ref.shape, (y.shape, ref.shape)
     if dt == "f32":
         assert np.allclose(y, ref, atol=1e-4, rtol=1e-4), (what, np.abs(y - ref).max())
     err = O.rel_l2(y, ref)
-    assert err <= REL[dt], (what, dt, err)
+    assert err <= (tol or REL[dt]), (what, dt, err)
+
+
+def w4_tol(dt, layout, rows):
+    """bf16 + derived layout + default arithmetic + GEMV row counts: the documented exception (module docstring)."""
+    return REL_DEFAULT_BF16 if (dt == "bf16" and layout == "packed" and rows <= 4) else None
 
 
 def launches():
@@ -77,9 +88,10 @@ def test_int4_golden(entry, layout):
         out = h4.w4_forward(a, qw, sc, bias)
     torch.cuda.synchronize()
     assert launches() > before
-    assert_close(out, c["out_fallback"], dt, name)
+    rows = a.numel() // a.shape[-1]
+    assert_close(out, c["out_fallback"], dt, name, w4_tol(dt, layout, rows))
     if "out_triton" in c:
-        assert_close(out, c["out_triton"], dt, name)
+        assert_close(out, c["out_triton"], dt, name, w4_tol(dt, layout, rows))
 
 
 @pytest.mark.parametrize("entry", [":".join(c) for c in G.cases(INT8)])
@@ -159,7 +171,7 @@ def test_int4_vs_oracle(M, K, N, dt, has_bias, layout):
         out = torch.cat([h4.w4_forward(ad[m0:m0 + step], qd, sd, bd, packed, strict=strict) for m0 in range(0, M, step)])
     else:
         out = h4.w4_forward(ad, qd, sd, bd)
-    assert_close(out, ref, dt, f"{M}x{K}x{N}")
+    assert_close(out, ref, dt, f"{M}x{K}x{N}", w4_tol(dt, layout, M))
     if (layout != "packed" or M > 4) and dt == "f16":
         # the reference's rounding sequence reproduced: only fp32 summation-order noise is left, which
         # flips an output's fp16 rounding now and then - an order of magnitude below the 1e-3 bar
