@@ -152,6 +152,22 @@ struct PackedTile16 {
 //                staged = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)               model.py:62-73,243-245
 // (enum PRO_* and struct Prologue: launch.h)
 
+// QL_SPAN_PROBE (developer build `make span`, never in libqlinear_hip.so): every wave of the 16-bit GEMV stamps the
+// constant 100 MHz s_memrealtime counter when it starts and when its sums are complete; min / max over the launch give
+// the KERNEL's own span, without the dependent-launch boundary that HIP events and rocprofv3 durations contain
+// ("boundary vs kernel" measured, not inferred).  Two plain 8-byte stores per wave into its own slot (a first
+// version used atomicMin / atomicMax on two words: 2 048 contended 64-bit atomics made the 4 us kernel take 45 us).
+#ifdef QL_SPAN_PROBE
+constexpr int kSpanWaves = 1 << 16;                       // one (start, end) slot per wave: plain stores, no contention
+__device__ unsigned long long ql_span_slots[2 * kSpanWaves];
+#define QL_SPAN_SLOT() (((int)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6)) & (kSpanWaves - 1))
+#define QL_SPAN_START() do { if ((threadIdx.x & 63) == 0) ql_span_slots[2 * QL_SPAN_SLOT()] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define QL_SPAN_END() do { if ((threadIdx.x & 63) == 0) ql_span_slots[2 * QL_SPAN_SLOT() + 1] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QL_SPAN_START() do { } while (0)
+#define QL_SPAN_END() do { } while (0)
+#endif
+
 template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
 __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
                                                                 const T* __restrict__ Sp, const void* pro_delta,
@@ -174,6 +190,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QW = 4 / KS;                 // column quads per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QL_SPAN_START();
     const int ks = wave % KS;
     const int t_raw = blockIdx.x * QW + wave / KS;
     const bool wave_active = t_raw * 4 < N;
@@ -485,6 +502,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
         }
     }
 
+    QL_SPAN_END();
     if (wave_active && ks == 0 && lane == 0) {
         float bq[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
         if (quad_early) {
@@ -908,3 +926,38 @@ int w4_packed(int dtype, const void* A, const void* packed, const void* bias, vo
 }
 
 }  // namespace ql
+
+#ifdef QL_SPAN_PROBE
+// developer entry points of the span-probe build (bench.py's kernel_span leg)
+// in-stream reset (one memset node: start = end = 0 in every slot), so that the probed launch runs behind other work
+extern "C" int qlinear_span_reset_async(void* stream) {
+    void* p = nullptr;
+    const int rc = (int)hipGetSymbolAddress(&p, HIP_SYMBOL(ql::ql_span_slots));
+    if (rc) return rc;
+    return (int)hipMemsetD32Async((hipDeviceptr_t)p, 0u, 4 * ql::kSpanWaves, (hipStream_t)stream);
+}
+// rate of the s_memrealtime counter in kHz (hipDeviceAttributeWallClockRate)
+extern "C" int qlinear_span_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+}
+// host-synchronous: min start / max end over the slots written since the last reset; waves = number of slots seen
+extern "C" int qlinear_span_read(unsigned long long* first_start, unsigned long long* last_end, int* waves) {
+    static unsigned long long host[2 * ql::kSpanWaves];
+    const int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ql::ql_span_slots), sizeof(host));
+    unsigned long long lo = ~0ull, hi = 0ull;
+    int n = 0;
+    for (int i = 0; i < ql::kSpanWaves; ++i) {
+        if (host[2 * i] == 0 || host[2 * i + 1] == 0) continue;
+        lo = host[2 * i] < lo ? host[2 * i] : lo;
+        hi = host[2 * i + 1] > hi ? host[2 * i + 1] : hi;
+        ++n;
+    }
+    *first_start = lo;
+    *last_end = hi;
+    *waves = n;
+    return rc;
+}
+#endif
