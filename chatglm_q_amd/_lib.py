@@ -37,6 +37,7 @@ OP_W8_FWD = 3
 OP_W8A8_FWD = 4
 OP_W8_FWD_TILED = 5
 OP_W8A8_LINEAR_TILED = 6
+OP_W4A8_LINEAR = 7
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -68,6 +69,10 @@ EXPORTS = {
     "qlinear_act_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "qlinear_w8a8_fwd_tiled": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
     "qlinear_w8a8_linear_tiled": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4a8_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "qlinear_w4a8_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4a8_fwd": (c_int, [c_void_p] * 5 + [c_int64] * 4 + [c_int, c_void_p]),
+    "qlinear_w4a8_linear": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_qembedding_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,

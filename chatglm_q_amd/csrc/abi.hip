@@ -66,6 +66,7 @@ size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t 
         return (M > 2 && K % 16 == 0) ? w8_tiled_workspace_bytes(M, N, K) : 0;
     case QL_OP_W8A8_FWD:             // optional too: int32 split-K slabs for shapes with few row tiles
         return K % 16 == 0 ? w8a8_workspace_bytes(M, N, K) : 0;
+    case QL_OP_W4A8_LINEAR:
     case QL_OP_W8A8_LINEAR_TILED:    // required: Aq (M x K int8, padded to 16 bytes) + a_scale (M floats)
         return (((size_t)M * (size_t)K + 15) & ~(size_t)15) + (size_t)M * sizeof(float);
     default: return 0;
@@ -291,6 +292,48 @@ int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, co
     if (K % 16 != 0) return QL_ERR_UNSUPPORTED;     /* rows are read in 16-byte units */
     if (!aligned(Aq, 16) || !aligned(W, 16)) return QL_ERR_MISALIGNED;
     return w8a8_gemm(dtype, Aq, a_scale, W, S, bias, C, M, N, K, ldc, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t qlinear_w4a8_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
+    if (N <= 0 || K <= 0 || group != 32 || K % 32 != 0 || (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16)) return 0;
+    return w4a8_packed_bytes(N, K, dtype);
+}
+
+int qlinear_w4a8_pack(const uint8_t* Wq, const void* S, void* packed_a8, int64_t N, int64_t K, int64_t group, int dtype,
+                      void* stream) {
+    if (!Wq || !S || !packed_a8) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || (K & 1)) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(packed_a8, 16)) return QL_ERR_MISALIGNED;
+    return w4a8_pack(dtype, Wq, S, packed_a8, N, K, (hipStream_t)stream);
+}
+
+int qlinear_w4a8_fwd(const int8_t* Aq, const float* a_scale, const void* packed_a8, const void* bias, void* C, int64_t M,
+                     int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+    if (!Aq || !a_scale || !packed_a8 || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(Aq, 16) || !aligned(packed_a8, 16)) return QL_ERR_MISALIGNED;
+    return w4a8_gemm(dtype, Aq, a_scale, packed_a8, bias, C, M, N, K, ldc, (hipStream_t)stream);
+}
+
+int qlinear_w4a8_linear(const void* A, const void* packed_a8, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                        int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !packed_a8 || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (flags & ~QL_FLAG_ACT_PER_TENSOR) return QL_ERR_UNSUPPORTED;
+    if (!workspace || !aligned(workspace, 16) || workspace_bytes < qlinear_workspace_bytes(QL_OP_W4A8_LINEAR, M, N, K, 32))
+        return QL_ERR_WORKSPACE;
+    if (!aligned(packed_a8, 16)) return QL_ERR_MISALIGNED;
+    int8_t* Aq = (int8_t*)workspace;
+    float* a_scale = (float*)((char*)workspace + (((size_t)M * (size_t)K + 15) & ~(size_t)15));
+    const int rc = act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (flags & QL_FLAG_ACT_PER_TENSOR) != 0, (hipStream_t)stream);
+    if (rc) return rc;
+    return w4a8_gemm(dtype, Aq, a_scale, packed_a8, bias, C, M, N, K, ldc, (hipStream_t)stream);
 }
 
 int qlinear_qembedding_w4(const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count, int64_t V,

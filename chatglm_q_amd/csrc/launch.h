@@ -148,6 +148,12 @@ int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W
               void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
+// w4a8.hip: int4g32 weights x int8 activations (i8 MFMA, one group per MFMA, fp32 fold); fp16 / bf16
+size_t w4a8_packed_bytes(int64_t N, int64_t K, int dtype);
+int w4a8_pack(int dtype, const uint8_t* Wq, const void* S, void* out, int64_t N, int64_t K, hipStream_t st);
+int w4a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
+              int64_t N, int64_t K, int64_t ldc, hipStream_t st);
+
 // embed_kernels.hip
 int qembedding_w4(int dtype, const int64_t* ids, const uint8_t* Wq, const void* S, void* out, int64_t count,
                   int64_t V, int64_t D, int64_t group, hipStream_t st);

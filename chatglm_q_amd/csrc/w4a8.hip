@@ -1,0 +1,426 @@
+// W4A8: int4 group-32 weights x int8-quantised activations on the i8 matrix cores (gfx950).
+//
+// SURVEY.md 8d config 5 / BASELINE configs[4] ("large-M int4 GEMM, MFMA-eligible after act-quant"): the activation
+// semantic is the one of the int8 path - row-wise symmetric quantisation, quantize_int8 (chatglm_q/int8/quantizer.py:
+// 11-19), integer matmul + scale epilogue (chatglm_q/int8/qlinear.py:60-62) - the weight decode is the int4 one,
+// (nibble - 8) * scale[group, column] (chatglm_q/int4/triton_ops.py:71-73, chatglm_q/int4/qlinear.py:20-33):
+//
+//      C[m, n] = round( a_scale[m] * sum_g  s[g, n] * ( sum_{k in g} Aq[m, k] * (nib[k, n] - 8) ) )   (+ bias)
+//
+// A group is 32 deep = ONE v_mfma_i32_32x32x32_i8: every MFMA starts from a zero accumulator, its exact int32 result is
+// converted and folded into the fp32 accumulator with the group's scale (one v_cvt_f32_i32 + one v_fma_f32 per
+// accumulator element - the price of group-wise scales on an integer contraction: 32 VALU operations per MFMA, more than
+// the MFMA's own 32 cycles, so this kernel is VALU-bound by construction at about half the i8 MFMA peak).
+// The integer stage is exact; the result differs from the weight-only W4A16 path by the activation quantisation error
+// (~1e-2 relative, reported by tests/test_parity_gpu.py, not claimed as parity with the Triton reference).
+//
+// Derived weight layout "a8" (qlinear_w4a8_pack, built lazily like the other derived layouts):
+//   Wa[ct][kt][lane][16 B]  ct = n / 32, kt = 64-deep K step, lane = 32 kb + j: column 32 ct + j;
+//                           bytes 0..7  = group 2 kt,     k = 16 kb .. 16 kb + 15 of the group  (two dwords of 8 nibbles)
+//                           bytes 8..15 = group 2 kt + 1, same
+//                           nibble position p of a dword holds k_local = (p >> 1) + 4 (p & 1), so that
+//                             ((w << 4) & 0xF0F0F0F0) ^ 0x80808080  = bytes 16 (n - 8) for k_local 0..3   (3 VALU)
+//                             ( w       & 0xF0F0F0F0) ^ 0x80808080  = ... for k_local 4..7                (2 VALU)
+//                           are two dwords of the MFMA B operand in natural k order; the factor 16 is folded into the scale.
+//   Sa[ct][kt][j][2]        the two groups' scales of column 32 ct + j (activation dtype).
+//   Columns past N / a missing last group: nibble 8 (= 0), scale 0.
+// Kernel skeleton = w8a8_tiled_kernel (w8a8.hip): 8 waves = two K-parity groups x four column tiles, A through three LDS
+// buffers with cross-barrier fragment prefetch, W straight from global into the MFMA operand path.
+#include <type_traits>
+
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct W4A8Layout {
+    int64_t ctiles, ksteps;
+    size_t off_s, bytes;
+};
+static inline W4A8Layout w4a8_layout(int64_t N, int64_t K, size_t esize) {
+    W4A8Layout L;
+    L.ctiles = (N + 31) / 32;
+    L.ksteps = (K / 32 + 1) / 2;
+    L.off_s = (size_t)(L.ctiles * L.ksteps) * 1024;
+    L.bytes = L.off_s + (size_t)(L.ctiles * L.ksteps) * 64 * esize;
+    return L;
+}
+size_t w4a8_packed_bytes(int64_t N, int64_t K, int dtype) { return w4a8_layout(N, K, dtype == QL_DTYPE_F32 ? 4 : 2).bytes; }
+
+// one thread per (ct, kt, lane): 16 bytes of weights; lanes < 32 also write their column's two scales
+template <typename T>
+__global__ __launch_bounds__(256) void w4a8_pack_kernel(const uint8_t* __restrict__ Wq, const T* __restrict__ S,
+                                                        u32x4* __restrict__ Wa, T* __restrict__ Sa, int N, int G, int ksteps,
+                                                        int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (ct * ksteps + kt) * 64 + lane
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), j = lane & 31, kb = lane >> 5;
+    const int64_t step = idx >> 6;
+    const int kt = (int)(step % ksteps), ct = (int)(step / ksteps);
+    const int n = ct * 32 + j;
+    u32 words[4] = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int g = 2 * kt + h;
+        if (n < N && g < G) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                u32 w = 0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int k = g * 32 + 16 * kb + 8 * d + (p >> 1) + 4 * (p & 1);
+                    const u32 b = Wq[(int64_t)(k >> 1) * N + n];         // canonical: byte [k / 2, n], low nibble = even k
+                    w |= ((k & 1) ? (b >> 4) : (b & 0xFu)) << (4 * p);
+                }
+                words[2 * h + d] = w;
+            }
+        }
+        if (kb == 0) {
+            T sc = (T)0.f;
+            if (n < N && g < G) sc = S[(int64_t)g * N + n];
+            Sa[(step * 32 + j) * 2 + h] = sc;
+        }
+    }
+    Wa[idx] = u32x4{words[0], words[1], words[2], words[3]};
+}
+
+template <typename T>
+static int launch_w4a8_pack(const uint8_t* Wq, const void* S, void* out, int64_t N, int64_t K, hipStream_t st) {
+    const W4A8Layout L = w4a8_layout(N, K, sizeof(T));
+    const int64_t total = L.ctiles * L.ksteps * 64;
+    w4a8_pack_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Wq, (const T*)S, (u32x4*)out, (T*)((char*)out + L.off_s),
+                                                                         (int)N, (int)(K / 32), (int)L.ksteps, total);
+    return finish_launch();
+}
+int w4a8_pack(int dtype, const uint8_t* Wq, const void* S, void* out, int64_t N, int64_t K, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w4a8_pack<float>(Wq, S, out, N, K, st);
+    case QL_DTYPE_F16: return launch_w4a8_pack<f16>(Wq, S, out, N, K, st);
+    case QL_DTYPE_BF16: return launch_w4a8_pack<__bf16>(Wq, S, out, N, K, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// =============================================================================================
+// GEMM.  One loop iteration of a K-parity group covers 128 bytes of K = 4 groups = 2 tile-major units.
+// =============================================================================================
+template <typename T, int MT, int DEPTH>
+__global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq, const u32x4* __restrict__ Wa,
+                                                   const T* __restrict__ Sa, int M, int N, int K, int nbx,
+                                                   const float* __restrict__ a_scale, const T* __restrict__ bias,
+                                                   T* __restrict__ C, int64_t ldc) {
+    constexpr int BM = 32 * MT;
+    constexpr int BK = 128;
+    constexpr int CPR = 8;                             // 16-byte chunks per tile row
+    constexpr int NCH = BM * CPR;
+    constexpr int ACH = (NCH + 255) / 256;
+    constexpr bool kAllStage = NCH % 256 == 0;
+    constexpr int BUF = BM * BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wv = wave & 3;
+    const int j = lane & 31, kb = lane >> 5;
+    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int G = K >> 5;
+    const int ksteps = (G + 1) >> 1;                   // 64-deep units per column tile
+    const int nchunks = (K + BK - 1) / BK;
+    const int niter = (nchunks + 1) >> 1;
+    const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile.x * 4 + wv;
+    const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
+    const u32x4* wbase = Wa + (int64_t)ct * ksteps * 64 + lane;
+    const T* sbase = Sa + ((int64_t)ct * ksteps * 32 + j) * 2;
+    char* lds_a = smem + grp * (3 * BUF);
+
+    const int8_t* a_src[ACH];
+    int a_dst[ACH];
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+        const int q = tg + u * 256, r = (q >> 3) % BM, c = q & 7;
+        a_src[u] = Aq + (int64_t)((m0 + r < M) ? (m0 + r) : (M - 1)) * K + c * 16;
+        a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
+    }
+    const int c_mine = tg & 7;
+    const int klast = K - 16;
+    // fragment read offsets: group q of the chunk (0..3), lane half kb: chunk 2 q + kb of row mt * 32 + j
+    int a_rd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_rd[q] = (j * 8 + ((2 * q + kb) ^ ((j >> 1) & 7))) * 16;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    struct Stage {
+        i32x4 a[ACH];                                  // A chunk of (slot's iteration + 2)
+        u32x4 w[2];                                    // two units = four groups of this lane's column
+        u32 s[2];                                      // their scales (two per unit)
+    };
+    Stage st[DEPTH];
+    auto chunk_of = [&](int i) { return 2 * (i < niter ? i : niter - 1) + grp; };
+    auto load_w = [&](int i, Stage& sg) {
+        int t = chunk_of(i);
+        t = t < nchunks ? t : nchunks - 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int ua = 2 * t + u;
+            ua = ua < ksteps ? ua : ksteps - 1;
+            sg.w[u] = wbase[(int64_t)ua * 64];
+            if constexpr (sizeof(T) == 2) sg.s[u] = *reinterpret_cast<const u32*>(sbase + (int64_t)ua * 64);
+        }
+        if constexpr (sizeof(T) == 4) {                // fp32 scales: handled by the (rare) fp32 instantiation below
+            sg.s[0] = sg.s[1] = 0;
+        }
+    };
+    auto load_a = [&](int i, i32x4 (&dst)[ACH]) {
+        int t = chunk_of(i);
+        t = t < nchunks ? t : nchunks - 1;
+        const int off = t * BK + c_mine * 16 <= klast ? t * BK : klast - c_mine * 16;
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) dst[u] = *reinterpret_cast<const i32x4*>(a_src[u] + off);
+    };
+    auto store_a = [&](int buf, const i32x4 (&src)[ACH]) {
+#pragma unroll
+        for (int u = 0; u < ACH; ++u)
+            if (kAllStage || tg + u * 256 < NCH) *reinterpret_cast<i32x4*>(lds_a + buf * BUF + a_dst[u]) = src[u];
+    };
+    auto read_a = [&](int buf, int q, i32x4 (&fr)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fr[mt] = *reinterpret_cast<const i32x4*>(lds_a + buf * BUF + mt * 32 * BK + a_rd[q]);
+    };
+    // nibbles -> int8 operand (bytes 16 (n - 8)); scale (activation dtype) -> fp32 / 16
+    u32 k_hi, k_sign;
+    asm volatile("s_mov_b32 %0, 0xF0F0F0F0" : "=s"(k_hi));
+    asm volatile("s_mov_b32 %0, 0x80808080" : "=s"(k_sign));
+    auto unpack = [&](u32 w0, u32 w1) {
+        return i32x4{(int)(((w0 << 4) & k_hi) ^ k_sign), (int)((w0 & k_hi) ^ k_sign), (int)(((w1 << 4) & k_hi) ^ k_sign),
+                     (int)((w1 & k_hi) ^ k_sign)};
+    };
+    auto scale_of = [&](u32 packed, int h) {
+        float lo, hi;
+        unpack2<T>(packed, lo, hi);
+        return (h ? hi : lo) * 0.0625f;
+    };
+    // One group = MT MFMAs from a zero accumulator; each exact int32 result is folded into the fp32 accumulator with the
+    // group's scale (16 v_cvt_f32_i32 + 16 v_fma_f32).  Software pipeline of depth one: the fold of MFMA e - 1 is issued
+    // behind MFMA e, so the VALU work runs in the shadow of the matrix pipe; the sched_barrier pins that pairing - left
+    // alone, hipcc hoists all 4 MT MFMAs of a chunk ahead of the folds (256 result registers: 1 108 spills at MT = 4).
+    auto fold = [&](const i32x16& r, float sc, f32x16& dst) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = __builtin_fmaf((float)r[i], sc, dst[i]);
+    };
+    auto zero16 = [] {
+        i32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0;
+        return z;
+    };
+    i32x4 fa[2][MT];
+    // full chunk: groups 0..3; fragments one group ahead, across the iteration boundary (three LDS buffers)
+    auto mma_chunk_full = [&](int buf, int nbuf, const Stage& sg) {
+        i32x16 pend = zero16();
+        float sc_prev = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q + 1 < 4) read_a(buf, q + 1, fa[(q + 1) & 1]);
+            else read_a(nbuf, 0, fa[0]);
+            const u32x4& w = sg.w[q >> 1];
+            const i32x4 b = unpack(w[2 * (q & 1)], w[2 * (q & 1) + 1]);
+            const float sc = scale_of(sg.s[q >> 1], q & 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const i32x16 r = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[q & 1][mt], b, zero16(), 0, 0, 0);
+                if (q > 0 || mt > 0) fold(pend, mt > 0 ? sc : sc_prev, acc[(mt + MT - 1) % MT]);
+                pend = r;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sc_prev = sc;
+        }
+        fold(pend, sc_prev, acc[MT - 1]);
+    };
+    auto mma_chunk_partial = [&](int buf, int nbuf, const Stage& sg, int groups) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < groups) {                                              // wave-uniform
+                i32x4 f[MT];
+                read_a(buf, q, f);
+                const u32x4& w = sg.w[q >> 1];
+                const i32x4 b = unpack(w[2 * (q & 1)], w[2 * (q & 1) + 1]);
+                const float sc = scale_of(sg.s[q >> 1], q & 1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const i32x16 r = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[mt], b, zero16(), 0, 0, 0);
+                    fold(r, sc, acc[mt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        read_a(nbuf, 0, fa[0]);
+    };
+
+    {
+        i32x4 a0[ACH], a1[ACH];
+        load_a(0, a0);
+        load_w(0, st[0]);
+        load_a(1, a1);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (d > 0) load_w(d, st[d]);
+            load_a(d + 2, st[d].a);
+        }
+        store_a(0, a0);
+        store_a(1, a1);
+    }
+    __syncthreads();
+    read_a(0, 0, fa[0]);
+
+    constexpr int U = DEPTH % 3 == 0 ? DEPTH : 3 * DEPTH;
+    int it = 0;
+    for (; it + U + DEPTH + 2 <= niter; it += U) {
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+            store_a(wbuf, st[slot].a);
+            mma_chunk_full(buf, nbuf, st[slot]);
+            load_w(it + d + DEPTH, st[slot]);
+            load_a(it + d + DEPTH + 2, st[slot].a);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < U + DEPTH + 1; ++d) {
+        const int i = it + d;
+        if (i < niter) {
+            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+            if (i + 2 < niter) store_a(wbuf, st[slot].a);
+            const int t = 2 * i + grp;
+            int groups = G - 4 * t;
+            groups = t >= nchunks ? 0 : groups;
+            if (groups >= 4) mma_chunk_full(buf, nbuf, st[slot]);
+            else mma_chunk_partial(buf, nbuf, st[slot], groups);
+            if (i + DEPTH < niter) load_w(i + DEPTH, st[slot]);
+            if (i + DEPTH + 2 < niter) load_a(i + DEPTH + 2, st[slot].a);
+            __syncthreads();
+        }
+    }
+
+    // epilogue operands requested before the exchange (their round trip overlaps it)
+    const int n = n0 + wv * 32 + j;
+    constexpr int OWN = MT == 1 ? 1 : MT / 2;
+    float asc[OWN][16];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int mt = MT == 1 ? 0 : 2 * o + grp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+            asc[o][i] = a_scale[m < M ? m : M - 1];
+        }
+    }
+    // combine the two K-parity groups (fp32 partial sums): row tile mt is finished by group mt & 1 (MT == 1: group 0)
+    constexpr int SLOTS = (MT + 1) / 2;
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner != grp) {
+            const int slot = mt >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
+                    f32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner == grp) {
+            const int slot = mt >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+            }
+        }
+    }
+    __syncthreads();
+
+    const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int owner = MT == 1 ? 0 : (mt & 1);
+        if (owner != grp) continue;
+        const int o = mt >> 1;
+        if constexpr (sizeof(T) == 2) {
+            if (wide) {
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
+                                    [&](int i) { return acc[mt][i] * asc[o][i]; });
+                continue;
+            }
+        }
+        if (n < N) {
+            const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) store_out<T>(C + (int64_t)m * ldc + n, acc[mt][i] * asc[o][i], bn);
+            }
+        }
+    }
+}
+
+template <typename T, int MT, int DEPTH>
+static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
+                          int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    constexpr int BM = 32 * MT;
+    const W4A8Layout L = w4a8_layout(N, K, sizeof(T));
+    const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
+    constexpr int kLds = 6 * BM * 128 < 16384 ? 16384 : 6 * BM * 128;
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4a8_kernel<T, MT, DEPTH>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    }();
+    (void)attr_set;
+    w4a8_kernel<T, MT, DEPTH><<<(unsigned)(nbx * nby), 512, kLds, st>>>(
+        Aq, (const u32x4*)packed, (const T*)((const char*)packed + L.off_s), (int)M, (int)N, (int)K,
+        xcd_order(nbx, nby, (double)M * K, (double)N * K / 2), a_scale, (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+template <typename T>
+static int launch_w4a8(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
+                       int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W4A8_MT"); return e ? atoi(e) : 0; }();
+    const int64_t nb = (N + 127) / 128;
+    int mt = 1;
+    for (int t = 4; t > 1; t >>= 1)
+        if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 256) { mt = t; break; }
+    if (mt == 1 && M > 32) mt = 2;
+    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
+    if (mt == 4) return launch_w4a8_mt<T, 4, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    if (mt == 2) return launch_w4a8_mt<T, 2, 3>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    return launch_w4a8_mt<T, 1, 3>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+}
+
+int w4a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
+              int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_w4a8<f16>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    case QL_DTYPE_BF16: return launch_w4a8<__bf16>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql

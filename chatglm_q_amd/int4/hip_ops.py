@@ -138,6 +138,65 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     return c.reshape(out_shape)
 
 
+def w4a8_supported(a: Tensor, b: Tensor, b_scale: Tensor) -> bool:
+    """Shapes / dtypes served by the int8-activation path (qlinear_w4a8_*): fp16 / bf16, group 32."""
+    return (a.is_cuda and a.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == a.dtype and b.dtype == torch.uint8
+            and b_scale.shape[0] * 32 == b.shape[0] * 2 and b.is_contiguous() and b_scale.is_contiguous())
+
+
+def pack_w4a8(b: Tensor, b_scale: Tensor) -> Tensor:
+    """Derived "a8" layout of canonical int4g32 buffers for the int8-activation GEMM (``qlinear_w4a8_pack``): a cache like
+    ``repack_w4g32``'s, never part of a state_dict."""
+    lib = _lib.get_lib()
+    K, N = b.shape[0] * 2, b.shape[1]
+    nbytes = int(lib.qlinear_w4a8_packed_bytes(N, K, 32, _lib.dtype_code(b_scale.dtype)))
+    if nbytes == 0:
+        raise ValueError(f"no W4A8 layout for N={N}, K={K}, dtype={b_scale.dtype} (group 32, fp16 / bf16)")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    with torch.cuda.device(b.device):
+        st = lib.qlinear_w4a8_pack(b.contiguous().data_ptr(), b_scale.contiguous().data_ptr(), out.data_ptr(), N, K, 32,
+                                   _lib.dtype_code(b_scale.dtype), _lib.stream_ptr(b.device))
+    _lib.check(st, "qlinear_w4a8_pack")
+    return out
+
+
+def w4a8_forward(a: Tensor, packed_a8: Tensor, n_out: int, bias: Tensor | None = None, per_tensor: bool = False) -> Tensor:
+    """int8-quantised activations x int4g32 weights on the i8 matrix cores (``qlinear_w4a8_linear``: activation
+    quantiser + GEMM in one library call).  NOT bit-compatible with the weight-only path: see include/qlinear_hip.h."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    _check_row_operands("w4a8_forward", a, K, bias=bias)
+    if packed_a8.device != a.device or packed_a8.numel() != int(lib.qlinear_w4a8_packed_bytes(n_out, K, 32, _lib.dtype_code(a.dtype))):
+        raise AssertionError(f"w4a8_forward: packed buffer does not belong to a ({K}, {n_out}) {a.dtype} weight on {a.device}")
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    if M:
+        if bias is not None:
+            bias = bias.contiguous()
+        with torch.cuda.device(a.device):
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4A8_LINEAR, M, n_out, K, 32))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+            st = lib.qlinear_w4a8_linear(a2.data_ptr(), packed_a8.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out, K,
+                                         a2.stride(0) if M > 1 else K, n_out, _lib.dtype_code(a.dtype),
+                                         _lib.FLAG_ACT_PER_TENSOR if per_tensor else 0, ws.data_ptr(), ws_bytes,
+                                         _lib.stream_ptr(a.device))
+        _lib.check(st, "qlinear_w4a8_linear")
+    return c.reshape(*a.shape[:-1], n_out)
+
+
+def w4a8_gemm(a_q: Tensor, a_s: Tensor, packed_a8: Tensor, n_out: int, dtype: torch.dtype, bias: Tensor | None = None) -> Tensor:
+    """Second step alone (``qlinear_w4a8_fwd``): pre-quantised int8 rows (M, K) and their fp32 scales."""
+    lib = _lib.get_lib()
+    M, K = a_q.shape
+    c = torch.empty((M, n_out), device=a_q.device, dtype=dtype)
+    if M:
+        with torch.cuda.device(a_q.device):
+            st = lib.qlinear_w4a8_fwd(a_q.data_ptr(), a_s.data_ptr(), packed_a8.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out,
+                                      K, n_out, _lib.dtype_code(dtype), _lib.stream_ptr(a_q.device))
+        _lib.check(st, "qlinear_w4a8_fwd")
+    return c
+
+
 def w4_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
     """Shapes / dtypes served by qlinear_w4g32_bwd_input (everything else takes the dense torch formula)."""
     K, N = b.shape[0] * 2, b.shape[1]

@@ -111,6 +111,10 @@ class DynamicQuantizeLinear(nn.Module):
         self._packed: Tensor | None = None
         self._packed_key = None
         self._gated, self._gated_key = None, None
+        self._a8, self._a8_key = None, None
+        # opt-in int8-activation path (W4A8, i8 MFMA): False | True (row-wise scales) | "per_tensor".  NOT bit-compatible
+        # with the weight-only path (activation quantisation error ~1e-2 relative): include/qlinear_hip.h
+        self.act_quant = False
 
     # -- derived layout -----------------------------------------------------------------------
     def _canonical_key(self):
@@ -121,6 +125,7 @@ class DynamicQuantizeLinear(nn.Module):
         after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
         self._packed, self._packed_key = None, None
         self._gated, self._gated_key = None, None
+        self._a8, self._a8_key = None, None
         return self
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -170,6 +175,12 @@ class DynamicQuantizeLinear(nn.Module):
                 if self.bias is not None:
                     out = out + self.bias      # not in place: the Function's output may be a view
                 return out
+            if self.act_quant and hip_ops.w4a8_supported(input, self.weight, self.weight_scale) and self.group_size == 32:
+                key = self._canonical_key()
+                if self._a8 is None or self._a8_key != key:
+                    self._a8, self._a8_key = hip_ops.pack_w4a8(self.weight, self.weight_scale), key
+                return hip_ops.w4a8_forward(input, self._a8, self.out_features, self.bias,
+                                            per_tensor=self.act_quant == "per_tensor")
             rows = input.numel() // max(input.shape[-1], 1)
             packed = None
             if (rows <= PACKED_MAX_ROWS or input.dtype in (torch.float16, torch.bfloat16)) and self._packed_supported():

@@ -78,6 +78,7 @@ extern "C" {
 #define QL_OP_W8A8_FWD 4
 #define QL_OP_W8_FWD_TILED 5
 #define QL_OP_W8A8_LINEAR_TILED 6  /* REQUIRED by qlinear_w8a8_linear_tiled: the int8 activations and their scales */
+#define QL_OP_W4A8_LINEAR 7        /* REQUIRED by qlinear_w4a8_linear: the same */
 
 int qlinear_abi_version(void);
 const char* qlinear_status_string(int status);
@@ -236,6 +237,25 @@ int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* t
 int qlinear_w8a8_linear_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M,
                               int64_t N, int64_t K, int64_t lda, int64_t ldc, int dtype, int flags, void* workspace,
                               size_t workspace_bytes, void* stream);
+
+/* ---- int4 g32 weights x int8-quantised activations (W4A8: SURVEY.md 8d config 5, BASELINE configs[4]) ------------
+ * C[m,n] = round(a_scale[m] * sum_g s[g,n] * (sum_{k in group g} Aq[m,k] * (nibble[k,n] - 8))) (+ bias):
+ * the activation side of the int8 path (row-wise / per-tensor symmetric quantisation, chatglm_q/int8/quantizer.py:11-19,
+ * chatglm_q/int8/qlinear.py:60-70) with the int4 weight decode (chatglm_q/int4/triton_ops.py:71-73).  One 32-deep
+ * v_mfma_i32_32x32x32_i8 = one group; its exact int32 result is scaled into an fp32 accumulator.  The integer stage is
+ * exact; the result differs from the weight-only (W4A16) path by the activation quantisation error (~1e-2 relative) -
+ * an opt-in accuracy / throughput trade, not a parity claim against the Triton reference.
+ * packed_a8: a third derived layout of the canonical buffers (qlinear_w4a8_pack; group 32, K % 32 == 0, fp16 / bf16),
+ * nibbles ordered so that two bit operations per dword give the MFMA's int8 operand (chatglm_q_amd/csrc/w4a8.hip). */
+size_t qlinear_w4a8_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype);
+int qlinear_w4a8_pack(const uint8_t* Wq, const void* S, void* packed_a8, int64_t N, int64_t K, int64_t group, int dtype,
+                      void* stream);
+int qlinear_w4a8_fwd(const int8_t* Aq, const float* a_scale, const void* packed_a8, const void* bias, void* C, int64_t M,
+                     int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
+/* quantise A (flags: 0 row-wise, QL_FLAG_ACT_PER_TENSOR) into the workspace, then qlinear_w4a8_fwd: one call, two launches;
+ * workspace as for qlinear_w8a8_linear_tiled (QL_OP_W4A8_LINEAR). */
+int qlinear_w4a8_linear(const void* A, const void* packed_a8, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                        int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- quantised embedding gathers ("next" row N3) -------------------------------------------
  * ids: (count) int64 token ids.  int4: Wq (V/2, D) packs along the vocabulary axis, S (V/group, D).

@@ -300,6 +300,34 @@ def w8a8_matmul(a: np.ndarray, w_nk: np.ndarray, w_scale: np.ndarray,
     return out.reshape(*lead, w_nk.shape[0])
 
 
+def w4a8_group_acc_i32(a_q: np.ndarray, qweight: np.ndarray) -> np.ndarray:
+    """Exact integer stage of W4A8: per group of 32 k, (M, K) int8 x (K, N) int4 codes -> (G, M, N) int32.
+    Codes = nibble - 8 (chatglm_q/int4/qlinear.py:24-30, chatglm_q/int4/triton_ops.py:71-72)."""
+    codes = unpack_int4_codes(qweight).astype(np.int32)                   # (K, N)
+    k, n = codes.shape
+    g = k // DEFAULT_GROUP_SIZE
+    a3 = a_q.astype(np.int32).reshape(a_q.shape[0], g, DEFAULT_GROUP_SIZE)
+    return np.einsum("mgk,gkn->gmn", a3, codes.reshape(g, DEFAULT_GROUP_SIZE, n))
+
+
+def w4a8_matmul(a: np.ndarray, qweight: np.ndarray, scale: np.ndarray, bias: np.ndarray | None = None,
+                dtype: str | None = None, per_tensor: bool = False) -> np.ndarray:
+    """int4g32 weights x int8-quantised activations (SURVEY.md 8d config 5 "W4A8 act-quant path"): the activation side
+    of the int8 path - quantize_int8 per row (chatglm_q/int8/quantizer.py:11-19) or per tensor (chatglm_q/int8/
+    qlinear.py:64-70), integer matmul, Cast, Mul by the scales (qlinear.py:60-62) - with the int4 weight decode
+    (nibble - 8) * scale[group, column].  out = round(a_scale[m] * sum_g scale[g, n] * acc_i32[g, m, n]) (+ bias after
+    the cast, chatglm_q/int4/qlinear.py:92-93); the group sum is evaluated in float64 here."""
+    dt = dtype_of(scale, dtype)
+    lead = a.shape[:-1]
+    a_q, a_s = act_quant_per_tensor(a) if per_tensor else act_quant_rowwise(a)
+    acc = w4a8_group_acc_i32(a_q, qweight).astype(np.float64)             # (G, M, N)
+    y = np.einsum("gmn,gn->mn", acc, as_f64(scale)) * a_s.astype(np.float64)[:, None]
+    out = round_to(y, dt)
+    if bias is not None:
+        out = round_to(as_f64(out) + as_f64(bias)[None, :], dt)
+    return out.reshape(*lead, qweight.shape[1])
+
+
 # --------------------------------------------------------------------------
 # quantized embeddings ("next" row N3)
 # --------------------------------------------------------------------------
