@@ -104,7 +104,7 @@ inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t ksteps, size_t ws_bytes)
     static const int forced_ks = [] { const char* e = getenv("QLINEAR_GEMM_KSPLIT"); return e ? atoi(e) : 0; }();
     const int64_t nb = (N + 127) / 128;
     int mt = 1;
-    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
+    if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4 || forced_mt == 8) mt = forced_mt;
     else
         for (int t = 4; t > 1; t >>= 1)
             if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 512) { mt = t; break; }

@@ -282,6 +282,8 @@ static int launch_gemm_any(const void* A, const void* packed, const void* bias, 
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     switch (plan.mt) {
+    case 8:   // 256-row tiles, one wave per SIMD with the whole register file (QLINEAR_GEMM_MT=8: experiment)
+        return launch_gemm<T, 8, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     case 4:
         // 8 waves (256 columns) per block halve the A-tile traffic per flop; worth it once that grid still fills the chip
         if (((N + 255) / 256) * ((M + 127) / 128) >= 256)
