@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
     // TILED: W is the tile-major derived copy (w8_tile_kernel): [column tile][K step][lane][32 bytes], zero padded
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * NW + wave;
-    const int8_t* wrow = TILED ? W + ((int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps * 64 + lane) * 32
+    const int8_t* wrow = TILED ? W + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps * 2048 + lane * 16
                                : W + (int64_t)n * ldw + kb * 32;
     const float sc = SK ? 0.f : Act<T>::load(S + n);
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void w8_gemm_kernel(const T* __restrict__ 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kt * 64 + kb * 32 + h * 16;
-            if constexpr (TILED) sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)kt * 2048 + h * 16);
+            if constexpr (TILED) sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)kt * 2048 + h * 1024);   // 1 KB contiguous per wave
             else sg.w[h] = *reinterpret_cast<const u32x4*>(wrow + (k <= kmax_w ? kt * 64 + h * 16 : kmax_w - kb * 32));   // cacheable: re-read by other row tiles
         }
     };
@@ -361,13 +361,16 @@ int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, con
     }
 }
 
-// tile-major derived copy: Wm[ct][kt][lane][32 bytes], lane = 32 kb + j holds bytes k = 64 kt + 32 kb .. + 31 of output
-// channel 32 ct + j; rows past N and bytes past K are 0
+// tile-major derived copy: Wm[ct][kt][h][lane][16 bytes], lane = 32 kb + j, half h: bytes k = 64 kt + 32 kb + 16 h .. + 15 of
+// output channel 32 ct + j; rows past N and bytes past K are 0.  One wave load instruction = the 64 lanes' 16-byte pieces of
+// one half = 1 KB contiguous.  (Round 1 stored a lane's two halves side by side, [lane][32 bytes]: every 16-byte load
+// instruction then touched 16 cache lines and used half of each - measured in round 2 on the W8A8 GEMM, whose K loop
+// turned out to be bound by the CU's vector-memory pipe.)
 __global__ __launch_bounds__(256) void w8_tile_kernel(const int8_t* __restrict__ W, int8_t* __restrict__ Wm, int N, int K,
                                                       int64_t ldw, int ksteps, int64_t total16) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte piece: ((ct * ksteps + kt) * 64 + lane) * 2 + h
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte piece: ((ct * ksteps + kt) * 2 + h) * 64 + lane
     if (idx >= total16) return;
-    const int h = (int)(idx & 1), lane = (int)((idx >> 1) & 63);
+    const int lane = (int)(idx & 63), h = (int)((idx >> 6) & 1);
     const int64_t step = idx >> 7;
     const int kt = (int)(step % ksteps), ct = (int)(step / ksteps);
     const int n = ct * 32 + (lane & 31), k = kt * 64 + (lane >> 5) * 32 + h * 16;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
     asm volatile("s_mov_b32 %0, 0x00FF00FF" : "=s"(k_mask));
     asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(k_magic));
 
-    const int8_t* wtile = Wm + ((int64_t)blockIdx.x * ksteps * 64 + lane) * 32;
+    const int8_t* wtile = Wm + (int64_t)blockIdx.x * ksteps * 2048 + lane * 16;
     const float sc = Act<T>::load(S + (n_raw < N ? n_raw : N - 1));
     char* abuf = smem + wave * 8192;
 
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(KW * 64) void w8_fewrow_kernel(const T* __restrict_
                 sg.a[u] = *reinterpret_cast<const u32x4*>(a_src[u] + (k <= kmax ? kt * 64 : kmax - c_mine * 8));
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            sg.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wtile + (int64_t)kt * 2048 + h * 16));
+            sg.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wtile + (int64_t)kt * 2048 + h * 1024));
     };
     auto store_a = [&](int buf, const Stage& sg) {
 #pragma unroll

@@ -35,6 +35,17 @@ namespace ql {
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// QL_W8A8_STAMPS (developer build, tools/w8a8_timeline.sh): thread 0 of every block stamps s_memrealtime (100 MHz) at
+// fixed points of the GEMM kernel - a measured timeline of one launch instead of inferences from ablations.
+#ifdef QL_W8A8_STAMPS
+constexpr int kStampBlocks = 4096, kStampPoints = 8;
+__device__ unsigned long long ql_w8a8_stamps[kStampBlocks * kStampPoints];
+#define QL_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < ql::kStampBlocks) \
+        ql::ql_w8a8_stamps[blockIdx.x * ql::kStampPoints + (i)] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QL_STAMP(i) do { } while (0)
+#endif
+
 // =============================================================================================
 // activation quantisation
 // =============================================================================================
@@ -210,8 +221,8 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 
 // =============================================================================================
 // W8A8 GEMM on the tile-major weights
-//   Wm[ct][kt][lane][32 B] (w8_tile_kernel, w8_gemm.hip): lane = 32 kb + j holds bytes k = 64 kt + 32 kb + 0..31 of
-//   output channel 32 ct + j, zero padded.  One 32-deep MFMA sub-step consumes 16 of them: sub-step (u, h) of a
+//   Wm[ct][kt][h][lane][16 B] (w8_tile_kernel, w8_gemm.hip): lane = 32 kb + j, half h holds bytes k = 64 kt + 32 kb + 16 h
+//   + 0..15 of output channel 32 ct + j, zero padded.  One 32-deep MFMA sub-step consumes one half: sub-step (u, h) of a
 //   128-byte K step (u = which 64-byte unit, h = which half) uses k = 128 t + 64 u + 32 kb + 16 h + 0..15, so the
 //   A fragment of lane (i, kb) is the 16-byte chunk 4 u + 2 kb + h of row i's 128-byte line (any K assignment that
 //   is the same for both operands is valid: the contraction is a sum over k).
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+    QL_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
     const int grp = wave >> 2, wv = wave & 3;                     // tests and the buffer bases then live in SGPRs
     const int j = lane & 31, kb = lane >> 5;
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     const int niter = (nchunks + 1) >> 1;              // both groups run the same number of iterations (barriers!)
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * 4 + wv;
-    const int8_t* wbase = Wm + ((int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 64 + lane) * 32;
+    const int8_t* wbase = Wm + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 2048 + lane * 16;
     char* lds_a = smem + grp * (3 * BUF);
 
     // swizzle: chunk c of row r sits at chunk position CPR r + (c ^ x(r)); 128-byte rows: x = (r >> 1) & 7, 256-byte
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
             ua = ua < ksteps64 ? ua : ksteps64 - 1;
             const int8_t* w0 = wbase + (int64_t)ua * 2048;
             sg.w[2 * u] = *reinterpret_cast<const i32x4*>(w0);
-            sg.w[2 * u + 1] = *reinterpret_cast<const i32x4*>(w0 + 16);
+            sg.w[2 * u + 1] = *reinterpret_cast<const i32x4*>(w0 + 1024);
         }
     };
     auto load_a = [&](int i, i32x4 (&dst)[ACH]) {
@@ -381,10 +393,12 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
             if (d > 0) load_w(d, st[d]);
             load_a(d + 2, st[d].a);
         }
+        QL_STAMP(1);                                   // setup done, every prologue load issued
         store_a(0, a0);
         store_a(1, a1);
     }
     __syncthreads();
+    QL_STAMP(2);                                       // first A tiles in LDS: the first MFMA can go
     read_a(0, 0, fa[0]);
 
     // main loop, unrolled so that ring slot and LDS buffers are compile-time constants.  Iteration i: the A chunk of
@@ -404,6 +418,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
             if (!(QL_W8A8_ABLATE & 16)) __syncthreads();
         }
     }
+    QL_STAMP(3);                                       // main loop done
     // tail: prefetches only while there is something left to fetch; chunks may be partial / absent
 #pragma unroll
     for (int d = 0; d < U + DEPTH + 1; ++d) {
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
         }
     }
 
+    QL_STAMP(4);                                       // K loop done
     // epilogue operands requested NOW: their global round trip overlaps the exchange below instead of sitting in the
     // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
     const int n = n0 + wv * 32 + j;
@@ -465,6 +481,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
         }
     }
     __syncthreads();                                                       // LDS is reused for the output tiles below
+    QL_STAMP(5);                                       // K-parity groups combined
 
     if (QL_W8A8_ABLATE & 64) {                         // no epilogue: one store keeps the accumulators alive
         int x = 0;
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
             }
         }
     }
+    QL_STAMP(6);                                       // output tiles stored (this wave)
 }
 
 template <typename T, int MT, int S, int DEPTH>
@@ -549,3 +567,9 @@ int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int
 }
 
 }  // namespace ql
+
+#ifdef QL_W8A8_STAMPS
+extern "C" int qlinear_w8a8_stamps_read(unsigned long long* out, int blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_w8a8_stamps), sizeof(unsigned long long) * ql::kStampPoints * blocks);
+}
+#endif

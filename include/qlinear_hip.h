@@ -162,9 +162,9 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
                    void* stream);
 
 /* ---- int8 weights, derived tile-major copy (rows >= 3: MFMA kernels) ------------------------
- * tiled[N / 32][64-deep K step][lane][32 bytes]: lane = 32 kb + j holds bytes k = 64 kt + 32 kb .. + 31 of output
- * channel 32 (n / 32) + j, zero padded - the order in which the lanes of a wave feed their MFMA fragments, so a
- * wave's weight load is 2 KB contiguous (from the (N, K) buffer it is 32 bytes from each of 32 rows).  A lazily
+ * tiled[N / 32][64-deep K step][half h][lane][16 bytes]: lane = 32 kb + j, half h holds bytes k = 64 kt + 32 kb + 16 h .. + 15
+ * of output channel 32 (n / 32) + j, zero padded - the order in which the lanes of a wave feed their MFMA fragments: every
+ * wave load instruction reads 1 KB contiguous (from the (N, K) buffer it is 16 bytes from each of 32 rows).  A lazily
  * built, non-persistent copy like the int4 one; the (N, K) buffer stays the source of truth.  fp16 / bf16,
  * K % 16 == 0.  qlinear_w8_fwd_tiled: few-row kernel (independent K-slice waves) up to 32 rows, tiled GEMM above;
  * workspace as for qlinear_w8_fwd (QL_OP_W8_FWD_TILED, optional). */

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Reader of the QL_W8A8_STAMPS build (tools/w8a8_timeline.sh): per-block timestamps of one GEMM launch, printed as
+microseconds after the earliest block start: min / median / max over the blocks."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chatglm_q_amd import _lib  # noqa: E402
+from chatglm_q_amd.int8 import hip_ops as h8  # noqa: E402
+
+NAMES = ["wave start", "setup done, prologue loads issued", "first A tiles in LDS (barrier)", "main loop done", "K loop done",
+         "K-parity groups combined", "output stored"]
+
+
+def main():
+    M, K, N = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (512, 4096, 4096)))
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    tiled = [h8.tile_w8(torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g)) for _ in range(12)]
+    sc = (torch.rand(N, device=dev, generator=g) * 0.01 + 0.001).half()
+    a_q, a_s = h8.act_quant_rowwise(torch.randn(M, K, device=dev, dtype=torch.float16))
+    lib = _lib.get_lib()
+    lib.qlinear_w8a8_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    mt = 2 if M <= 512 else 4
+    blocks = ((N + 127) // 128) * ((M + 32 * mt - 1) // (32 * mt))
+    blocks = min(blocks, 4096)
+    rows = []
+    for rep in range(6):
+        for t in tiled[:-1]:
+            h8.w8a8_gemm_tiled(a_q, a_s, t, N, sc)          # keep the chip busy and clocked up
+        h8.w8a8_gemm_tiled(a_q, a_s, tiled[-1], N, sc)      # the launch that is read (stamps of the LAST launch survive)
+        torch.cuda.synchronize()
+        buf = np.zeros((blocks, 8), dtype=np.uint64)
+        assert lib.qlinear_w8a8_stamps_read(buf.ctypes.data, blocks) == 0
+        t = buf[:, :7].astype(np.int64)
+        t0 = t[:, 0].min()
+        rows.append((t - t0) * 0.01)
+    r = np.median(np.stack(rows), axis=0)                   # median over repetitions, per block and point
+    print(f"{M}x{K}x{N}: {blocks} blocks; microseconds after the earliest block start (min / median / max over blocks)")
+    for i, name in enumerate(NAMES):
+        col = r[:, i]
+        print(f"  {name:38s} {col.min():7.2f} {np.median(col):7.2f} {col.max():7.2f}")
+
+
+if __name__ == "__main__":
+    main()
