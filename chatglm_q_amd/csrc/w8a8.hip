@@ -401,6 +401,30 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     QL_STAMP(2);                                       // first A tiles in LDS: the first MFMA can go
     read_a(0, 0, fa[0]);
 
+    // K loop.  UNIFIED = one loop shape for every iteration (ring depth a multiple of 3: slot = i % DEPTH, LDS buffer =
+    // i % 3): every load unconditional - past the end it re-reads the last chunk (cache hits, never used) - and the trip
+    // count rounded up to the unroll (an extra iteration does no MFMAs).  The peeled form (main loop + tail with
+    // conditional loads) drains the ring in every tail iteration (hipcc's vmcnt bookkeeping turns conservative: vmcnt(0)
+    // in the ISA), and with K = 4096 the tail is most of the loop.
+    if constexpr (DEPTH % 3 == 0) {
+        for (int it = 0; it < niter; it += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int i = it + d;
+                const int buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+                store_a(wbuf, st[d].a);
+                const int t = chunk_of(i);
+                int units = ksteps64 - 2 * S * t;
+                units = (i >= niter || t >= nchunks) ? 0 : units;
+                if (units >= 2 * S) mma_chunk_full(buf, nbuf, st[d].w);
+                else mma_chunk_partial(buf, nbuf, st[d].w, units);
+                load_w(i + DEPTH, st[d]);
+                load_a(i + DEPTH + 2, st[d].a);
+                if (!(QL_W8A8_ABLATE & 16)) __syncthreads();
+            }
+        }
+        QL_STAMP(3);
+    } else {
     // main loop, unrolled so that ring slot and LDS buffers are compile-time constants.  Iteration i: the A chunk of
     // iteration i + 2 (in this slot since DEPTH iterations) goes to buffer (i + 2) % 3; MFMAs on buffer i % 3 with the
     // slot's W fragments; THEN the slot is re-loaded with W of i + DEPTH and A of i + DEPTH + 2 (loading first would need
@@ -433,6 +457,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
         }
     }
 
+    }
     QL_STAMP(4);                                       // K loop done
     // epilogue operands requested NOW: their global round trip overlaps the exchange below instead of sitting in the
     // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
@@ -550,7 +575,8 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
     if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 2) {
-        if (variant == 1) return launch_w8a8_tiled_mt<T, 2, 1, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+        if (variant == 1) return launch_w8a8_tiled_mt<T, 2, 1, 6>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+        if (variant == 2) return launch_w8a8_tiled_mt<T, 2, 2, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
         return launch_w8a8_tiled_mt<T, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     }
     return launch_w8a8_tiled_mt<T, 1, 2, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
