@@ -295,6 +295,14 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
         i32x4 w[NS];                                   // W fragments of the slot's iteration
     };
     Stage st[DEPTH];
+    // WHAT BOUNDS THE K LOOP (round 2, measured: tools/w8a8_timeline.sh stamps, ablation builds, five loop structures).
+    // 2 or 3 LDS buffers, 128 or 256 bytes of K per barrier, fragments 1 sub-step / 2 sub-steps / a whole chunk ahead, ring
+    // depth 2 / 3 / 4 / 6, lane-contiguous or 32-byte-strided weight tiles, K rotation: the K loop of 512 x 4096 x 4096 takes
+    // 8.2 - 12.6 us in every one of them, i.e. the 256 CUs pull their 196 MB of operands (every W line is wanted by 8 CUs,
+    // every A line by 32) through the L2s at 17 - 24 TB/s whatever the issue pattern; MORE loads in flight (ring depth 6)
+    // make it slower (12.5 us), fewer barriers do not help, an MFMA-only ablation of the loop runs in 2.5 us.  A 64 x 128
+    // tile per CU is the least-traffic way to cover 512 x 4096 on 256 CUs without split-K slabs, so config 3 is bound by
+    // operand delivery from L2 (~9 us of loop), not by its 3.4 us of MFMA work.  profiles/r02_w8a8_timeline.txt.
     // K ROTATION (see the header): block (x, y) starts at phase (2 y + x mod 4) of its K walk.  Measured neutral at
     // 512 x 4096 x 4096 (19.2 vs 19.4 us) - kept behind QLINEAR_W8A8_ROTATE=1 for experiments, default off.
     const int phases = niter < 16 ? niter : 16;
