@@ -55,8 +55,10 @@ summary = {
 with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 for a, b in (("bench/bench_kernel_stats.csv", "bench_kernel_stats.csv"), ("decode/decode_kernel_stats.csv", "decode_step_kernel_stats.csv"),
-             ("prefill/prefill_kernel_stats.csv", "prefill_kernel_stats.csv")):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
+             ("prefill/prefill_kernel_stats.csv", "prefill_kernel_stats.csv"), ("w8a8/w8a8_kernel_stats.csv", "w8a8_kernel_stats.csv"),
+             ("w4a8/w4a8_kernel_stats.csv", "w4a8_kernel_stats.csv")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
 for a, b in (("bench_unprofiled.json", "bench_unprofiled.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json")):
     line = open(os.path.join(src, a)).read().strip().split("\n")[-1]
     with open(os.path.join(dst, f"{tag}_{b}"), "w") as f:

@@ -14,6 +14,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o decode -- python $ROOT/tools/profile_decode.py 64 > $OUT/decode.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefill -o prefill -- python $ROOT/tools/profile_prefill.py > $OUT/prefill.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w8a8 -o w8a8 -- python $ROOT/tools/w8a8_config3.py > $OUT/w8a8.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w4a8 -o w4a8 -- python $ROOT/tools/w4a8_sweep.py 8192 > $OUT/w4a8.log 2>&1
+find $OUT/w8a8 $OUT/w4a8 -name "*kernel_trace.csv" -delete
 # keep only what fits the 64 MiB return budget: stats and (for the PMC / bench runs) the counter / kernel trace tables
 find $OUT -name "*_agent_info.csv" -delete
 find $OUT/decode $OUT/prefill -name "*kernel_trace.csv" -delete
