@@ -281,6 +281,11 @@ template <typename T>
 static int launch_gemm_any(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
+    static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
+    if (forced_nt == 2 && plan.mt == 4)       // 64 columns per wave: every A fragment feeds two MFMAs (experiment)
+        return launch_gemm<T, 4, 2, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    if (forced_nt == 2 && plan.mt == 2)
+        return launch_gemm<T, 2, 2, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     switch (plan.mt) {
     case 8:   // 256-row tiles, one wave per SIMD with the whole register file (QLINEAR_GEMM_MT=8: experiment)
         return launch_gemm<T, 8, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);

@@ -70,6 +70,18 @@ class DecodeSession:
         self.graph = None
         self.length = 0
 
+    def reset(self):
+        """Forget the sequences (not the captured graph): the session can serve the next generation.  Cache rows need no
+        clearing - every position is masked until a prefill / decode step writes and unmasks it."""
+        self.length = 0
+        self.cache.length = 0
+        self.pad_cols.zero_()
+        self.n_tokens.zero_()
+        self.write_index.zero_()
+        self.pos.zero_()
+        self.mask.fill_(-1e10)
+        return self
+
     # -- prefill -------------------------------------------------------------------------------------
     @torch.no_grad()
     def prefill(self, ids: Tensor, chunk: Optional[int] = None, attention_mask: Optional[Tensor] = None) -> Tensor:
@@ -134,6 +146,8 @@ class DecodeSession:
         """Capture one decode step.  Every weight's derived layout must already exist (module.prepare())."""
         if not self.use_graph:
             return
+        if self.graph is not None and self._captured_greedy == greedy:
+            return                                              # a reused session keeps its graph (static addresses)
         saved = (self.tok.clone(), self.write_index.clone(), self.pos.clone(), self.mask.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -177,6 +191,17 @@ class ChatGLMDecoder:
         self.time_log = time_log
         self.last_stats: dict = {}
 
+    def _session_for(self, capacity: int, use_graph: Optional[bool]) -> DecodeSession:
+        """One DecodeSession (cache + captured HIP graph) is kept and reused while the requested capacity fits and the
+        model's parameters have not moved; a generation then costs no allocation and no re-capture."""
+        p = self.model.final_ln.weight
+        key = (p.device, p.dtype, p.data_ptr(), use_graph)
+        sess = getattr(self, "_session", None)
+        if sess is not None and self._session_key == key and sess.capacity >= capacity:
+            return sess.reset()
+        self._session, self._session_key = DecodeSession(self.model, 1, capacity, use_graph), key
+        return self._session
+
     @torch.no_grad()
     def generate_ids(self, prefix_ids: Iterable[int], max_generated_tokens: int = 400, top_k: int = 100,
                      top_p: float = 0.8, temperature: float = 1.0, greedy: bool = False, ignore_eos: bool = False,
@@ -187,7 +212,7 @@ class ChatGLMDecoder:
         if budget <= 0:
             return
         capacity = -(-(len(prefix) + budget) // 64) * 64
-        sess = DecodeSession(self.model, 1, capacity, use_graph)
+        sess = self._session_for(capacity, use_graph)
         times = []
         sync = (lambda: torch.cuda.synchronize(sess.device)) if sess.device.type == "cuda" else (lambda: None)
 

@@ -131,3 +131,22 @@ def test_reference_training_contract_labels_loss_backward():
     with torch.no_grad():
         _, ref_logits, _ = model(input_ids=ids)
     assert torch.allclose(logits, ref_logits, atol=1e-5, rtol=1e-5)      # same function with and without the graph
+
+
+def test_decoder_reuses_its_session_across_generations():
+    """every generate_ids() used to allocate a new cache (and re-capture a HIP graph on the GPU).  One session
+    is now kept while the capacity fits; a second, different prompt through the reused session equals a fresh decoder."""
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    model, cfg = build("f32")
+    p1 = Z["f32/ids"][0].tolist()
+    p2 = [(7 * t + 3) % cfg.vocab_size for t in range(5)]
+    dec = ChatGLMDecoder(None, model)
+    a1 = list(dec.generate_ids(p1, max_generated_tokens=6, greedy=True, ignore_eos=True))
+    sess = dec._session
+    a2 = list(dec.generate_ids(p2, max_generated_tokens=6, greedy=True, ignore_eos=True))
+    assert dec._session is sess                                   # reused, not rebuilt
+    fresh = list(ChatGLMDecoder(None, model).generate_ids(p2, max_generated_tokens=6, greedy=True, ignore_eos=True))
+    assert a2 == fresh and len(a1) == 6
+    sess.capacity = 8                                             # pretend the kept session is too small for the next request
+    list(dec.generate_ids(p1, max_generated_tokens=6, greedy=True, ignore_eos=True))
+    assert dec._session is not sess and dec._session.capacity >= len(p1) + 6
