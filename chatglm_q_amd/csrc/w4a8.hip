@@ -108,8 +108,9 @@ int w4a8_pack(int dtype, const uint8_t* Wq, const void* S, void* out, int64_t N,
 // =============================================================================================
 // GEMM.  One loop iteration of a K-parity group covers 128 bytes of K = 4 groups = 2 tile-major units.
 // =============================================================================================
-template <typename T, int MT, int DEPTH>
-__global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq, const u32x4* __restrict__ Wa,
+// NG: K-parity groups per block, as in w8a8_tiled_kernel (2: one 8-wave block per CU; 1: two independent 4-wave blocks).
+template <typename T, int MT, int DEPTH, int NG>
+__global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const int8_t* __restrict__ Aq, const u32x4* __restrict__ Wa,
                                                    const T* __restrict__ Sa, int M, int N, int K, int nbx,
                                                    const float* __restrict__ a_scale, const T* __restrict__ bias,
                                                    T* __restrict__ C, int64_t ldc) {
@@ -124,14 +125,14 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
 
     const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wv = wave & 3;
+    const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;
     const int j = lane & 31, kb = lane >> 5;
     const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
     const int m0 = tile.y * BM, n0 = tile.x * 128;
     const int G = K >> 5;
     const int ksteps = (G + 1) >> 1;                   // 64-deep units per column tile
     const int nchunks = (K + BK - 1) / BK;
-    const int niter = (nchunks + 1) >> 1;
+    const int niter = NG == 1 ? nchunks : (nchunks + 1) >> 1;
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * 4 + wv;
     const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
         u32 s[2];                                      // their scales (two per unit)
     };
     Stage st[DEPTH];
-    auto chunk_of = [&](int i) { return 2 * (i < niter ? i : niter - 1) + grp; };
+    auto chunk_of = [&](int i) { return NG * (i < niter ? i : niter - 1) + grp; };
     auto load_w = [&](int i, Stage& sg) {
         int t = chunk_of(i);
         t = t < nchunks ? t : nchunks - 1;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
         if (i < niter) {
             const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
             if (i + 2 < niter) store_a(wbuf, st[slot].a);
-            const int t = 2 * i + grp;
+            const int t = NG * i + grp;
             int groups = G - 4 * t;
             groups = t >= nchunks ? 0 : groups;
             if (groups >= 4) mma_chunk_full(buf, nbuf, st[slot]);
@@ -315,11 +316,13 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
 
     // epilogue operands requested before the exchange (their round trip overlaps it)
     const int n = n0 + wv * 32 + j;
-    constexpr int OWN = MT == 1 ? 1 : MT / 2;
+    constexpr int OWN = NG == 1 ? MT : (MT == 1 ? 1 : MT / 2);
+    auto owner_of = [](int mt) { return (NG == 1 || MT == 1) ? 0 : (mt & 1); };
+    auto own_slot = [](int mt) { return NG == 1 ? mt : (mt >> 1); };
     float asc[OWN][16];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-        const int mt = MT == 1 ? 0 : 2 * o + grp;
+        const int mt = NG == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
@@ -327,42 +330,43 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
         }
     }
     // combine the two K-parity groups (fp32 partial sums): row tile mt is finished by group mt & 1 (MT == 1: group 0)
-    constexpr int SLOTS = (MT + 1) / 2;
-    f32x4* xch = reinterpret_cast<f32x4*>(smem);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner != grp) {
-            const int slot = mt >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
-                    f32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner == grp) {
-            const int slot = mt >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+    if constexpr (NG == 2) {
+        constexpr int SLOTS = (MT + 1) / 2;
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int owner = owner_of(mt);
+            if (owner != grp) {
+                const int slot = mt >> 1;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
+                        f32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
             }
         }
+        __syncthreads();
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int owner = owner_of(mt);
+            if (owner == grp) {
+                const int slot = mt >> 1;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+                }
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner != grp) continue;
-        const int o = mt >> 1;
+        if (owner_of(mt) != grp) continue;
+        const int o = own_slot(mt);
         if constexpr (sizeof(T) == 2) {
             if (wide) {
                 store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
@@ -381,19 +385,20 @@ __global__ __launch_bounds__(512) void w4a8_kernel(const int8_t* __restrict__ Aq
     }
 }
 
-template <typename T, int MT, int DEPTH>
+template <typename T, int MT, int DEPTH, int NG>
 static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
                           int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     constexpr int BM = 32 * MT;
     const W4A8Layout L = w4a8_layout(N, K, sizeof(T));
     const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
-    constexpr int kLds = 6 * BM * 128 < 16384 ? 16384 : 6 * BM * 128;
+    constexpr int kTiles = NG * 3 * BM * 128;
+    constexpr int kLds = kTiles < NG * 8192 ? NG * 8192 : kTiles;
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4a8_kernel<T, MT, DEPTH>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4a8_kernel<T, MT, DEPTH, NG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
-    w4a8_kernel<T, MT, DEPTH><<<(unsigned)(nbx * nby), 512, kLds, st>>>(
+    w4a8_kernel<T, MT, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, (const u32x4*)packed, (const T*)((const char*)packed + L.off_s), (int)M, (int)N, (int)K,
         xcd_order(nbx, nby, (double)M * K, (double)N * K / 2), a_scale, (const T*)bias, (T*)C, ldc);
     return finish_launch();
@@ -403,15 +408,19 @@ template <typename T>
 static int launch_w4a8(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
                        int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     static const int forced_mt = [] { const char* e = getenv("QLINEAR_W4A8_MT"); return e ? atoi(e) : 0; }();
+    static const int forced_ng = [] { const char* e = getenv("QLINEAR_W4A8_NG"); return e ? atoi(e) : 0; }();
     const int64_t nb = (N + 127) / 128;
     int mt = 1;
     for (int t = 4; t > 1; t >>= 1)
         if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 256) { mt = t; break; }
     if (mt == 1 && M > 32) mt = 2;
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
-    if (mt == 4) return launch_w4a8_mt<T, 4, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
-    if (mt == 2) return launch_w4a8_mt<T, 2, 3>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
-    return launch_w4a8_mt<T, 1, 3>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
+    if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
+    if (mt == 4 && ng == 1) return launch_w4a8_mt<T, 4, 2, 1>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    if (mt == 4) return launch_w4a8_mt<T, 4, 2, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    if (mt == 2) return launch_w4a8_mt<T, 2, 3, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    return launch_w4a8_mt<T, 1, 3, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
 }
 
 int w4a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,

@@ -229,8 +229,12 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 //   Block = 8 waves: wave w serves column tile (w & 3) of the block's 128 columns and K-parity group (w >> 2).
 //   LDS: per group two A-tile buffers of BM x 128 bytes, chunk c of row r at chunk position 8 r + (c ^ ((r >> 1) & 7)).
 // =============================================================================================
-template <typename T, int MT, int S, int DEPTH>
-__global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
+// NG = K-parity groups per block: 2 (8 waves; the shape for few row tiles, where a CU gets ONE block and the two groups
+// are its only latency hiding) or 1 (4 waves, <= 256 registers, no combine step: two independent blocks per CU whose
+// prologues / epilogues overlap each other's K loop - the many-row shape; one 8-wave block per CU showed 6.4 us of setup,
+// first-tile latency and epilogue around every 19 us loop, profiles/r02_w8a8_timeline.txt).
+template <typename T, int MT, int S, int DEPTH, int NG>
+__global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
                                                          int N, int K, int nbx, int rotate, const float* __restrict__ a_scale,
                                                          const T* __restrict__ S_, const T* __restrict__ bias,
                                                          T* __restrict__ C, int64_t ldc) {
@@ -250,13 +254,13 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
     QL_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
-    const int grp = wave >> 2, wv = wave & 3;                     // tests and the buffer bases then live in SGPRs
+    const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;       // tests and the buffer bases then live in SGPRs
     const int j = lane & 31, kb = lane >> 5;
     const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
     const int m0 = tile.y * BM, n0 = tile.x * 128;
     const int ksteps64 = (K + 63) >> 6;                // tile-major units per column tile
     const int nchunks = (K + BK - 1) / BK;
-    const int niter = (nchunks + 1) >> 1;              // both groups run the same number of iterations (barriers!)
+    const int niter = NG == 1 ? nchunks : (nchunks + 1) >> 1;   // both groups run the same number of iterations (barriers!)
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * 4 + wv;
     const int8_t* wbase = Wm + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 2048 + lane * 16;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     auto chunk_of = [&](int i) {                       // K chunk of loop iteration i (i may run past niter: clamped by users)
         int r = i + rot;
         r = r >= niter ? r - niter : r;
-        return 2 * r + grp;
+        return NG * r + grp;
     };
     auto load_w = [&](int i, Stage& sg) {
         int t = chunk_of(i < niter ? i : niter - 1);
@@ -471,11 +475,13 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
     const int n = n0 + wv * 32 + j;
     const float ws = Act<T>::load(Sc + (n < N ? n : N - 1));
-    constexpr int OWN = MT == 1 ? 1 : MT / 2;                              // row tiles this group finishes
+    constexpr int OWN = NG == 1 ? MT : (MT == 1 ? 1 : MT / 2);            // row tiles this group finishes
+    auto owner_of = [](int mt) { return (NG == 1 || MT == 1) ? 0 : (mt & 1); };
+    auto own_slot = [](int mt) { return NG == 1 ? mt : (mt >> 1); };
     float asc[OWN][16];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-        const int mt = MT == 1 ? 0 : 2 * o + grp;
+        const int mt = NG == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
@@ -486,34 +492,36 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     // ---- combine the two K-parity groups through LDS (exact: int32), then the rank-1 scale epilogue ----------
     // row tile mt is finished by group (mt & 1) (MT == 1: group 0): each group hands the OTHER group's tiles over
     // as 16-byte pieces [tile slot][piece q][lane] - consecutive lanes, consecutive 16 bytes: conflict-free
-    constexpr int SLOTS = (MT + 1) / 2;                                    // tiles a group receives
-    i32x4* xch = reinterpret_cast<i32x4*>(smem);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner != grp) {
-            const int slot = mt >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
-                    i32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner == grp) {
-            const int slot = mt >> 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const i32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+    if constexpr (NG == 2) {
+        constexpr int SLOTS = (MT + 1) / 2;                                    // tiles a group receives
+        i32x4* xch = reinterpret_cast<i32x4*>(smem);
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int owner = owner_of(mt);
+            if (owner != grp) {
+                const int slot = mt >> 1;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xch[(((owner * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane] =
+                        i32x4{acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
             }
         }
+        __syncthreads();
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int owner = owner_of(mt);
+            if (owner == grp) {
+                const int slot = mt >> 1;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32x4 o = xch[(((grp * 4 + wv) * SLOTS + slot) * 4 + q) * 64 + lane];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += o[e];
+                }
+            }
+        }
+        __syncthreads();                                                       // LDS is reused for the output tiles below
     }
-    __syncthreads();                                                       // LDS is reused for the output tiles below
     QL_STAMP(5);                                       // K-parity groups combined
 
     if (QL_W8A8_ABLATE & 64) {                         // no epilogue: one store keeps the accumulators alive
@@ -529,9 +537,8 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;     // 2 KB per wave (16 KB <= the A buffers)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int owner = MT == 1 ? 0 : (mt & 1);
-        if (owner != grp) continue;
-        const int o = mt >> 1;
+        if (owner_of(mt) != grp) continue;
+        const int o = own_slot(mt);
         if constexpr (sizeof(T) == 2) {
             if (wide) {
                 store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
@@ -551,19 +558,20 @@ __global__ __launch_bounds__(512) void w8a8_tiled_kernel(const int8_t* __restric
     QL_STAMP(6);                                       // output tiles stored (this wave)
 }
 
-template <typename T, int MT, int S, int DEPTH>
+template <typename T, int MT, int S, int DEPTH, int NG>
 static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* Sc, const void* bias, void* C,
                                 int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     constexpr int BM = 32 * MT;
     const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
-    constexpr int kLds = 6 * BM * 128 * S < 16384 ? 16384 : 6 * BM * 128 * S;   // two groups x three buffers (epilogue: 2 KB per wave)
+    constexpr int kTiles = NG * 3 * BM * 128 * S;                               // NG groups x three A buffers
+    constexpr int kLds = kTiles < NG * 8192 ? NG * 8192 : kTiles;              // epilogue: 2 KB per wave
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH, NG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
     static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch
-    w8a8_tiled_kernel<T, MT, S, DEPTH><<<(unsigned)(nbx * nby), 512, kLds, st>>>(
+    w8a8_tiled_kernel<T, MT, S, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, a_scale, (const T*)Sc,
         (const T*)bias, (T*)C, ldc);
     return finish_launch();
@@ -573,7 +581,7 @@ template <typename T>
 static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
                              int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     static const int forced_mt = [] { const char* e = getenv("QLINEAR_W8A8_MT"); return e ? atoi(e) : 0; }();
-    static const int variant = [] { const char* e = getenv("QLINEAR_W8A8_VARIANT"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    static const int forced_ng = [] { const char* e = getenv("QLINEAR_W8A8_NG"); return e ? atoi(e) : 0; }();   // tuning sweeps
     const int64_t nb = (N + 127) / 128;
     // tallest row tile that still gives every CU a block
     int mt = 1;
@@ -581,13 +589,13 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
         if (M > 16 * t && nb * ((M + 32 * t - 1) / (32 * t)) >= 256) { mt = t; break; }
     if (mt == 1 && M > 32) mt = 2;
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
-    if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-    if (mt == 2) {
-        if (variant == 1) return launch_w8a8_tiled_mt<T, 2, 1, 6>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-        if (variant == 2) return launch_w8a8_tiled_mt<T, 2, 2, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-        return launch_w8a8_tiled_mt<T, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-    }
-    return launch_w8a8_tiled_mt<T, 1, 2, 3>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    // two independent 4-wave blocks per CU once there are at least two 128-row tiles per CU
+    int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
+    if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
+    if (mt == 4 && ng == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 1>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    if (mt == 2) return launch_w8a8_tiled_mt<T, 2, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    return launch_w8a8_tiled_mt<T, 1, 2, 3, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 }
 
 int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
