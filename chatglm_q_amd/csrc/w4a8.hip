@@ -111,7 +111,7 @@ int w4a8_pack(int dtype, const uint8_t* Wq, const void* S, void* out, int64_t N,
 // NG: K-parity groups per block, as in w8a8_tiled_kernel (2: one 8-wave block per CU; 1: two independent 4-wave blocks).
 template <typename T, int MT, int DEPTH, int NG>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const int8_t* __restrict__ Aq, const u32x4* __restrict__ Wa,
-                                                   const T* __restrict__ Sa, int M, int N, int K, int nbx,
+                                                   const T* __restrict__ Sa, int M, int N, int K, int nbx, int super_rows,
                                                    const float* __restrict__ a_scale, const T* __restrict__ bias,
                                                    T* __restrict__ C, int64_t ldc) {
     constexpr int BM = 32 * MT;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;
     const int j = lane & 31, kb = lane >> 5;
-    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
     const int m0 = tile.y * BM, n0 = tile.x * 128;
     const int G = K >> 5;
     const int ksteps = (G + 1) >> 1;                   // 64-deep units per column tile
@@ -398,9 +398,12 @@ static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* pa
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
+    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
+    const int sy = NG == 1 ? 8 : 4;
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;    // ql_common.h: xcd_tile_super
     w4a8_kernel<T, MT, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, (const u32x4*)packed, (const T*)((const char*)packed + L.off_s), (int)M, (int)N, (int)K,
-        xcd_order(nbx, nby, (double)M * K, (double)N * K / 2), a_scale, (const T*)bias, (T*)C, ldc);
+        super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K / 2), super ? sy : 0, a_scale, (const T*)bias, (T*)C, ldc);
     return finish_launch();
 }
 

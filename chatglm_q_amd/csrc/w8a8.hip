@@ -235,7 +235,7 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 // first-tile latency and epilogue around every 19 us loop, profiles/r02_w8a8_timeline.txt).
 template <typename T, int MT, int S, int DEPTH, int NG>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
-                                                         int N, int K, int nbx, int rotate, const float* __restrict__ a_scale,
+                                                         int N, int K, int nbx, int rotate, int super_rows, const float* __restrict__ a_scale,
                                                          const T* __restrict__ S_, const T* __restrict__ bias,
                                                          T* __restrict__ C, int64_t ldc) {
     // One loop iteration of a K-parity group covers a CHUNK of BK = 128 S bytes of K (S 128-byte steps = 2 S tile-major
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
     const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;       // tests and the buffer bases then live in SGPRs
     const int j = lane & 31, kb = lane >> 5;
-    const TileXY tile = xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
     const int m0 = tile.y * BM, n0 = tile.x * 128;
     const int ksteps64 = (K + 63) >> 6;                // tile-major units per column tile
     const int nchunks = (K + BK - 1) / BK;
@@ -571,8 +571,12 @@ static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const in
     }();
     (void)attr_set;
     static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch
+    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
+    const int sy = NG == 1 ? 8 : 4;                    // blocks in flight per XCD: 64 (two per CU) or 32
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w8a8_tiled_kernel<T, MT, S, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
-        Aq, Wm, (int)M, (int)N, (int)K, xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, a_scale, (const T*)Sc,
+        Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, super ? sy : 0,
+        a_scale, (const T*)Sc,
         (const T*)bias, (T*)C, ldc);
     return finish_launch();
 }
