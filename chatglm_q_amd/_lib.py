@@ -51,6 +51,13 @@ EXPORTS = {
                                         c_int64, c_int, c_void_p]),
     "qlinear_w4g32_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4g32_gemv_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "qlinear_w4g32_tiled_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "qlinear_w4g32_repack_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4g32_tile": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4g32_fwd_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                        c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_fwd_tiled_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                          c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w4g32_fwd_packed_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,

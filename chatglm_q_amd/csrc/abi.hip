@@ -114,6 +114,47 @@ int qlinear_w4g32_repack(const uint8_t* Wq, const void* S, void* packed, int64_t
     return w4_repack(dtype, Wq, S, packed, N, K, (hipStream_t)stream);
 }
 
+size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
+    if (N <= 0 || K <= 0 || group != 32 || K % 32 != 0 || !dtype_ok(dtype)) return 0;
+    return w4_layout(N, K, esize(dtype)).off_wm;
+}
+
+size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype) {
+    if (N <= 0 || K <= 0 || group != 32 || K % 32 != 0 || (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16)) return 0;
+    const W4Layout L = w4_layout(N, K, esize(dtype));
+    return L.bytes - L.off_wm;
+}
+
+int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, int64_t group, int dtype,
+                              void* stream) {
+    if (!Wq || !S || !gemv) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || (K & 1)) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(gemv, 16)) return QL_ERR_MISALIGNED;
+    return w4_repack_gemv(dtype, Wq, S, gemv, N, K, (hipStream_t)stream);
+}
+
+int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int64_t group, int dtype, void* stream) {
+    if (!gemv || !tiled) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || N <= 0 || K <= 0) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(gemv, 16) || !aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    return w4_tile(dtype, gemv, tiled, N, K, (hipStream_t)stream);
+}
+
+int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                            int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+    if (!A || !tiled || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
+    return w4_tiled(dtype, A, tiled, bias, C, M, N, K, lda, ldc, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                              int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, int flags,
                              void* workspace, size_t workspace_bytes, void* stream) {
@@ -143,18 +184,27 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
     return w4_packed_fused(dtype, prologue, gate, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
 }
 
-int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-                                   int64_t lda, int64_t ldc, int dtype, void* stream) {
-    if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
+int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!A || !tiled || !C) return QL_ERR_NULL_POINTER;
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || N % 4 != 0 || lda < K ||
         ldc < N / 2)
         return QL_ERR_BAD_SHAPE;
-    if (!aligned(packed, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
+    if (!aligned(tiled, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
     // the epilogue lives in the few-row kernel without K slabs (wide first MLP projections, 3..32 rows)
     if (!w4_rows_use_gemm(M, N, K) || !w4_fewrow_supported(M, N, K) || w4_fewrow_workspace_bytes(M, N, K) != 0 || N % 32 != 0)
         return QL_ERR_UNSUPPORTED;
-    return w4_fewrow(dtype, A, packed, bias, C, M, N, K, lda, ldc, nullptr, 0, (hipStream_t)stream, true);
+    return w4_fewrow(dtype, A, tiled, bias, C, M, N, K, lda, ldc, nullptr, 0, (hipStream_t)stream, true);
+}
+
+int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!packed) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (N <= 0 || K <= 0 || K % 32 != 0) return QL_ERR_BAD_SHAPE;
+    return qlinear_w4g32_fwd_tiled_gated(A, (const char*)packed + w4_layout(N, K, 2).off_wm, bias, C, M, N, K, lda, ldc, dtype,
+                                         stream);
 }
 
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,

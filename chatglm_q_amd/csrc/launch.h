@@ -46,6 +46,9 @@ inline W4Layout w4_layout(int64_t N, int64_t K, size_t esize) {
     L.bytes = L.off_sm + (size_t)(L.ctiles * L.ksteps) * 64 * esize;
     return L;
 }
+// The two parts may also live in two allocations (qlinear_w4g32_repack_gemv / qlinear_w4g32_tile): part 1 is then a
+// buffer of off_wm bytes, part 2 ("tiled") one of bytes - off_wm, its scales at off_sm - off_wm.  The MFMA launchers
+// take the address of part 2, the GEMV launchers the address of part 1.
 
 constexpr int64_t kCanonMChunk = 64;   // rows per pass of the canonical split-K path (bounds the workspace)
 
@@ -55,7 +58,11 @@ int w4_generic(int dtype, const void* A, const uint8_t* Wq, const void* S, const
 size_t w4_canon_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int w4_canon(int dtype, const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C, void* ws,
              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
-int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st);
+int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st);   // both parts, one buffer
+int w4_repack_gemv(int dtype, const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st);     // part 1 only
+int w4_tile(int dtype, const void* gemv, void* tiled, int64_t N, int64_t K, hipStream_t st);                          // part 2 from part 1
+int w4_tiled(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+             int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // any row count on part 2 (fp16 / bf16)
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st);
 
@@ -65,16 +72,16 @@ int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, cons
                     int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 
 // w4_gemm.hip (M > 4, fp16 / bf16, MFMA)
-int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
-                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
+int w4_packed_gemm(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // tiled: part 2
 size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K);
 size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K);   // of whichever kernel w4_packed() picks
 // w4_fewrow.hip (rows <= 32, fp16 / bf16): independent K-slice waves, MFMA
 bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K);
 size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate = false);   // w4_packed.hip: GEMV or GEMM for this row count
+int w4_fewrow(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate = false);   // tiled: part 2
 
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,

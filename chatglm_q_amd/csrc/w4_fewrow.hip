@@ -277,14 +277,14 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 template <typename T, int NT, int MT>
-static int launch_fewrow_nt(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
+static int launch_fewrow_nt(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda,
                             int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
     constexpr int KW = kFewRowWaves;
     const FewRowPlan plan = fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const int64_t G = L.G;
-    const u32x4* Wt = (const u32x4*)((const char*)packed + L.off_wm);
-    const T* Sp = (const T*)((const char*)packed + L.off_sm);
+    const u32x4* Wt = (const u32x4*)tiled;
+    const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
     float* part = plan.ksplit > 1 ? (float*)ws : nullptr;
     if (gate && (part || N % 32 != 0)) return QL_ERR_UNSUPPORTED;   // the gate epilogue lives in this kernel only
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
@@ -300,16 +300,16 @@ static int launch_fewrow_nt(const void* A, const void* packed, const void* bias,
 }
 
 template <typename T>
-static int launch_fewrow(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
+static int launch_fewrow(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda,
                          int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
-    return launch_fewrow_nt<T, 1, 1>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
+    return launch_fewrow_nt<T, 1, 1>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
 }
 
-int w4_fewrow(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+int w4_fewrow(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
     switch (dtype) {
-    case QL_DTYPE_F16: return launch_fewrow<f16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
-    case QL_DTYPE_BF16: return launch_fewrow<__bf16>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
+    case QL_DTYPE_F16: return launch_fewrow<f16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
+    case QL_DTYPE_BF16: return launch_fewrow<__bf16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, ws, ws_bytes, st, gate);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

@@ -257,12 +257,12 @@ __global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __rest
 }
 
 template <typename T, int MT, int NT, int NW>
-static int launch_gemm(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
+static int launch_gemm(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda,
                        int64_t ldc, const GemmPlan& plan, float* ws, hipStream_t st) {
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const int64_t G = L.G;
-    const u32x4* Wt = (const u32x4*)((const char*)packed + L.off_wm);     // tile-major part
-    const T* Sp = (const T*)((const char*)packed + L.off_sm);
+    const u32x4* Wt = (const u32x4*)tiled;                                 // tile-major part
+    const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
     float* part = plan.ksplit > 1 ? ws : nullptr;
     constexpr int BN = NW * 32 * NT;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
@@ -278,34 +278,34 @@ static int launch_gemm(const void* A, const void* packed, const void* bias, void
 
 
 template <typename T>
-static int launch_gemm_any(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+static int launch_gemm_any(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
     if (forced_nt == 2 && plan.mt == 4)       // 64 columns per wave: every A fragment feeds two MFMAs (experiment)
-        return launch_gemm<T, 4, 2, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+        return launch_gemm<T, 4, 2, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     if (forced_nt == 2 && plan.mt == 2)
-        return launch_gemm<T, 2, 2, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+        return launch_gemm<T, 2, 2, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     switch (plan.mt) {
     case 8:   // 256-row tiles, one wave per SIMD with the whole register file (QLINEAR_GEMM_MT=8: experiment)
-        return launch_gemm<T, 8, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+        return launch_gemm<T, 8, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     case 4:
         // 8 waves (256 columns) per block halve the A-tile traffic per flop; worth it once that grid still fills the chip
         if (((N + 255) / 256) * ((M + 127) / 128) >= 256)
-            return launch_gemm<T, 4, 1, 8>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
-        return launch_gemm<T, 4, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
-    case 2: return launch_gemm<T, 2, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
-    default: return launch_gemm<T, 1, 1, 4>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+            return launch_gemm<T, 4, 1, 8>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+        return launch_gemm<T, 4, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    case 2: return launch_gemm<T, 2, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
+    default: return launch_gemm<T, 1, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     }
 }
 
 size_t w4_packed_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) { return gemm_workspace_bytes(M, N, (K / 32 + 1) / 2); }
 
-int w4_packed_gemm(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+int w4_packed_gemm(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (dtype) {
-    case QL_DTYPE_F16: return launch_gemm_any<f16>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
-    case QL_DTYPE_BF16: return launch_gemm_any<__bf16>(A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_F16: return launch_gemm_any<f16>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    case QL_DTYPE_BF16: return launch_gemm_any<__bf16>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

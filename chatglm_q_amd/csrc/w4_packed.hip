@@ -661,19 +661,23 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-static int launch_w4_repack(const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
+static int launch_w4_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st) {
     const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
-    u32x4* Wt = (u32x4*)packed;
-    T* Sp = (T*)((char*)packed + Npad * G * 16);
+    u32x4* Wt = (u32x4*)gemv;
+    T* Sp = (T*)((char*)gemv + Npad * G * 16);
     dim3 grid((unsigned)((Npad + 255) / 256), (unsigned)G);
     w4_repack_kernel<T><<<grid, 256, 0, st>>>(Wq, (const T*)S, Wt, Sp, (int)N, (int)Npad, (int)G);
-    const int rc = finish_launch();
-    if (rc != 0) return rc;
+    return finish_launch();
+}
+
+// part 2 (tile-major) from part 1: the two may be one buffer (tiled = gemv + off_wm) or two allocations
+template <typename T>
+static int launch_w4_tile(const void* gemv, void* tiled, int64_t N, int64_t K, hipStream_t st) {
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const int64_t total = L.ctiles * L.ksteps * 64;
-    w4_tile_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Wt, Sp, (u32x4*)((char*)packed + L.off_wm),
-                                                                      (T*)((char*)packed + L.off_sm), (int)Npad, (int)G,
-                                                                      (int)L.ksteps, total);
+    w4_tile_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const u32x4*)gemv, (const T*)((const char*)gemv + L.off_sp),
+                                                                      (u32x4*)tiled, (T*)((char*)tiled + (L.off_sm - L.off_wm)),
+                                                                      (int)L.Npad, (int)L.G, (int)L.ksteps, total);
     return finish_launch();
 }
 
@@ -854,13 +858,28 @@ int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, cons
     return QL_ERR_UNSUPPORTED;
 }
 
-int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
+int w4_repack_gemv(int dtype, const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st) {
     switch (dtype) {
-    case QL_DTYPE_F32: return launch_w4_repack<float>(Wq, S, packed, N, K, st);
-    case QL_DTYPE_F16: return launch_w4_repack<f16>(Wq, S, packed, N, K, st);
-    case QL_DTYPE_BF16: return launch_w4_repack<__bf16>(Wq, S, packed, N, K, st);
+    case QL_DTYPE_F32: return launch_w4_repack_gemv<float>(Wq, S, gemv, N, K, st);
+    case QL_DTYPE_F16: return launch_w4_repack_gemv<f16>(Wq, S, gemv, N, K, st);
+    case QL_DTYPE_BF16: return launch_w4_repack_gemv<__bf16>(Wq, S, gemv, N, K, st);
     default: return QL_ERR_BAD_DTYPE;
     }
+}
+
+int w4_tile(int dtype, const void* gemv, void* tiled, int64_t N, int64_t K, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w4_tile<float>(gemv, tiled, N, K, st);
+    case QL_DTYPE_F16: return launch_w4_tile<f16>(gemv, tiled, N, K, st);
+    case QL_DTYPE_BF16: return launch_w4_tile<__bf16>(gemv, tiled, N, K, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st) {
+    const int rc = w4_repack_gemv(dtype, Wq, S, packed, N, K, st);
+    if (rc != 0) return rc;
+    return w4_tile(dtype, packed, (char*)packed + w4_layout(N, K, dtype == QL_DTYPE_F32 ? 4 : 2).off_wm, N, K, st);
 }
 
 // Which kernel serves M rows.  The VALU GEMV does 4 rows per pass at about 4x the issue cost of one row; the MFMA
@@ -903,13 +922,19 @@ size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return w4_fewrow_supported(M, N, K) ? w4_fewrow_workspace_bytes(M, N, K) : w4_packed_gemm_workspace_bytes(M, N, K);
 }
 
+// any row count on the tile-major part alone (fp16 / bf16): the MFMA kernels
+int w4_tiled(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+             int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (w4_fewrow_supported(M, N, K)) return w4_fewrow(dtype, A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+    return w4_packed_gemm(dtype, A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
+}
+
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st) {
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
-    if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16)) {
-        if (w4_fewrow_supported(M, N, K)) return w4_fewrow(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
-        return w4_packed_gemm(dtype, A, packed, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
-    }
+    if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
+        return w4_tiled(dtype, A, (const char*)packed + w4_layout(N, K, 2).off_wm, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     if (lda > 0x7fffffff) return QL_ERR_UNSUPPORTED;          // the GEMV kernels take the row stride as 32 bits
     const PackedArgs p{A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, strict, st};
     switch (dtype) {

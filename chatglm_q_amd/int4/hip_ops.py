@@ -7,6 +7,8 @@ under ``python -O``).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -75,30 +77,67 @@ def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
     return int(_lib.get_lib().qlinear_w4g32_packed_bytes(N, K, group, _lib.dtype_code(dtype)))
 
 
-def repack_w4g32(b: Tensor, b_scale: Tensor) -> Tensor:
-    """Build the derived streaming layout (include/qlinear_hip.h) from canonical buffers.
-    Returns a uint8 tensor; it is a cache, never part of a state_dict."""
+# rows served by the GEMV (part 1 of the derived layout); more rows take the MFMA kernels on part 2.  The library reads the
+# same variable (w4_rows_use_gemm, csrc/w4_packed.hip).
+GEMV_MAX_ROWS = int(os.environ.get("QLINEAR_GEMV_MAX_ROWS", "2"))
+
+
+def gemv_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
+    """Bytes of part 1 (column-major, the GEMVs) of the derived layout."""
+    return int(_lib.get_lib().qlinear_w4g32_gemv_bytes(N, K, group, _lib.dtype_code(dtype)))
+
+
+def tiled_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
+    """Bytes of part 2 (tile-major, the MFMA kernels); 0 for dtypes without an MFMA path (fp32)."""
+    return int(_lib.get_lib().qlinear_w4g32_tiled_bytes(N, K, group, _lib.dtype_code(dtype)))
+
+
+def _repack(entry: str, nbytes: int, b: Tensor, b_scale: Tensor) -> Tensor:
     lib = _lib.get_lib()
     K, N = b.shape[0] * 2, b.shape[1]
     group = K // b_scale.shape[0]
-    b = b.contiguous()
-    b_scale = b_scale.contiguous()
-    nbytes = packed_nbytes(N, K, b_scale.dtype, group)
     if nbytes == 0:
         raise ValueError(f"no packed layout for N={N}, K={K}, group={group}")
     packed = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
     with torch.cuda.device(b.device):
-        st = lib.qlinear_w4g32_repack(b.data_ptr(), b_scale.data_ptr(), packed.data_ptr(), N, K, group,
-                                      _lib.dtype_code(b_scale.dtype), _lib.stream_ptr(b.device))
-    _lib.check(st, "qlinear_w4g32_repack")
+        st = getattr(lib, entry)(b.contiguous().data_ptr(), b_scale.contiguous().data_ptr(), packed.data_ptr(), N, K, group,
+                                 _lib.dtype_code(b_scale.dtype), _lib.stream_ptr(b.device))
+    _lib.check(st, entry)
     return packed
 
 
+def repack_w4g32(b: Tensor, b_scale: Tensor) -> Tensor:
+    """Build the derived streaming layout (include/qlinear_hip.h), both parts in one buffer, from canonical buffers.
+    Returns a uint8 tensor; it is a cache, never part of a state_dict."""
+    K, N = b.shape[0] * 2, b.shape[1]
+    return _repack("qlinear_w4g32_repack", packed_nbytes(N, K, b_scale.dtype, K // b_scale.shape[0]), b, b_scale)
+
+
+def repack_w4g32_gemv(b: Tensor, b_scale: Tensor) -> Tensor:
+    """Part 1 alone (rows <= GEMV_MAX_ROWS and every fused one-row launch): what the modules build first."""
+    K, N = b.shape[0] * 2, b.shape[1]
+    return _repack("qlinear_w4g32_repack_gemv", gemv_nbytes(N, K, b_scale.dtype, K // b_scale.shape[0]), b, b_scale)
+
+
+def tile_w4g32(gemv: Tensor, N: int, K: int, dtype: torch.dtype) -> Tensor:
+    """Part 2 (tile-major, fp16 / bf16) built from part 1: what the modules build on their first forward with more rows."""
+    lib = _lib.get_lib()
+    nbytes = tiled_nbytes(N, K, dtype)
+    if nbytes == 0 or gemv.numel() < gemv_nbytes(N, K, dtype):
+        raise ValueError(f"no tile-major layout for N={N}, K={K}, {dtype}, or part 1 too small")
+    tiled = torch.empty(nbytes, dtype=torch.uint8, device=gemv.device)
+    with torch.cuda.device(gemv.device):
+        st = lib.qlinear_w4g32_tile(gemv.data_ptr(), tiled.data_ptr(), N, K, 32, _lib.dtype_code(dtype), _lib.stream_ptr(gemv.device))
+    _lib.check(st, "qlinear_w4g32_tile")
+    return tiled
+
+
 def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
-               packed: Tensor | None = None, strict: bool | None = None) -> Tensor:
-    """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernel;
-    ``strict`` (default: env QLINEAR_STRICT) asks for the reference's per-weight rounding bit for bit
-    (the canonical-layout kernel always rounds that way)."""
+               packed: Tensor | None = None, strict: bool | None = None, tiled: Tensor | None = None) -> Tensor:
+    """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernels: a buffer of
+    ``repack_w4g32`` (both parts, any row count) or of ``repack_w4g32_gemv`` (part 1: rows <= GEMV_MAX_ROWS, fp32 any);
+    ``tiled`` (part 2, ``tile_w4g32``) serves fp16 / bf16 at any row count.  ``strict`` (default: env QLINEAR_STRICT) asks
+    for the reference's per-weight rounding bit for bit (the canonical-layout and MFMA kernels always round that way)."""
     _check_w4_args(a, b, b_scale)
     _check_row_operands("w4_forward", a, a.shape[-1], bias=bias)
     lib = _lib.get_lib()
@@ -116,7 +155,21 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
         bias = bias.contiguous()
     with torch.cuda.device(a.device):
         stream = _lib.stream_ptr(a.device)
-        if packed is not None:
+        mfma_rows = M > GEMV_MAX_ROWS and a.dtype in (torch.float16, torch.bfloat16)
+        if tiled is not None and (mfma_rows or packed is None):
+            if a.dtype not in (torch.float16, torch.bfloat16) or group != 32 or tiled.device != a.device or \
+                    tiled.numel() < tiled_nbytes(N, K, a.dtype):
+                raise AssertionError("w4_forward: the tile-major buffer serves fp16 / bf16, group 32, and must belong to (K, N)")
+            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, max(M, GEMV_MAX_ROWS + 1), N, K, group))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
+            st = lib.qlinear_w4g32_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K, group,
+                                             a2.stride(0) if M > 1 else K, N, code, _lib.ptr(ws), ws_bytes, stream)
+            _lib.check(st, "qlinear_w4g32_fwd_tiled")
+        elif packed is not None:
+            need = packed_nbytes(N, K, a.dtype, group) if mfma_rows else gemv_nbytes(N, K, a.dtype, group)
+            if packed.device != a.device or packed.numel() < need:
+                raise AssertionError(f"w4_forward: derived buffer of {packed.numel()} bytes cannot serve {M} rows of a ({K}, {N}) "
+                                     f"weight ({need} needed: part 1 alone serves up to {GEMV_MAX_ROWS} rows)")
             # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
             ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group)) if M > 1 else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
@@ -262,7 +315,7 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     if a.numel() != a.shape[-1]:
         raise ValueError("fused prologues serve exactly one activation row")
     _check_row_operands("w4_forward_fused", a, a.shape[-1], bias=bias, delta=delta, ln_weight=ln_weight, hout=hout)
-    if packed.device != a.device or packed.numel() < packed_nbytes(n_out, K, a.dtype):
+    if packed.device != a.device or packed.numel() < gemv_nbytes(n_out, K, a.dtype):
         raise AssertionError("w4_forward_fused: packed buffer on another device or too small for (n_out, K)")
     a = a.contiguous()
     c = torch.empty((*a.shape[:-1], n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out), device=a.device, dtype=a.dtype)
@@ -274,26 +327,27 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     return c
 
 
-def w4_forward_gated(a: Tensor, gated_packed: Tensor, n_out: int, bias: Tensor | None) -> Tensor | None:
+def w4_forward_gated(a: Tensor, gated_tiled: Tensor, n_out: int, bias: Tensor | None) -> Tensor | None:
     """Few rows (3..32) through a gate-interleaved first MLP projection with SiLU * gate in the kernel's epilogue
-    (``qlinear_w4g32_fwd_packed_gated``): (..., K) -> (..., n_out / 2).  None when the library does not serve the
-    shape that way (the caller then runs the projection and ``silu_mul`` separately)."""
+    (``qlinear_w4g32_fwd_tiled_gated``): (..., K) -> (..., n_out / 2).  ``gated_tiled``: part 2 of the gate-interleaved
+    copy (``DynamicQuantizeLinear.gated_tiled``).  None when the library does not serve the shape that way (the caller
+    then runs the projection and ``silu_mul`` separately)."""
     lib = _lib.get_lib()
     K = a.shape[-1]
     _check_row_operands("w4_forward_gated", a, K, bias=bias)
-    if gated_packed.device != a.device or gated_packed.numel() < packed_nbytes(n_out, K, a.dtype):
-        raise AssertionError("w4_forward_gated: packed buffer on another device or too small for (n_out, K)")
+    if gated_tiled.device != a.device or gated_tiled.numel() < tiled_nbytes(n_out, K, a.dtype):
+        raise AssertionError("w4_forward_gated: tile-major buffer on another device or too small for (n_out, K)")
     a2 = a.reshape(-1, K)
     if a2.stride(1) != 1 or a2.stride(0) % 8:
         a2 = a2.contiguous()
     c = torch.empty((a2.shape[0], n_out // 2), device=a.device, dtype=a.dtype)
     with torch.cuda.device(a.device):
-        st = lib.qlinear_w4g32_fwd_packed_gated(a2.data_ptr(), gated_packed.data_ptr(), _lib.ptr(bias), c.data_ptr(),
-                                                a2.shape[0], n_out, K, a2.stride(0), n_out // 2,
-                                                _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+        st = lib.qlinear_w4g32_fwd_tiled_gated(a2.data_ptr(), gated_tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                               a2.shape[0], n_out, K, a2.stride(0), n_out // 2,
+                                               _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
     if st == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(st, "qlinear_w4g32_fwd_packed_gated")
+    _lib.check(st, "qlinear_w4g32_fwd_tiled_gated")
     return c.reshape(*a.shape[:-1], n_out // 2)
 
 
@@ -304,7 +358,7 @@ def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | No
     if a.numel() != a.shape[-1] or residual.numel() != n_out:
         raise ValueError("the residual epilogue serves exactly one row")
     _check_row_operands("w4_forward_residual", a, a.shape[-1], bias=bias, residual=residual)
-    if packed.device != a.device or packed.numel() < packed_nbytes(n_out, a.shape[-1], a.dtype):
+    if packed.device != a.device or packed.numel() < gemv_nbytes(n_out, a.shape[-1], a.dtype):
         raise AssertionError("w4_forward_residual: packed buffer on another device or too small for (n_out, K)")
     a = a.contiguous()
     residual = residual.contiguous()

@@ -108,9 +108,13 @@ class DynamicQuantizeLinear(nn.Module):
             self.register_buffer("bias", None)
         # derived streaming layout: a cache keyed on the canonical buffers' identity + version,
         # never registered, never saved (SURVEY.md 8b "Buffer ownership")
+        # part 1 (column-major, the GEMVs) is built on the first GPU forward; part 2 (tile-major, the MFMA kernels) on the
+        # first forward with more than hip_ops.GEMV_MAX_ROWS rows - a decode-only session never allocates it
         self._packed: Tensor | None = None
         self._packed_key = None
+        self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._gated_tiled, self._gated_tiled_key = None, None
         self._a8, self._a8_key = None, None
         # opt-in int8-activation path (W4A8, i8 MFMA): False | True (row-wise scales) | "per_tensor".  NOT bit-compatible
         # with the weight-only path (activation quantisation error ~1e-2 relative): include/qlinear_hip.h
@@ -124,7 +128,9 @@ class DynamicQuantizeLinear(nn.Module):
         """Drop every derived layout; the next GPU forward rebuilds them from the canonical buffers.  Needed only
         after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
         self._packed, self._packed_key = None, None
+        self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._gated_tiled, self._gated_tiled_key = None, None
         self._a8, self._a8_key = None, None
         return self
 
@@ -141,16 +147,31 @@ class DynamicQuantizeLinear(nn.Module):
                 and self.weight.is_contiguous() and self.weight_scale.is_contiguous())
 
     @torch.no_grad()
-    def prepare(self):
-        """Build (or refresh) the derived layout now, e.g. before capturing a HIP graph."""
+    def prepare(self, rows: int = 1):
+        """Build (or refresh) the derived layout now, e.g. before capturing a HIP graph: part 1, and part 2 as well when
+        ``rows`` (the row count the module is about to serve) needs the MFMA kernels."""
         if not self._packed_supported():
             self._packed, self._packed_key = None, None
+            self._tiled, self._tiled_key = None, None
             return self
         key = self._canonical_key()
         if self._packed is None or self._packed_key != key:
-            self._packed = hip_ops.repack_w4g32(self.weight, self.weight_scale)
+            self._packed = hip_ops.repack_w4g32_gemv(self.weight, self.weight_scale)
             self._packed_key = key
+        if rows > hip_ops.GEMV_MAX_ROWS and self.weight_scale.dtype in (torch.float16, torch.bfloat16):
+            self.tiled()
         return self
+
+    @torch.no_grad()
+    def tiled(self) -> Tensor:
+        """Part 2 of the derived layout (tile-major, the few-row and MFMA GEMM kernels; fp16 / bf16), built from part 1
+        on first use and cached like it."""
+        key = self._canonical_key()
+        if self._tiled is None or self._tiled_key != key:
+            self.prepare()
+            self._tiled = hip_ops.tile_w4g32(self._packed, self.out_features, self.in_features, self.weight_scale.dtype)
+            self._tiled_key = key
+        return self._tiled
 
     @torch.no_grad()
     def gated_packed(self, hidden: int):
@@ -163,10 +184,22 @@ class DynamicQuantizeLinear(nn.Module):
         key = (self._canonical_key(), _lib.buffer_key(self.bias))
         if getattr(self, "_gated", None) is None or self._gated_key != key:
             perm = hip_ops.gate_interleave(hidden, self.weight.device)
-            packed = hip_ops.repack_w4g32(self.weight.index_select(1, perm), self.weight_scale.index_select(1, perm))
+            packed = hip_ops.repack_w4g32_gemv(self.weight.index_select(1, perm), self.weight_scale.index_select(1, perm))
             bias = self.bias.index_select(0, perm) if self.bias is not None else None
             self._gated, self._gated_key = (packed, bias), key
+            self._gated_tiled, self._gated_tiled_key = None, None
         return self._gated
+
+    @torch.no_grad()
+    def gated_tiled(self, hidden: int):
+        """Part 2 of the gate-interleaved copy (batched decode, 3..32 rows: qlinear_w4g32_fwd_tiled_gated), built on first
+        use.  Returns (tiled, bias_or_None)."""
+        packed, bias = self.gated_packed(hidden)
+        key = self._gated_key
+        if self._gated_tiled is None or self._gated_tiled_key != key:
+            self._gated_tiled = hip_ops.tile_w4g32(packed, self.out_features, self.in_features, self.weight_scale.dtype)
+            self._gated_tiled_key = key
+        return self._gated_tiled, bias
 
     def forward(self, input: Tensor):
         if check_input(input):
@@ -182,13 +215,16 @@ class DynamicQuantizeLinear(nn.Module):
                 return hip_ops.w4a8_forward(input, self._a8, self.out_features, self.bias,
                                             per_tensor=self.act_quant == "per_tensor")
             rows = input.numel() // max(input.shape[-1], 1)
-            packed = None
-            if (rows <= PACKED_MAX_ROWS or input.dtype in (torch.float16, torch.bfloat16)) and self._packed_supported():
-                self.prepare()
-                packed = self._packed
+            packed = tiled = None
+            half = input.dtype in (torch.float16, torch.bfloat16)
+            if (rows <= PACKED_MAX_ROWS or half) and self._packed_supported() and input.dtype == self.weight_scale.dtype:
+                if half and rows > hip_ops.GEMV_MAX_ROWS:
+                    tiled = self.tiled()
+                else:
+                    packed = self.prepare()._packed
             # bias is added inside the kernel epilogue AFTER the rounding to the output dtype,
             # i.e. the same two roundings as "out = matmul(); out += bias" (qlinear.py:90-94)
-            return hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed)
+            return hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed, tiled=tiled)
         out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
         if self.bias is not None:
             out += self.bias

@@ -281,8 +281,8 @@ class ChatGLM2Model(nn.Module):
         if not (isinstance(w_in, Q4) and x.dtype in (torch.float16, torch.bfloat16) and w_in._packed_supported()
                 and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0):
             return None
-        packed, bias = w_in.gated_packed(ffn.hidden_dim)
-        return H4.w4_forward_gated(x, packed, w_in.out_features, bias)
+        tiled, bias = w_in.gated_tiled(ffn.hidden_dim)
+        return H4.w4_forward_gated(x, tiled, w_in.out_features, bias)
 
     def _one_row_kind(self, dtype) -> Optional[str]:
         """"int4" / "int8" when every QLinear of the graph can take the fused one-row launches, else None."""

@@ -132,6 +132,22 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
                              int64_t ldc, int dtype, int flags, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* The two parts as two allocations, so that a weight which never sees three or more rows (decode-only sessions, fp32)
+ * never pays for part 2: part 1 ("gemv", qlinear_w4g32_gemv_bytes) is what qlinear_w4g32_fwd_packed reads for M <= 2
+ * and every one-row fused / residual entry point reads; part 2 ("tiled", qlinear_w4g32_tiled_bytes; 0 for fp32, which
+ * has no MFMA path) is built FROM part 1 by qlinear_w4g32_tile and serves any row count through
+ * qlinear_w4g32_fwd_tiled (the few-row and MFMA GEMM kernels; workspace: qlinear_workspace_bytes(QL_OP_W4G32_FWD_PACKED)).
+ * gemv_bytes + tiled_bytes == packed_bytes, and a buffer of qlinear_w4g32_repack is exactly gemv followed by tiled.
+ * The host module (chatglm_q_amd/int4/qlinear.py) builds part 2 on the first forward with >= 3 rows. */
+size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype);
+size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype);
+int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, int64_t group, int dtype,
+                              void* stream);
+int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int64_t group, int dtype, void* stream);
+int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                            int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* One-row (decode) forward on the derived layout with an activation PROLOGUE fused into the staging of the
  * activation row, so that the small op in front of the QLinear call costs no launch of its own (SURVEY.md 8f
  * N1).  fp16 / bf16, group 32, exact-dequant arithmetic.  Rounding sequence as the model graph's:
@@ -180,6 +196,9 @@ int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const 
  * matrices, other row counts): run qlinear_w4g32_fwd_packed + qlinear_silu_mul instead.  fp16 / bf16. */
 int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                    int64_t lda, int64_t ldc, int dtype, void* stream);
+/* the same on part 2 alone (qlinear_w4g32_tile of the gate-interleaved part 1) */
+int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldc, int dtype, void* stream);
 
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245

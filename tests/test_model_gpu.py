@@ -272,7 +272,9 @@ def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     if bias:
         layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
     x = torch.randn(M, 1, K, device=DEV, generator=g).to(dtype)
-    gp, gb = layer.gated_packed(hidden)
+    assert layer._gated_tiled is None                        # part 2 of the gated copy: built on first use only
+    gp, gb = layer.gated_tiled(hidden)
+    assert layer.gated_tiled(hidden)[0] is gp
     got = H4.w4_forward_gated(x, gp, 2 * hidden, gb)
     with torch.no_grad():
         want = F_.silu_mul(layer(x), hidden)
@@ -282,7 +284,7 @@ def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     small = DynamicQuantizeLinear(4096, 512, bias=False, dtype=dtype, device=DEV)
     small.weight.copy_(torch.randint(0, 256, small.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
     small.weight_scale.fill_(0.01)
-    sp, _ = small.gated_packed(256)
+    sp, _ = small.gated_tiled(256)
     assert H4.w4_forward_gated(x, sp, 512, None) is None
 
 

@@ -684,3 +684,46 @@ def test_w8_backward_golden_and_autograd():
     y.backward(go)
     ref = O.w8_matmul_grad_input(t2n(go), layer.weight.cpu().numpy().T, t2n(layer.weight_scale), dtype="f16")
     assert O.rel_l2(t2n(x.grad), ref) < REL["f16"]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_int4_derived_parts_are_built_lazily_and_equal_the_single_buffer(dt):
+    """Part 1 (GEMV layout) is built on the first GPU forward, part 2 (tile-major, MFMA kernels) on the first forward with
+    >= 3 rows (qlinear_w4g32_repack_gemv / qlinear_w4g32_tile / qlinear_w4g32_fwd_tiled); both are byte-identical to
+    the halves of the one-buffer layout (qlinear_w4g32_repack) and give bit-identical outputs."""
+    K, N = 512, 320
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    qw, sc = _rand_w4(K, N, dt, 321)
+    layer = q4.DynamicQuantizeLinear(K, N, bias=False, dtype=tdt)
+    layer.apply_weights_(qw, sc)
+    layer = layer.to(DEV)
+    full = h4.repack_w4g32(layer.weight, layer.weight_scale)
+    nb1, nb2 = h4.gemv_nbytes(N, K, tdt), h4.tiled_nbytes(N, K, tdt)
+    assert nb1 + nb2 == full.numel() == h4.packed_nbytes(N, K, tdt)
+    x1 = torch.randn(1, K).to(tdt).to(DEV)
+    x9 = torch.randn(9, K).to(tdt).to(DEV)
+    with torch.no_grad():
+        y1 = layer(x1)
+    assert layer._packed is not None and layer._packed.numel() == nb1 and layer._tiled is None
+    assert torch.equal(layer._packed, full[:nb1])
+    with torch.no_grad():
+        y9 = layer(x9)
+    assert layer._tiled is not None and layer._tiled.numel() == nb2
+    assert torch.equal(layer._tiled, full[nb1:])
+    assert torch.equal(y1, h4.w4_forward(x1, layer.weight, layer.weight_scale, None, full))
+    assert torch.equal(y9, h4.w4_forward(x9, layer.weight, layer.weight_scale, None, full))
+    assert_close(y9, O.w4_matmul(t2n(x9), qw.numpy(), t2n(sc), None, dtype=dt), dt)
+    # part 1 alone cannot serve the MFMA row counts, and says so
+    with pytest.raises(AssertionError):
+        h4.w4_forward(x9, layer.weight, layer.weight_scale, None, layer._packed)
+    # the tile-major part serves any row count
+    assert_close(h4.w4_forward(x1, layer.weight, layer.weight_scale, None, None, tiled=layer._tiled),
+                 O.w4_matmul(t2n(x1), qw.numpy(), t2n(sc), None, dtype=dt), dt)
+    # refreshed together with part 1 when the canonical buffers change
+    t_old = layer._tiled
+    layer.weight.add_(1)
+    with torch.no_grad():
+        layer(x9)
+    assert layer._tiled is not t_old
+    # fp32 has no MFMA path: no part 2 at all
+    assert h4.tiled_nbytes(N, K, torch.float32) == 0
