@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
     }
 }
 
+__device__ __forceinline__ int64_t clamp_pos(int64_t p, int capacity) { return p < 0 ? 0 : (p <= capacity ? p : capacity); }
+
 // ---------------------------------------------------------------------------------------------
 // fused_qkv (rows, (H + 2G) D): rotate q and k pairs (re, im) by (cos, sin) of the row's position, write
 // q (rows, H D); k, v into the caches at row `write_index[s]`.
@@ -141,8 +143,13 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict_
                                                             int S, int H, int G, int D, int capacity, int64_t ldqkv) {
     const int row = blockIdx.x, b = row / S, s = row - b * S;
     const T* in = QKV + (int64_t)row * ldqkv;
-    const T* cs = table + pos[row] * D;                      // D/2 pairs x 2 = D values
+    // Bounds (the ABI carries no table length): positions are 1-based counts of the unmasked tokens up to and including
+    // the row (chatglm_q/model.py:307-308), so a valid position is at most its cache row + 1: positions are clamped to
+    // [0, capacity] - the table holds capacity + 1 rows (checked by the host wrappers) - and a row index outside the
+    // cache writes nothing.
+    const T* cs = table + clamp_pos(pos[row], capacity) * D;     // D/2 pairs x 2 = D values
     const int64_t wrow = widx[s];
+    const bool in_cache = wrow >= 0 && wrow < capacity;
     const int per_head = D / 8;                              // 8-value units per head
     const int n_units = (H + 2 * G) * per_head;
     for (int i = threadIdx.x; i < n_units; i += 256) {
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const T* __restrict_
             dst = Kc + (((int64_t)b * capacity + wrow) * G + (head - H)) * D;
         else
             dst = Vc + (((int64_t)b * capacity + wrow) * G + (head - H - G)) * D;
+        if (head >= H && !in_cache) continue;
         if (head < H + G) {
             float c[8], y[8];
             load8<T>(cs + u * 8, c);                         // (cos, sin) x 4 pairs
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
         // blocks must not read that cache row while block (h % (H/G) == 0) writes it
         wrow = (int)widx[0] - t_lo;                          // window-local; outside [0, capacity) for other windows
         const T* row = Q + (int64_t)b * ldq;
-        const T* cs = table + pos[b] * D;
+        const T* cs = table + clamp_pos(pos[b], cap_full) * D;
         const int d = threadIdx.x;
         if (d < D) {
             const int p = d < D / 2 ? d : d - D / 2;
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
         }
     const int wrow = (int)widx[0] - t_lo;                     // window-local row written by this step
     const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
-    const T* cs = table + pos[b] * D;
+    const T* cs = table + clamp_pos(pos[b], cap_full) * D;
 #pragma unroll
     for (int k = 0; k < QPT; ++k) cq[k] = *reinterpret_cast<const u32*>(cs + 2 * ((tid + NTH * k) & 63));
     // xk / xv are used under `tid < 64` / `tid < 80` only: left alone, the compiler sinks their loads into those

@@ -55,6 +55,9 @@ class DecodeSession:
         self.model = model
         p = model.final_ln.weight
         self.device, self.dtype = p.device, p.dtype
+        if capacity > model.config.max_sequence_length:
+            raise ValueError(f"cache capacity {capacity} exceeds max_sequence_length {model.config.max_sequence_length} "
+                             "(no rotary table rows for those positions)")
         self.batch, self.capacity = batch, capacity
         self.cache: KVCache = model.new_cache(batch, capacity)
         self.use_graph = (self.device.type == "cuda") if use_graph is None else use_graph
@@ -211,7 +214,7 @@ class ChatGLMDecoder:
         budget = min(max_generated_tokens, self.max_sequence_length - len(prefix))
         if budget <= 0:
             return
-        capacity = -(-(len(prefix) + budget) // 64) * 64
+        capacity = min(-(-(len(prefix) + budget) // 64) * 64, self.model.config.max_sequence_length)
         sess = self._session_for(capacity, use_graph)
         times = []
         sync = (lambda: torch.cuda.synchronize(sess.device)) if sess.device.type == "cuda" else (lambda: None)

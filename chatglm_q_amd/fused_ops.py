@@ -41,11 +41,20 @@ def add_rmsnorm(x: Tensor, delta: Tensor, weight: Tensor, eps: float):
     return h.reshape(shape), out.reshape(shape)
 
 
+def _check_rope_table(table: Tensor, k_cache: Tensor, d_head: int):
+    """The kernels clamp positions to [0, capacity] (1-based positions: row r holds position <= r + 1) and skip cache
+    rows outside the cache - the ABI carries no table length - so the rotary table must hold capacity + 1 positions."""
+    if table.numel() < (k_cache.shape[1] + 1) * d_head:
+        raise ValueError(f"rotary table of {table.numel() // d_head} positions does not cover a cache of {k_cache.shape[1]} rows "
+                         f"(positions 0..{k_cache.shape[1]})")
+
+
 def rope_kv_write(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
                   n_head: int, n_groups: int, d_head: int) -> Tensor:
     """qkv (B, S, (H+2G) D) -> rotated q (B, S, H*D); rotated k and v are written into the caches in place."""
     lib = _lib.get_lib()
     B, S, W = qkv.shape
+    _check_rope_table(table, k_cache, d_head)
     qkv = qkv.contiguous()
     q = torch.empty((B, S, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
     with torch.cuda.device(qkv.device):
@@ -88,6 +97,7 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     B, S, W = qkv.shape
     if S != 1:
         raise ValueError("decode_attention_rope serves one position per sequence")
+    _check_rope_table(table, k_cache, d_head)
     qkv = qkv.contiguous()
     out = torch.empty((B, 1, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
     capacity = k_cache.shape[1]

@@ -194,8 +194,11 @@ class ChatGLM2Model(nn.Module):
         self.final_ln = RMSNorm(config.hidden_size, config.layernorm_epsilon, dtype)
         self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False, dtype=dtype)
         # the reference keeps the table in the model dtype (chatglm_q/model.py:268-270)
-        table = rotary_table(config.head_hidden_size, config.max_sequence_length).to(dtype=dtype)
-        self.register_buffer("freqs_cis_cache", table.view(config.max_sequence_length, -1), persistent=False)
+        # One row more than the reference's table: positions are 1-based (cumsum of the mask), so a cache of
+        # max_sequence_length rows reaches position max_sequence_length - where the reference's F.embedding raises; the
+        # HIP kernels clamp positions to [0, capacity] instead (no table length crosses the ABI) and must find that row.
+        table = rotary_table(config.head_hidden_size, config.max_sequence_length + 1).to(dtype=dtype)
+        self.register_buffer("freqs_cis_cache", table.view(config.max_sequence_length + 1, -1), persistent=False)
 
     # -- cache helpers ---------------------------------------------------------------------------
     def new_cache(self, batch: int, capacity: int, device=None, dtype=None) -> KVCache:

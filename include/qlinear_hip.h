@@ -297,7 +297,10 @@ int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, vo
  *                                                                                              model.py:157-175
  * decode_attention_rope: rope_kv_write (S = 1) and decode_attention in ONE launch: qkv (B, (H+2G)*D) in, the
  *                    cache row widx[0] written by one block per (b, group), out (B, H*D)
- * silu_mul:          in (rows, 2*hidden) -> out[r,i] = round(round(silu(in[r,i])) * in[r,hidden+i])   model.py:200-201 */
+ * silu_mul:          in (rows, 2*hidden) -> out[r,i] = round(round(silu(in[r,i])) * in[r,hidden+i])   model.py:200-201
+ * Bounds of the rotary entry points (no table length crosses the ABI): `table` must hold capacity + 1 positions; pos
+ * values are clamped to [0, capacity] - positions are 1-based counts (model.py:307-308), a valid one is at most its
+ * cache row + 1 - and a widx outside [0, capacity) writes no cache row. */
 int qlinear_rmsnorm(const void* X, const void* W, void* Out, int64_t rows, int64_t dim, int64_t ldx, int64_t ldo,
                     float eps, int dtype, void* stream);
 int qlinear_add_rmsnorm(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows,

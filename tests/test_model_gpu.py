@@ -214,6 +214,36 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
     assert O.rel_l2(t2n(got_split), t2n(want)) < {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
 
 
+@pytest.mark.parametrize("geom", [(2, 32, 2, 128, 64), (1, 4, 1, 32, 40)])
+def test_rotary_entry_points_stay_inside_table_and_cache(geom):
+    """No table length crosses the ABI: positions past the cache are clamped to `capacity` (the last row the table must
+    hold), a write index outside the cache writes nothing, and a table that does not cover the cache is refused."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd import model as M
+    B, H, Gq, D, cap = geom
+    g = torch.Generator(device=DEV).manual_seed(9)
+    qkv = torch.randn(B, 1, (H + 2 * Gq) * D, device=DEV, generator=g).half()
+    table = M.rotary_table(D, cap + 1).to(DEV).half().reshape(cap + 1, -1).contiguous()
+    k0 = torch.randn(B, cap, Gq, D, device=DEV, generator=g).half()
+    v0 = torch.randn(B, cap, Gq, D, device=DEV, generator=g).half()
+    mask = torch.zeros(B, 1, cap, device=DEV)
+    far = torch.full((B, 1), 10 ** 9, dtype=torch.long, device=DEV)
+    last = torch.full((B, 1), cap, dtype=torch.long, device=DEV)
+    for widx in (cap, cap + 1000, -3):
+        w = torch.tensor([widx], dtype=torch.long, device=DEV)
+        k, v = k0.clone(), v0.clone()
+        q_far = F_.rope_kv_write(qkv, table, far, w, k, v, H, Gq, D)
+        assert torch.equal(k, k0) and torch.equal(v, v0)                  # nothing written outside the cache
+        k2, v2 = k0.clone(), v0.clone()
+        q_last = F_.rope_kv_write(qkv, table, last, torch.tensor([cap - 1], dtype=torch.long, device=DEV), k2, v2, H, Gq, D)
+        assert torch.equal(q_far, q_last)                                # position clamped to `capacity`
+        k3, v3 = k0.clone(), v0.clone()
+        out = F_.decode_attention_rope(qkv, table, far, w, k3, v3, mask, H, Gq, D)
+        assert torch.equal(k3, k0) and torch.equal(v3, v0) and bool(torch.isfinite(out).all())
+    with pytest.raises(ValueError):
+        F_.rope_kv_write(qkv, table[:cap], last, torch.tensor([0], dtype=torch.long, device=DEV), k0.clone(), v0.clone(), H, Gq, D)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("geom", [(1, 32, 2, 128, 256, 130), (2, 32, 2, 128, 192, 70), (1, 16, 1, 128, 40, 39),
                                   (1, 32, 2, 128, 2048, 1500), (2, 16, 1, 128, 320, 319), (1, 32, 2, 128, 8064, 7000),
