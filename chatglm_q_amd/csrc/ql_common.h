@@ -20,6 +20,8 @@ constexpr int kWave = 64;
 __device__ __forceinline__ h2 as_h2(u32 u) { return __builtin_bit_cast(h2, u); }
 __device__ __forceinline__ u32 as_u32(h2 h) { return __builtin_bit_cast(u32, h); }
 __device__ __forceinline__ float u32_as_f32(u32 u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float i32_as_f32(int i) { return __builtin_bit_cast(float, i); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32 f32_as_u32(float f) { return __builtin_bit_cast(u32, f); }
 
 // ---------------------------------------------------------------------------------------------

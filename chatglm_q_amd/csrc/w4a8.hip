@@ -7,10 +7,11 @@
 //
 //      C[m, n] = round( a_scale[m] * sum_g  s[g, n] * ( sum_{k in g} Aq[m, k] * (nib[k, n] - 8) ) )   (+ bias)
 //
-// A group is 32 deep = ONE v_mfma_i32_32x32x32_i8: every MFMA starts from a zero accumulator, its exact int32 result is
-// converted and folded into the fp32 accumulator with the group's scale (one v_cvt_f32_i32 + one v_fma_f32 per
-// accumulator element - the price of group-wise scales on an integer contraction: 32 VALU operations per MFMA, more than
-// the MFMA's own 32 cycles, so this kernel is VALU-bound by construction at about half the i8 MFMA peak).
+// A group is 32 deep = ONE v_mfma_i32_32x32x32_i8: every MFMA starts a fresh sum, whose exact int32 result is converted
+// and folded into the fp32 accumulator with the group's scale - the price of group-wise scales on an integer
+// contraction.  One v_cvt_f32_i32 + one v_fma_f32 per accumulator element would be 32 VALU instructions per MFMA; the
+// fold used here starts the MFMA from the bit pattern of 1.5 * 2^23 and needs 8 v_pk_add_f32 + 8 v_pk_fma_f32 (see
+// `fold`), still twice the MFMA's own 32 cycles: VALU-bound by construction at half the i8 MFMA peak at best.
 // The integer stage is exact; the result differs from the weight-only W4A16 path by the activation quantisation error
 // (~1e-2 relative, reported by tests/test_parity_gpu.py, not claimed as parity with the Triton reference).
 //
@@ -31,7 +32,34 @@
 #include "launch.h"
 #include "ql_common.h"
 
+// Build-time switches, each measured on 8192 x {4608, 4096, 27392} x 4096 and 8192 x 4096 x 13696 (tools/ab, W4A8 GEMM alone,
+// TOP/s; the f16-MFMA path on the same shapes: 924 / 974 / 995 / 1044):
+//   QL_W4A8_PKFOLD  packed fold on a magic-biased accumulator (below)          0: 777 / 784 / 824 / 927   1: 803 / 827 / 825 / 991
+//   QL_W4A8_DEPTH4  weight register stages of the 128-row variants (with 1)    2: as above   1: 891 / 916 / 912 / 1016   3: 861 / 883 / 860 / 961
+//   QL_W4A8_DA4     A-chunk register stages of the 128-row variants            1 (2 spills: 16 registers per stage)
+//   QL_W4A8_ROLL    one fragment buffer refilled in place instead of two       neutral (807 / 840 / 834 / 973 with PKFOLD, depth 2)
+// and, at run time, QLINEAR_W4A8_COLG=1: 8-wave blocks of 256 columns sharing one A tile (column groups instead of K-parity
+// groups): 807 / 902 / 898 / 1000 - half the A bytes per flop buy nothing, this kernel is not bound by operand delivery.
+// PMC (rocprofv3, tools/prof_pmc.sh, 8192 x 4096 x 4096, PKFOLD 1 / DEPTH4 1): 24 VALU instructions per MFMA (16 of them the
+// fold), VALU busy 64 % and the matrix pipe 21 % of the cycles at 1.94 GHz; the f16-MFMA kernel on the same shape: 6 VALU per
+// (half-K) MFMA, matrix pipe busy 56 % at a clock throttled to 1.63 GHz.
+#ifndef QL_W4A8_PKFOLD
+#define QL_W4A8_PKFOLD 1
+#endif
+#ifndef QL_W4A8_ROLL
+#define QL_W4A8_ROLL 0
+#endif
+#ifndef QL_W4A8_DEPTH4
+#define QL_W4A8_DEPTH4 1          // register-stage depth (weights) of the 128-row variants
+#endif
+#ifndef QL_W4A8_DA4
+#define QL_W4A8_DA4 1             // register-stage depth of the A chunks of the 128-row variants (16 registers each)
+#endif
+
 namespace ql {
+
+constexpr int gcd2(int a, int b) { return b == 0 ? a : gcd2(b, a % b); }
+constexpr int lcm3(int a, int b, int c) { return (a * b / gcd2(a, b)) * c / gcd2(a * b / gcd2(a, b), c); }
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -108,8 +136,11 @@ int w4a8_pack(int dtype, const uint8_t* Wq, const void* S, void* out, int64_t N,
 // =============================================================================================
 // GEMM.  One loop iteration of a K-parity group covers 128 bytes of K = 4 groups = 2 tile-major units.
 // =============================================================================================
-// NG: K-parity groups per block, as in w8a8_tiled_kernel (2: one 8-wave block per CU; 1: two independent 4-wave blocks).
-template <typename T, int MT, int DEPTH, int NG>
+// NG: 4-wave groups per block (2: one 8-wave block per CU; 1: two independent 4-wave blocks).  The two groups of an 8-wave
+// block are K-parity groups as in w8a8_tiled_kernel (same 128 columns, alternate K chunks, fp32 partial sums exchanged at
+// the end) or, with COLG, COLUMN groups: the block covers 256 columns, both groups walk the same K chunks and share ONE
+// A tile in LDS - half the A bytes per flop from L2 / the fabric, no exchange.
+template <typename T, int MT, int DEPTH, int NG, bool COLG = false>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const int8_t* __restrict__ Aq, const u32x4* __restrict__ Wa,
                                                    const T* __restrict__ Sa, int M, int N, int K, int nbx, int super_rows,
                                                    const float* __restrict__ a_scale, const T* __restrict__ bias,
@@ -117,34 +148,38 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     constexpr int BM = 32 * MT;
     constexpr int BK = 128;
     constexpr int CPR = 8;                             // 16-byte chunks per tile row
+    constexpr int KP = COLG ? 1 : NG;                  // K-parity groups
+    constexpr int BN = COLG ? 128 * NG : 128;          // columns per block
+    constexpr int STG = COLG ? NG * 256 : 256;         // threads staging one A tile
     constexpr int NCH = BM * CPR;
-    constexpr int ACH = (NCH + 255) / 256;
-    constexpr bool kAllStage = NCH % 256 == 0;
+    constexpr int ACH = (NCH + STG - 1) / STG;
+    constexpr bool kAllStage = NCH % STG == 0;
     constexpr int BUF = BM * BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
 
-    const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+    const int tid = threadIdx.x, lane = tid & 63, tg = COLG ? tid : tid & 255;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;
     const int j = lane & 31, kb = lane >> 5;
     const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
-    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
     const int G = K >> 5;
     const int ksteps = (G + 1) >> 1;                   // 64-deep units per column tile
     const int nchunks = (K + BK - 1) / BK;
-    const int niter = NG == 1 ? nchunks : (nchunks + 1) >> 1;
+    const int niter = KP == 1 ? nchunks : (nchunks + 1) >> 1;
+    const int kgrp = COLG ? 0 : grp;                   // K-parity index of this group
     const int ctiles = (N + 31) >> 5;
-    const int ct_raw = tile.x * 4 + wv;
+    const int ct_raw = tile.x * (BN / 32) + (COLG ? grp * 4 : 0) + wv;
     const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
     const u32x4* wbase = Wa + (int64_t)ct * ksteps * 64 + lane;
     const T* sbase = Sa + ((int64_t)ct * ksteps * 32 + j) * 2;
-    char* lds_a = smem + grp * (3 * BUF);
+    char* lds_a = smem + kgrp * (3 * BUF);
 
     const int8_t* a_src[ACH];
     int a_dst[ACH];
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
-        const int q = tg + u * 256, r = (q >> 3) % BM, c = q & 7;
+        const int q = tg + u * STG, r = (q >> 3) % BM, c = q & 7;
         a_src[u] = Aq + (int64_t)((m0 + r < M) ? (m0 + r) : (M - 1)) * K + c * 16;
         a_dst[u] = (r * 8 + (c ^ ((r >> 1) & 7))) * 16;
     }
@@ -161,13 +196,18 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
+    // register stages: weights DEPTH iterations ahead, A chunks DA + 2 iterations ahead (two of them sit in LDS)
+    constexpr int DA = MT == 4 ? QL_W4A8_DA4 : DEPTH;
+    struct StageA {
+        i32x4 a[ACH];                                  // A chunk of (slot's iteration + DA + 2)
+    };
     struct Stage {
-        i32x4 a[ACH];                                  // A chunk of (slot's iteration + 2)
         u32x4 w[2];                                    // two units = four groups of this lane's column
         u32 s[2];                                      // their scales (two per unit)
     };
     Stage st[DEPTH];
-    auto chunk_of = [&](int i) { return NG * (i < niter ? i : niter - 1) + grp; };
+    StageA sa[DA];
+    auto chunk_of = [&](int i) { return KP * (i < niter ? i : niter - 1) + kgrp; };
     auto load_w = [&](int i, Stage& sg) {
         int t = chunk_of(i);
         t = t < nchunks ? t : nchunks - 1;
@@ -192,7 +232,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     auto store_a = [&](int buf, const i32x4 (&src)[ACH]) {
 #pragma unroll
         for (int u = 0; u < ACH; ++u)
-            if (kAllStage || tg + u * 256 < NCH) *reinterpret_cast<i32x4*>(lds_a + buf * BUF + a_dst[u]) = src[u];
+            if (kAllStage || tg + u * STG < NCH) *reinterpret_cast<i32x4*>(lds_a + buf * BUF + a_dst[u]) = src[u];
     };
     auto read_a = [&](int buf, int q, i32x4 (&fr)[MT]) {
 #pragma unroll
@@ -215,9 +255,35 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     // group's scale (16 v_cvt_f32_i32 + 16 v_fma_f32).  Software pipeline of depth one: the fold of MFMA e - 1 is issued
     // behind MFMA e, so the VALU work runs in the shadow of the matrix pipe; the sched_barrier pins that pairing - left
     // alone, hipcc hoists all 4 MT MFMAs of a chunk ahead of the folds (256 result registers: 1 108 spills at MT = 4).
-    auto fold = [&](const i32x16& r, float sc, f32x16& dst) {
+#if QL_W4A8_PKFOLD
+    // The MFMAs start from the integer 0x4B400000 instead of 0: the bits of the fp32 value 1.5 * 2^23, whose ulp is 1, so the
+    // int32 result READ AS A FLOAT is exactly 12582912 + sum (|sum| <= 32 * 127 * 128 < 2^22).  One packed subtraction
+    // gives float(sum) exactly - v_cvt_f32_i32 has no packed form, v_pk_add_f32 / v_pk_fma_f32 handle two accumulators
+    // per instruction: 8 + 8 VALU instructions per MFMA instead of 16 + 16, same bits.
+    // The accumulators live as 8 register PAIRS per row tile (not as one 16-wide vector: insert / extract on that made
+    // hipcc rotate the whole accumulator through fresh registers at every fold); the 8 subtractions are issued ahead of
+    // the 8 fmas (a dependent v_pk_add -> v_pk_fma pair costs an s_nop).
+    f32x2 accp[MT][8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = __builtin_fmaf((float)r[i], sc, dst[i]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) accp[mt][p] = f32x2{0.f, 0.f};
+    auto fold = [&](const i32x16& r, float sc, int mt) {
+        const f32x2 s2 = {sc, sc}, m2 = {-12582912.0f, -12582912.0f};
+        f32x2 f[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) f[p] = f32x2{i32_as_f32(r[2 * p]), i32_as_f32(r[2 * p + 1])} + m2;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) accp[mt][p] = __builtin_elementwise_fma(f[p], s2, accp[mt][p]);
+    };
+    i32x16 magic;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) magic[i] = 0x4B400000;
+    auto zero16 = [&] { return magic; };
+#else
+    auto fold = [&](const i32x16& r, float sc, int mt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = __builtin_fmaf((float)r[i], sc, acc[mt][i]);
     };
     auto zero16 = [] {
         i32x16 z;
@@ -225,6 +291,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
         for (int i = 0; i < 16; ++i) z[i] = 0;
         return z;
     };
+#endif
     i32x4 fa[2][MT];
     // full chunk: groups 0..3; fragments one group ahead, across the iteration boundary (three LDS buffers)
     auto mma_chunk_full = [&](int buf, int nbuf, const Stage& sg) {
@@ -232,21 +299,30 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
         float sc_prev = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#if !QL_W4A8_ROLL
             if (q + 1 < 4) read_a(buf, q + 1, fa[(q + 1) & 1]);
             else read_a(nbuf, 0, fa[0]);
+#endif
             const u32x4& w = sg.w[q >> 1];
             const i32x4 b = unpack(w[2 * (q & 1)], w[2 * (q & 1) + 1]);
             const float sc = scale_of(sg.s[q >> 1], q & 1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+#if QL_W4A8_ROLL
+                // one fragment buffer refilled in place: (next group, row tile mt) is requested right behind the MFMA that
+                // consumed fa[0][mt] and has MT MFMAs + folds to arrive
+                const i32x16 r = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0][mt], b, zero16(), 0, 0, 0);
+                fa[0][mt] = *reinterpret_cast<const i32x4*>(lds_a + (q + 1 < 4 ? buf : nbuf) * BUF + mt * 32 * BK + a_rd[(q + 1) & 3]);
+#else
                 const i32x16 r = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[q & 1][mt], b, zero16(), 0, 0, 0);
-                if (q > 0 || mt > 0) fold(pend, mt > 0 ? sc : sc_prev, acc[(mt + MT - 1) % MT]);
+#endif
+                if (q > 0 || mt > 0) fold(pend, mt > 0 ? sc : sc_prev, (mt + MT - 1) % MT);
                 pend = r;
                 __builtin_amdgcn_sched_barrier(0);
             }
             sc_prev = sc;
         }
-        fold(pend, sc_prev, acc[MT - 1]);
+        fold(pend, sc_prev, MT - 1);
     };
     auto mma_chunk_partial = [&](int buf, int nbuf, const Stage& sg, int groups) {
 #pragma unroll
@@ -260,7 +336,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const i32x16 r = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[mt], b, zero16(), 0, 0, 0);
-                    fold(r, sc, acc[mt]);
+                    fold(r, sc, mt);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -274,55 +350,66 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
         load_w(0, st[0]);
         load_a(1, a1);
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (d > 0) load_w(d, st[d]);
-            load_a(d + 2, st[d].a);
-        }
+        for (int d = 1; d < DEPTH; ++d) load_w(d, st[d]);
+#pragma unroll
+        for (int d = 0; d < DA; ++d) load_a(d + 2, sa[d].a);
         store_a(0, a0);
         store_a(1, a1);
     }
     __syncthreads();
     read_a(0, 0, fa[0]);
 
-    constexpr int U = DEPTH % 3 == 0 ? DEPTH : 3 * DEPTH;
+    constexpr int U = lcm3(3, DEPTH, DA);
+    constexpr int AHEAD = DA + 2 > DEPTH ? DA + 2 : DEPTH;
     int it = 0;
-    for (; it + U + DEPTH + 2 <= niter; it += U) {
+    for (; it + U + AHEAD <= niter; it += U) {
 #pragma unroll
         for (int d = 0; d < U; ++d) {
-            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
-            store_a(wbuf, st[slot].a);
+            const int slot = d % DEPTH, aslot = d % DA, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+            store_a(wbuf, sa[aslot].a);
             mma_chunk_full(buf, nbuf, st[slot]);
             load_w(it + d + DEPTH, st[slot]);
-            load_a(it + d + DEPTH + 2, st[slot].a);
+            load_a(it + d + DA + 2, sa[aslot].a);
             __syncthreads();
         }
     }
 #pragma unroll
-    for (int d = 0; d < U + DEPTH + 1; ++d) {
+    for (int d = 0; d < U + AHEAD - 1; ++d) {
         const int i = it + d;
         if (i < niter) {
-            const int slot = d % DEPTH, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
-            if (i + 2 < niter) store_a(wbuf, st[slot].a);
-            const int t = NG * i + grp;
+            const int slot = d % DEPTH, aslot = d % DA, buf = d % 3, nbuf = (d + 1) % 3, wbuf = (d + 2) % 3;
+            if (i + 2 < niter) store_a(wbuf, sa[aslot].a);
+            const int t = KP * i + kgrp;
             int groups = G - 4 * t;
             groups = t >= nchunks ? 0 : groups;
             if (groups >= 4) mma_chunk_full(buf, nbuf, st[slot]);
             else mma_chunk_partial(buf, nbuf, st[slot], groups);
             if (i + DEPTH < niter) load_w(i + DEPTH, st[slot]);
-            if (i + DEPTH + 2 < niter) load_a(i + DEPTH + 2, st[slot].a);
+            if (i + DA + 2 < niter) load_a(i + DA + 2, sa[aslot].a);
             __syncthreads();
         }
     }
 
+#if QL_W4A8_PKFOLD
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            acc[mt][2 * p] = accp[mt][p][0];
+            acc[mt][2 * p + 1] = accp[mt][p][1];
+        }
+#endif
     // epilogue operands requested before the exchange (their round trip overlaps it)
-    const int n = n0 + wv * 32 + j;
-    constexpr int OWN = NG == 1 ? MT : (MT == 1 ? 1 : MT / 2);
-    auto owner_of = [](int mt) { return (NG == 1 || MT == 1) ? 0 : (mt & 1); };
-    auto own_slot = [](int mt) { return NG == 1 ? mt : (mt >> 1); };
+    const int nw = n0 + (COLG ? grp * 128 : 0) + wv * 32;     // first column of this wave
+    const int n = nw + j;
+    constexpr int OWN = KP == 1 ? MT : (MT == 1 ? 1 : MT / 2);
+    auto owner_of = [](int mt) { return (KP == 1 || MT == 1) ? 0 : (mt & 1); };
+    auto owns = [&](int mt) { return KP == 1 || owner_of(mt) == grp; };
+    auto own_slot = [](int mt) { return KP == 1 ? mt : (mt >> 1); };
     float asc[OWN][16];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-        const int mt = NG == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
+        const int mt = KP == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
@@ -330,7 +417,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
         }
     }
     // combine the two K-parity groups (fp32 partial sums): row tile mt is finished by group mt & 1 (MT == 1: group 0)
-    if constexpr (NG == 2) {
+    if constexpr (KP == 2) {
         constexpr int SLOTS = (MT + 1) / 2;
         f32x4* xch = reinterpret_cast<f32x4*>(smem);
     #pragma unroll
@@ -365,11 +452,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (owner_of(mt) != grp) continue;
+        if (!owns(mt)) continue;
         const int o = own_slot(mt);
         if constexpr (sizeof(T) == 2) {
             if (wide) {
-                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, nw, M, N, bias, lane,
                                     [&](int i) { return acc[mt][i] * asc[o][i]; });
                 continue;
             }
@@ -385,23 +472,24 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w4a8_kernel(const i
     }
 }
 
-template <typename T, int MT, int DEPTH, int NG>
+template <typename T, int MT, int DEPTH, int NG, bool COLG = false>
 static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
                           int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     constexpr int BM = 32 * MT;
     const W4A8Layout L = w4a8_layout(N, K, sizeof(T));
-    const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
-    constexpr int kTiles = NG * 3 * BM * 128;
+    constexpr int BN = COLG ? 128 * NG : 128;
+    const int nbx = (int)((N + BN - 1) / BN), nby = (int)((M + BM - 1) / BM);
+    constexpr int kTiles = (COLG ? 1 : NG) * 3 * BM * 128;
     constexpr int kLds = kTiles < NG * 8192 ? NG * 8192 : kTiles;
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4a8_kernel<T, MT, DEPTH, NG>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4a8_kernel<T, MT, DEPTH, NG, COLG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
     static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
     const int sy = NG == 1 ? 8 : 4;
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;    // ql_common.h: xcd_tile_super
-    w4a8_kernel<T, MT, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
+    w4a8_kernel<T, MT, DEPTH, NG, COLG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, (const u32x4*)packed, (const T*)((const char*)packed + L.off_s), (int)M, (int)N, (int)K,
         super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K / 2), super ? sy : 0, a_scale, (const T*)bias, (T*)C, ldc);
     return finish_launch();
@@ -420,8 +508,10 @@ static int launch_w4a8(const int8_t* Aq, const float* a_scale, const void* packe
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
     int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
     if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
-    if (mt == 4 && ng == 1) return launch_w4a8_mt<T, 4, 2, 1>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
-    if (mt == 4) return launch_w4a8_mt<T, 4, 2, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    static const int colg = [] { const char* e = getenv("QLINEAR_W4A8_COLG"); return e ? atoi(e) : 0; }();
+    if (mt == 4 && colg == 1) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 2, true>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    if (mt == 4 && ng == 1) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 1>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
+    if (mt == 4) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
     if (mt == 2) return launch_w4a8_mt<T, 2, 3, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
     return launch_w4a8_mt<T, 1, 3, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
 }
