@@ -282,6 +282,7 @@ static int launch_gemm_any(const void* A, const void* tiled, const void* bias, v
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
+    static const int forced_nw = [] { const char* e = getenv("QLINEAR_GEMM_NW"); return e ? atoi(e) : 0; }();   // 4: two 4-wave blocks per CU (measurement)
     if (forced_nt == 2 && plan.mt == 4)       // 64 columns per wave: every A fragment feeds two MFMAs (experiment)
         return launch_gemm<T, 4, 2, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     if (forced_nt == 2 && plan.mt == 2)
@@ -291,7 +292,7 @@ static int launch_gemm_any(const void* A, const void* tiled, const void* bias, v
         return launch_gemm<T, 8, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     case 4:
         // 8 waves (256 columns) per block halve the A-tile traffic per flop; worth it once that grid still fills the chip
-        if (((N + 255) / 256) * ((M + 127) / 128) >= 256)
+        if (((N + 255) / 256) * ((M + 127) / 128) >= 256 && forced_nw != 4)
             return launch_gemm<T, 4, 1, 8>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
         return launch_gemm<T, 4, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     case 2: return launch_gemm<T, 2, 1, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
