@@ -31,8 +31,15 @@
 
 namespace ql {
 
+#ifndef QL_GEMM_WPE
+#define QL_GEMM_WPE 0
+#endif
 template <typename T, int MT, int NT, int NW, int DEPTH>
-__global__ __launch_bounds__(NW * 64) void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+__global__ __launch_bounds__(NW * 64)
+#if QL_GEMM_WPE
+__attribute__((amdgpu_waves_per_eu(QL_GEMM_WPE, QL_GEMM_WPE)))
+#endif
+void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
                                                                  const T* __restrict__ Sp, int M, int N, int K, int G,
                                                                  int64_t lda, int per, int nbx, const T* __restrict__ bias,
                                                                  T* __restrict__ C, int64_t ldc, float* __restrict__ part) {

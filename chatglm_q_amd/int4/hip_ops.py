@@ -7,6 +7,7 @@ under ``python -O``).
 """
 from __future__ import annotations
 
+import functools
 import os
 
 import torch
@@ -73,6 +74,7 @@ def _rows(a: Tensor) -> Tensor:
     return a2
 
 
+@functools.lru_cache(maxsize=None)
 def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
     return int(_lib.get_lib().qlinear_w4g32_packed_bytes(N, K, group, _lib.dtype_code(dtype)))
 
@@ -82,14 +84,21 @@ def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
 GEMV_MAX_ROWS = int(os.environ.get("QLINEAR_GEMV_MAX_ROWS", "2"))
 
 
+@functools.lru_cache(maxsize=None)
 def gemv_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
     """Bytes of part 1 (column-major, the GEMVs) of the derived layout."""
     return int(_lib.get_lib().qlinear_w4g32_gemv_bytes(N, K, group, _lib.dtype_code(dtype)))
 
 
+@functools.lru_cache(maxsize=None)
 def tiled_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
     """Bytes of part 2 (tile-major, the MFMA kernels); 0 for dtypes without an MFMA path (fp32)."""
     return int(_lib.get_lib().qlinear_w4g32_tiled_bytes(N, K, group, _lib.dtype_code(dtype)))
+
+
+@functools.lru_cache(maxsize=None)
+def _workspace_nbytes(op: int, M: int, N: int, K: int, group: int) -> int:
+    return int(_lib.get_lib().qlinear_workspace_bytes(op, M, N, K, group))
 
 
 def _repack(entry: str, nbytes: int, b: Tensor, b_scale: Tensor) -> Tensor:
@@ -160,7 +169,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
             if a.dtype not in (torch.float16, torch.bfloat16) or group != 32 or tiled.device != a.device or \
                     tiled.numel() < tiled_nbytes(N, K, a.dtype):
                 raise AssertionError("w4_forward: the tile-major buffer serves fp16 / bf16, group 32, and must belong to (K, N)")
-            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, max(M, GEMV_MAX_ROWS + 1), N, K, group))
+            ws_bytes = _workspace_nbytes(_lib.OP_W4G32_FWD_PACKED, max(M, GEMV_MAX_ROWS + 1), N, K, group)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
             st = lib.qlinear_w4g32_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K, group,
                                              a2.stride(0) if M > 1 else K, N, code, _lib.ptr(ws), ws_bytes, stream)
@@ -171,7 +180,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
                 raise AssertionError(f"w4_forward: derived buffer of {packed.numel()} bytes cannot serve {M} rows of a ({K}, {N}) "
                                      f"weight ({need} needed: part 1 alone serves up to {GEMV_MAX_ROWS} rows)")
             # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
-            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group)) if M > 1 else 0
+            ws_bytes = _workspace_nbytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group) if M > 1 else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
             st = lib.qlinear_w4g32_fwd_packed(a2.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
                                               group, a2.stride(0) if M > 1 else K, N, code, flags, _lib.ptr(ws),
@@ -182,7 +191,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
                 b = b.contiguous()
             if not b_scale.is_contiguous():
                 b_scale = b_scale.contiguous()
-            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4G32_FWD, M, N, K, group))
+            ws_bytes = _workspace_nbytes(_lib.OP_W4G32_FWD, M, N, K, group)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
             st = lib.qlinear_w4g32_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(),
                                        M, N, K, group, a2.stride(0) if M > 1 else K, N, code, _lib.ptr(ws), ws_bytes,
