@@ -233,7 +233,9 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 // are its only latency hiding) or 1 (4 waves, <= 256 registers, no combine step: two independent blocks per CU whose
 // prologues / epilogues overlap each other's K loop - the many-row shape; one 8-wave block per CU showed 6.4 us of setup,
 // first-tile latency and epilogue around every 19 us loop, profiles/r02_w8a8_timeline.txt).
-template <typename T, int MT, int S, int DEPTH, int NG>
+// COLG (with NG = 2): the two groups are COLUMN groups instead - the block covers 256 columns, both groups walk the same K
+// chunks and share ONE A tile in LDS (half the A bytes per flop from L2 / the fabric, no exchange at the end).
+template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
                                                          int N, int K, int nbx, int rotate, int super_rows, const float* __restrict__ a_scale,
                                                          const T* __restrict__ S_, const T* __restrict__ bias,
@@ -243,28 +245,32 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     constexpr int BM = 32 * MT;
     constexpr int BK = 128 * S;
     constexpr int CPR = 8 * S;                         // 16-byte chunks per tile row
+    constexpr int KP = COLG ? 1 : NG;                  // K-parity groups
+    constexpr int BN = COLG ? 128 * NG : 128;          // columns per block
+    constexpr int STG = COLG ? NG * 256 : 256;         // threads staging one A tile
     constexpr int NCH = BM * CPR;                      // chunks per tile
-    constexpr int ACH = (NCH + 255) / 256;             // ... staged per thread (of a group) per iteration
-    constexpr bool kAllStage = NCH % 256 == 0;
+    constexpr int ACH = (NCH + STG - 1) / STG;         // ... staged per thread per iteration
+    constexpr bool kAllStage = NCH % STG == 0;
     constexpr int BUF = BM * BK;                       // one A-tile buffer
     constexpr int NS = 4 * S;                          // MFMA sub-steps per chunk
     const T* __restrict__ Sc = S_;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
 
-    const int tid = threadIdx.x, lane = tid & 63, tg = tid & 255;
+    const int tid = threadIdx.x, lane = tid & 63, tg = COLG ? tid : tid & 255;
     QL_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
     const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;       // tests and the buffer bases then live in SGPRs
     const int j = lane & 31, kb = lane >> 5;
     const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
-    const int m0 = tile.y * BM, n0 = tile.x * 128;
+    const int m0 = tile.y * BM, n0 = tile.x * BN;
+    const int kgrp = COLG ? 0 : grp;                   // K-parity index of this group
     const int ksteps64 = (K + 63) >> 6;                // tile-major units per column tile
     const int nchunks = (K + BK - 1) / BK;
-    const int niter = NG == 1 ? nchunks : (nchunks + 1) >> 1;   // both groups run the same number of iterations (barriers!)
+    const int niter = KP == 1 ? nchunks : (nchunks + 1) >> 1;   // both groups run the same number of iterations (barriers!)
     const int ctiles = (N + 31) >> 5;
-    const int ct_raw = tile.x * 4 + wv;
+    const int ct_raw = tile.x * (BN / 32) + (COLG ? grp * 4 : 0) + wv;
     const int8_t* wbase = Wm + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 2048 + lane * 16;
-    char* lds_a = smem + grp * (3 * BUF);
+    char* lds_a = smem + kgrp * (3 * BUF);
 
     // swizzle: chunk c of row r sits at chunk position CPR r + (c ^ x(r)); 128-byte rows: x = (r >> 1) & 7, 256-byte
     // rows (one row = all 64 banks): x = r & 15 - fragment reads (16 lanes = 16 rows, one chunk index) conflict-free
@@ -273,11 +279,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     int a_dst[ACH];
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
-        const int q = tg + u * 256, r = (q / CPR) % BM, c = q % CPR;
+        const int q = tg + u * STG, r = (q / CPR) % BM, c = q % CPR;
         a_src[u] = Aq + (int64_t)((m0 + r < M) ? (m0 + r) : (M - 1)) * K + c * 16;
         a_dst[u] = (r * CPR + (c ^ swz(r))) * 16;
     }
-    const int c_mine = tg % CPR;                       // (tg + 256 u) % CPR is the same for every u
+    const int c_mine = tg % CPR;                       // (tg + STG u) % CPR is the same for every u
     const int klast = K - 16;                          // last in-bounds 16-byte chunk start (K % 16 == 0)
     // fragment read offsets: sub-step s = (step, unit, half) reads chunk 8 step + 4 unit + 2 kb + half of row mt * 32 + j;
     // swz(mt * 32 + j) does not depend on mt, so ONE offset per sub-step serves every row tile (+ mt * 32 rows: immediate)
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     auto chunk_of = [&](int i) {                       // K chunk of loop iteration i (i may run past niter: clamped by users)
         int r = i + rot;
         r = r >= niter ? r - niter : r;
-        return NG * r + grp;
+        return KP * r + kgrp;
     };
     auto load_w = [&](int i, Stage& sg) {
         int t = chunk_of(i < niter ? i : niter - 1);
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     auto store_a = [&](int buf, const i32x4 (&src)[ACH]) {
 #pragma unroll
         for (int u = 0; u < ACH; ++u)
-            if (!(QL_W8A8_ABLATE & 32) && (kAllStage || tg + u * 256 < NCH))
+            if (!(QL_W8A8_ABLATE & 32) && (kAllStage || tg + u * STG < NCH))
                 *reinterpret_cast<i32x4*>(lds_a + buf * BUF + a_dst[u]) = src[u];
     };
     auto read_a = [&](int buf, int sub, i32x4 (&fr)[MT]) {
@@ -473,15 +479,17 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     QL_STAMP(4);                                       // K loop done
     // epilogue operands requested NOW: their global round trip overlaps the exchange below instead of sitting in the
     // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
-    const int n = n0 + wv * 32 + j;
+    const int nw = n0 + (COLG ? grp * 128 : 0) + wv * 32;     // first column of this wave
+    const int n = nw + j;
     const float ws = Act<T>::load(Sc + (n < N ? n : N - 1));
-    constexpr int OWN = NG == 1 ? MT : (MT == 1 ? 1 : MT / 2);            // row tiles this group finishes
-    auto owner_of = [](int mt) { return (NG == 1 || MT == 1) ? 0 : (mt & 1); };
-    auto own_slot = [](int mt) { return NG == 1 ? mt : (mt >> 1); };
+    constexpr int OWN = KP == 1 ? MT : (MT == 1 ? 1 : MT / 2);            // row tiles this group finishes
+    auto owner_of = [](int mt) { return (KP == 1 || MT == 1) ? 0 : (mt & 1); };
+    auto owns = [&](int mt) { return KP == 1 || owner_of(mt) == grp; };
+    auto own_slot = [](int mt) { return KP == 1 ? mt : (mt >> 1); };
     float asc[OWN][16];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-        const int mt = NG == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
+        const int mt = KP == 1 ? o : (MT == 1 ? 0 : 2 * o + grp);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     // ---- combine the two K-parity groups through LDS (exact: int32), then the rank-1 scale epilogue ----------
     // row tile mt is finished by group (mt & 1) (MT == 1: group 0): each group hands the OTHER group's tiles over
     // as 16-byte pieces [tile slot][piece q][lane] - consecutive lanes, consecutive 16 bytes: conflict-free
-    if constexpr (NG == 2) {
+    if constexpr (KP == 2) {
         constexpr int SLOTS = (MT + 1) / 2;                                    // tiles a group receives
         i32x4* xch = reinterpret_cast<i32x4*>(smem);
     #pragma unroll
@@ -537,11 +545,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     T* lds_wave = reinterpret_cast<T*>(smem) + (grp * 4 + wv) * 1024;     // 2 KB per wave (16 KB <= the A buffers)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (owner_of(mt) != grp) continue;
+        if (!owns(mt)) continue;
         const int o = own_slot(mt);
         if constexpr (sizeof(T) == 2) {
             if (wide) {
-                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, n0 + wv * 32, M, N, bias, lane,
+                store_tile_32x32<T>(lds_wave, C, ldc, m0 + mt * 32, nw, M, N, bias, lane,
                                     [&](int i) { return (float)acc[mt][i] * (asc[o][i] * ws); });
                 continue;
             }
@@ -558,15 +566,16 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     QL_STAMP(6);                                       // output tiles stored (this wave)
 }
 
-template <typename T, int MT, int S, int DEPTH, int NG>
+template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false>
 static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* Sc, const void* bias, void* C,
                                 int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     constexpr int BM = 32 * MT;
-    const int nbx = (int)((N + 127) / 128), nby = (int)((M + BM - 1) / BM);
-    constexpr int kTiles = NG * 3 * BM * 128 * S;                               // NG groups x three A buffers
+    constexpr int BN = COLG ? 128 * NG : 128;
+    const int nbx = (int)((N + BN - 1) / BN), nby = (int)((M + BM - 1) / BM);
+    constexpr int kTiles = (COLG ? 1 : NG) * 3 * BM * 128 * S;                  // K-parity groups x three A buffers
     constexpr int kLds = kTiles < NG * 8192 ? NG * 8192 : kTiles;              // epilogue: 2 KB per wave
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH, NG>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
@@ -574,7 +583,7 @@ static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const in
     static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
     const int sy = NG == 1 ? 8 : 4;                    // blocks in flight per XCD: 64 (two per CU) or 32
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
-    w8a8_tiled_kernel<T, MT, S, DEPTH, NG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
+    w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, super ? sy : 0,
         a_scale, (const T*)Sc,
         (const T*)bias, (T*)C, ldc);
@@ -596,6 +605,8 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
     // two independent 4-wave blocks per CU once there are at least two 128-row tiles per CU
     int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
     if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
+    static const int colg = [] { const char* e = getenv("QLINEAR_W8A8_COLG"); return e ? atoi(e) : 0; }();
+    if (mt == 4 && colg == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 4 && ng == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 1>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 2) return launch_w8a8_tiled_mt<T, 2, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
