@@ -155,6 +155,12 @@ int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, 
     return w4_tiled(dtype, A, tiled, bias, C, M, N, K, lda, ldc, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags) {
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return 0;         // fp32 has no MFMA path
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+    return w4_rows_use_gemm(M, N, K) && !w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0) ? 1 : 0;
+}
+
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                              int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, int flags,
                              void* workspace, size_t workspace_bytes, void* stream) {

@@ -83,6 +83,12 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int w4_fewrow(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate = false);   // tiled: part 2
 
+// w4_rows4.hip (1..4 rows, fp16 / bf16, exact-dequant arithmetic): 4x4x4 MFMA on part 1 of the derived layout; ks = K slices per quad
+bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
+bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict);   // w4_packed.hip: the routing rule
+int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+             int64_t lda, int64_t ldc, hipStream_t st);
+
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,
              int64_t lda, int64_t ldw, int64_t lds, int64_t ldc, hipStream_t st);

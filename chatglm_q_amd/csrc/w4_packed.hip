@@ -909,6 +909,20 @@ int w4_packed_residual(int dtype, const void* A, const void* packed, const void*
     return QL_ERR_UNSUPPORTED;
 }
 
+// 2..4 rows in the default arithmetic: the 4x4x4-MFMA kernel on part 1 (w4_rows4.hip).  Measured against what served those
+// row counts before (us, fp16, ChatGLM2-6B shapes qkv / o / w_in / w_out; tools/gemv_rows.py):
+//   rows   GEMV (2) / few-row MFMA (3, 4)     rows4
+//   2      6.6 / 5.9 / 19.1 / 13.1            6.5 / 5.8 / 17.1 / 11.8
+//   3      8.8 / 8.4 / 19.6 / 13.8            6.9 / 6.2 / 17.9 / 15.4
+//   4      9.1 / 8.4 / 19.3 / 13.6            7.2 / 6.6 / 18.5 / 16.5
+// (one row: 4.7 / 4.4 / 13.0 / 9.1 on the GEMV, 6.0 / 5.3 / 15.9 / 13.9 here) - so: 2 rows always, 3 and 4 rows while the
+// staged rows stay small (K <= 8192: w_out's 13696-deep rows are the case that loses).  QLINEAR_ROWS4_MIN / _MAX move the
+// row range (MAX = 0 turns the kernel off).
+bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict) {
+    static const int r4_min = env_int("QLINEAR_ROWS4_MIN", 2), r4_max = env_int("QLINEAR_ROWS4_MAX", 4);
+    return !strict && M >= r4_min && M <= r4_max && (M <= 2 || M * K * 2 <= 64 * 1024) && w4_rows4_supported(dtype, M, N, K, lda);
+}
+
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return M > forced;
@@ -932,6 +946,10 @@ int w4_tiled(int dtype, const void* A, const void* tiled, const void* bias, void
 
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (w4_rows4_serves(dtype, M, N, K, lda, strict)) {
+        const int64_t Npad = (N + 3) & ~(int64_t)3;
+        return w4_rows4(dtype, choose_ksplit(Npad / 4, K / 32, (int)M), A, packed, bias, C, M, N, K, lda, ldc, st);
+    }
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
     if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
         return w4_tiled(dtype, A, (const char*)packed + w4_layout(N, K, 2).off_wm, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);

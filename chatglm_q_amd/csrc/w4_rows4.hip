@@ -1,0 +1,265 @@
+// int4g32 forward for 2..4 activation rows on the 4x4x4 matrix instruction (gfx950), derived layout part 1.
+//
+// Why: the VALU GEMV (w4_packed.hip) pays one v_dot2c per weight pair AND ROW - two rows cost 46 % more than one
+// (w_in: 20 us against 13.7), four rows 3.5x - and the 32-row MFMA tiles of w4_fewrow.hip pay for 32 rows whatever the
+// count (w_in: 20 - 22 us at 3..16 rows).  v_mfma_f32_4x4x4_16b_{f16,bf16} is 16 independent 4 x 4 x 4 products: block
+// b = lane / 4; lane 4 b + i supplies row i of A (4 values of k), lane 4 b + j column j of B, and lane 4 b + j receives
+// D[0..3][j] - FOUR rows for one instruction, with the weights of column j never leaving the lane that unpacked them
+// (mapping probed on the hardware: tools/microbench/mfma4_probe.hip).  Mapping used here: block b <-> one K group
+// (16 consecutive groups per wave step), lane j of a block <-> column j of the wave's column quad; per step a lane
+// loads ONE 16-byte unit (its column's 32 nibbles of its group) and issues 8 MFMAs (4 k each).
+// Arithmetic = the GEMV's default mode (exact dequant: no per-weight rounding, fp32 accumulation, rounded once at the
+// end; include/qlinear_hip.h QL_FLAG_STRICT_ROUNDING explains the two modes):
+//   fp16: (n - 8) is formed exactly in fp16 from the exponent splice (0x6400 | n) - 1032 resp. (0x6400 | 16 n) / 16 - 72
+//   bf16: no packed bf16 arithmetic on this chip - the splice 128 + n goes into the MFMA as it is and a second MFMA with
+//         B = 1 accumulates the row's activation sum; (sum a (128 + n)) - 136 (sum a) = sum a (n - 8), in fp32.
+// Reference semantic: chatglm_q/int4/triton_ops.py:66-80 (nibble decode, group scale, fp32 accumulate, cast), bias added
+// as a second rounded operation (chatglm_q/int4/qlinear.py:90-94).
+#include <cstdlib>
+
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Rows4;
+template <> struct Rows4<f16> {
+    static __device__ __forceinline__ f32x4 mma(u32 a0, u32 a1, u32 b0, u32 b1, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, u32x2{a0, a1}), __builtin_bit_cast(f16x4, u32x2{b0, b1}), c, 0, 0, 0);
+    }
+};
+template <> struct Rows4<__bf16> {
+    static __device__ __forceinline__ f32x4 mma(u32 a0, u32 a1, u32 b0, u32 b1, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(s16x4, u32x2{a0, a1}), __builtin_bit_cast(s16x4, u32x2{b0, b1}), c, 0, 0, 0);
+    }
+};
+
+// KS: K slices per column quad inside the block (its 4 waves = 4 / KS quad sets x KS slices), as in the GEMV.
+// NQ: column quads per wave: they share the activation fragments (LDS reads per weight / NQ), the staged rows and the
+// block's fixed costs (staging, barriers, reduction) are spread over NQ x the columns.
+template <typename T, int KS, int RING, int NQ>
+__global__ __launch_bounds__(256) void w4_rows4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                       int N, int K, int M, int lda32, const T* __restrict__ bias,
+                                                       T* __restrict__ C, int64_t ldc) {
+    constexpr bool kF16 = Act<T>::code == QL_DTYPE_F16;
+    constexpr int QW = 4 / KS;                                 // quad sets per block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int G = K >> 5, cpr = K >> 3;
+    const int64_t lda = lda32;
+    const int rowb = K * 2 + 16;                               // staged row + 16 bytes: the 4 rows of a block land in 4 bank groups
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = lane >> 2, x = lane & 3;                     // x: row index as A supplier, column index as B supplier / D owner
+    const int ks = wave % KS;
+    const int quads = (N + 3) >> 2;
+    const int t0 = (blockIdx.x * QW + wave / KS) * NQ;         // first quad of this wave
+    const int gs = (G + KS - 1) / KS, g_begin = ks * gs;
+    const int g_end = G < g_begin + gs ? G : g_begin + gs;
+    const int iters = g_end > g_begin ? (g_end - g_begin + 15) >> 4 : 0;
+
+    // weight / scale ring first: independent of the activations, RING steps in flight before anything waits
+    const u32x4* wp[NQ];
+    const T* sp[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int t = t0 + n < quads ? t0 + n : 0;             // quads past the end shadow quad 0 (stores are masked)
+        wp[n] = Wt + (int64_t)(t * 4 + x) * G;
+        sp[n] = Sp + (int64_t)t * G * 4 + x;
+    }
+    auto group_of = [&](int it) {
+        const int g = g_begin + it * 16 + b;
+        return g < g_end ? g : (g_end > g_begin ? g_end - 1 : 0);
+    };
+    u32x4 wr[RING][NQ];
+    T sr[RING][NQ];
+    auto load_w = [&](int it, int slot) {
+        const int gc = group_of(it < iters ? it : (iters > 0 ? iters - 1 : 0));
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            wr[slot][n] = __builtin_nontemporal_load(wp[n] + gc);
+            sr[slot][n] = sp[n][(int64_t)gc * 4];
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < RING; ++r) load_w(r, r);
+
+    // stage the M rows: 16-byte chunk cc of row m (k = 8 cc .. 8 cc + 7) at m * rowb + 16 cc, its dwords in the order
+    // (0, 2, 1, 3): the two dwords an MFMA takes as its A operand are then an aligned register pair of the ds_read_b128.
+    // No swizzle: the 16 lanes of a ds_read_b128 phase are 4 blocks (64-byte stride) x 4 rows (16-byte row padding).
+    for (int c = tid; c < M * cpr; c += 256) {
+        const int m = c / cpr, cc = c - m * cpr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + cc * 8);
+        *reinterpret_cast<u32x4*>(smem + (int64_t)m * rowb + cc * 16) = u32x4{v[0], v[2], v[1], v[3]};
+    }
+    __syncthreads();
+
+    const char* arow = smem + (int64_t)(x < M ? x : M - 1) * rowb;   // rows past M repeat the last one (their sums are dropped)
+    u32 k_lo, k_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(kF16 ? 0x64006400 : 0x43004300));
+    const h2 k1032 = {(f16)1032.0f, (f16)1032.0f}, kInv16 = {(f16)0.0625f, (f16)0.0625f}, kM72 = {(f16)-72.0f, (f16)-72.0f};
+    const u32 kOnes = 0x3F803F80u;                             // bf16 (1, 1)
+
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the 4 activation chunks of a step are requested one step AHEAD (two register sets, alternating): issued in front of
+    // each MFMA they put a full LDS round trip on every one of them
+    auto load_a = [&](int it, u32x4 (&av)[4]) {
+        const int gc = group_of(it < iters ? it : (iters > 0 ? iters - 1 : 0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const u32x4*>(arow + gc * 64 + q * 16);
+    };
+    auto step = [&](int it, int slot, const u32x4 (&av)[4]) {
+        const int g = g_begin + it * 16 + b;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 osum;                                            // bf16: the rows' activation sums, shared by the NQ quads
+        if constexpr (!kF16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                osum = Rows4<T>::mma(av[q][0], av[q][1], kOnes, kOnes, q == 0 ? zero : osum);
+                osum = Rows4<T>::mma(av[q][2], av[q][3], kOnes, kOnes, osum);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            const u32x4 wv = wr[slot][n];
+            const float sc = g < g_end ? (float)sr[slot][n] : 0.f;       // lanes past the slice contribute 0
+            f32x4 e, o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // word q holds k = 8 q .. 8 q + 7 at nibble positions p(k) = (k >> 1) + 4 (k & 1)  [w4_repack_kernel]:
+                // (w & 0x000F000F) = nibbles of k (0, 1), ((w >> 8) & 0x000F000F) = k (4, 5): one MFMA over k {0, 1, 4, 5}
+                // with dwords 0 and 2 of the activation chunk (staged as registers 0, 1); the 0x00F000F0 masks give k (2, 3)
+                // and (6, 7): dwords 1 and 3 (registers 2, 3)
+                const u32 w = wv[q], w8 = w >> 8;
+                if constexpr (kF16) {
+                    const u32 b0 = as_u32(as_h2((w & k_lo) | k_magic) - k1032);
+                    const u32 b1 = as_u32(as_h2((w8 & k_lo) | k_magic) - k1032);
+                    const u32 b2 = as_u32(as_h2((w & k_hi) | k_magic) * kInv16 + kM72);
+                    const u32 b3 = as_u32(as_h2((w8 & k_hi) | k_magic) * kInv16 + kM72);
+                    e = Rows4<T>::mma(av[q][0], av[q][1], b0, b1, q == 0 ? zero : e);
+                    o = Rows4<T>::mma(av[q][2], av[q][3], b2, b3, q == 0 ? zero : o);
+                } else {
+                    // bf16: 128 + n as spliced
+                    const u32 b0 = (w & k_lo) | k_magic, b1 = (w8 & k_lo) | k_magic;
+                    const u32 b2 = ((w >> 4) & k_lo) | k_magic, b3 = ((w8 >> 4) & k_lo) | k_magic;
+                    e = Rows4<T>::mma(av[q][0], av[q][1], b0, b1, q == 0 ? zero : e);
+                    o = Rows4<T>::mma(av[q][2], av[q][3], b2, b3, q == 0 ? zero : o);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float grp = kF16 ? e[i] + o[i] : __builtin_fmaf(-136.0f, osum[i], e[i] + o[i]);
+                acc[n][i] = __builtin_fmaf(sc, grp, acc[n][i]);
+            }
+        }
+    };
+
+    // ring walk: slot r serves steps r, r + RING, ...; the refill is issued right behind the step that freed the slot.
+    // Whole rounds only contain unconditional loads (hipcc then counts its vmcnt waits); the last round is peeled.
+    static_assert(RING % 2 == 0, "the activation register sets alternate with the step parity");
+    u32x4 av[2][4];
+    load_a(0, av[0]);
+    int it = 0;
+    for (; it + 2 * RING <= iters; it += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            load_a(it + r + 1, av[(r + 1) & 1]);
+            step(it + r, r, av[r & 1]);
+            load_w(it + r + RING, r);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * RING - 1; ++r) {
+        if (it + r < iters) {
+            load_a(it + r + 1, av[(r + 1) & 1]);
+            step(it + r, r % RING, av[r & 1]);
+            if (it + r + RING < iters) load_w(it + r + RING, r % RING);
+        }
+    }
+
+    // sum over the 16 blocks of the wave (lanes of equal x): DPP inside each 16-lane row, the 4 rows through LDS -
+    // together with the K slices of the other waves
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[n][i] += dpp_move<0x128>(acc[n][i]);            // row_ror:8
+            acc[n][i] += dpp_move<0x124>(acc[n][i]);            // row_ror:4
+        }
+    __syncthreads();                                            // every wave is done with the staged rows
+    float* red = reinterpret_cast<float*>(smem);               // [wave][quad of the wave][16-lane row][x][i]
+    if ((lane & 12) == 0) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(((wave * NQ + n) * 4 + (lane >> 4)) * 4 + x) * 4 + i] = acc[n][i];
+    }
+    __syncthreads();
+    for (int o = tid; o < QW * NQ * 16; o += 256) {
+        const int qs = o / (NQ * 16), n = (o >> 4) % NQ, j = (o >> 2) & 3, i = o & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += red[((((qs * KS + k) * NQ + n) * 4 + r) * 4 + j) * 4 + i];
+        const int col = ((blockIdx.x * QW + qs) * NQ + n) * 4 + j;
+        if (i < M && col < N) store_out<T>(C + (int64_t)i * ldc + col, s, bias ? bias + col : nullptr);
+    }
+}
+
+template <typename T, int KS, int NQ>
+static int launch_rows4_ks(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
+                           int64_t ldc, hipStream_t st) {
+    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
+    const u32x4* Wt = (const u32x4*)packed;
+    const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
+    constexpr int QW = 4 / KS, RING = 4;
+    const int quads = (int)(Npad / 4), per_block = QW * NQ;
+    size_t lds = (size_t)M * (K * 2 + 16);
+    if (lds < (size_t)4 * NQ * 256) lds = (size_t)4 * NQ * 256;                 // the reduction scratch
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    }();
+    (void)attr_set;
+    w4_rows4_kernel<T, KS, RING, NQ><<<(unsigned)((quads + per_block - 1) / per_block), 256, lds, st>>>(
+        (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda) {
+    // the M staged rows (+ 16 bytes each) live in LDS; one block per CU is the floor for the widest layer
+    return (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && M >= 1 && M <= 4 && K % 32 == 0 && K >= 32 && lda <= 0x7fffffff &&
+           (size_t)M * (K * 2 + 16) <= 150 * 1024;
+}
+
+// ks: K slices per column quad (1, 2 or 4: w4_packed.hip's choose_ksplit)
+int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+             int64_t lda, int64_t ldc, hipStream_t st) {
+#define QL_R4(T_)                                                                                                       \
+    if (nq == 2) switch (ks) {                                                                                          \
+    case 4: return launch_rows4_ks<T_, 4, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
+    case 2: return launch_rows4_ks<T_, 2, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
+    default: return launch_rows4_ks<T_, 1, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                \
+    }                                                                                                                   \
+    switch (ks) {                                                                                                       \
+    case 4: return launch_rows4_ks<T_, 4, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
+    case 2: return launch_rows4_ks<T_, 2, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
+    default: return launch_rows4_ks<T_, 1, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                \
+    }
+    // one quad per wave; two (QLINEAR_ROWS4_NQ=2: shared activation fragments, half the blocks) measured slower on every
+    // layer shape but w_out at one row (2 rows: 7.2 / 5.8 / 18.4 / 13.3 us against 6.5 / 5.8 / 17.1 / 11.8)
+    static const int nq = [] { const char* e = getenv("QLINEAR_ROWS4_NQ"); return e && atoi(e) == 2 ? 2 : 1; }();
+    if (dtype == QL_DTYPE_F16) { QL_R4(f16) }
+    if (dtype == QL_DTYPE_BF16) { QL_R4(__bf16) }
+#undef QL_R4
+    return QL_ERR_BAD_DTYPE;
+}
+
+}  // namespace ql

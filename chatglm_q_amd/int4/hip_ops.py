@@ -79,9 +79,19 @@ def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
     return int(_lib.get_lib().qlinear_w4g32_packed_bytes(N, K, group, _lib.dtype_code(dtype)))
 
 
-# rows served by the GEMV (part 1 of the derived layout); more rows take the MFMA kernels on part 2.  The library reads the
-# same variable (w4_rows_use_gemm, csrc/w4_packed.hip).
+# rows served by the GEMV (part 1 of the derived layout).  The library reads the same variable (w4_rows_use_gemm,
+# csrc/w4_packed.hip); which part a given call needs is the library's decision: rows_on_tiled().
 GEMV_MAX_ROWS = int(os.environ.get("QLINEAR_GEMV_MAX_ROWS", "2"))
+
+
+@functools.lru_cache(maxsize=None)
+def rows_on_tiled(M: int, N: int, K: int, dtype: torch.dtype, strict: bool = False) -> bool:
+    """True when ``M`` rows of a (K, N) int4g32 weight are served from part 2 of the derived layout (tile-major: few-row and
+    MFMA GEMM kernels), False when part 1 serves them (GEMV, the 4x4x4-MFMA kernel for 2..4 rows, fp32)."""
+    if dtype not in (torch.float16, torch.bfloat16):
+        return False
+    flags = _lib.FLAG_STRICT_ROUNDING if strict else 0
+    return bool(_lib.get_lib().qlinear_w4g32_rows_on_tiled(M, N, K, _lib.dtype_code(dtype), flags))
 
 
 @functools.lru_cache(maxsize=None)
@@ -164,7 +174,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
         bias = bias.contiguous()
     with torch.cuda.device(a.device):
         stream = _lib.stream_ptr(a.device)
-        mfma_rows = M > GEMV_MAX_ROWS and a.dtype in (torch.float16, torch.bfloat16)
+        mfma_rows = group == 32 and rows_on_tiled(M, N, K, a.dtype, bool(flags & _lib.FLAG_STRICT_ROUNDING))
         if tiled is not None and (mfma_rows or packed is None):
             if a.dtype not in (torch.float16, torch.bfloat16) or group != 32 or tiled.device != a.device or \
                     tiled.numel() < tiled_nbytes(N, K, a.dtype):
@@ -178,7 +188,7 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
             need = packed_nbytes(N, K, a.dtype, group) if mfma_rows else gemv_nbytes(N, K, a.dtype, group)
             if packed.device != a.device or packed.numel() < need:
                 raise AssertionError(f"w4_forward: derived buffer of {packed.numel()} bytes cannot serve {M} rows of a ({K}, {N}) "
-                                     f"weight ({need} needed: part 1 alone serves up to {GEMV_MAX_ROWS} rows)")
+                                     f"weight ({need} needed: part 1 alone serves few rows only, see rows_on_tiled)")
             # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
             ws_bytes = _workspace_nbytes(_lib.OP_W4G32_FWD_PACKED, M, N, K, group) if M > 1 else 0
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None

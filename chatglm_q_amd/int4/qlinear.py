@@ -158,7 +158,7 @@ class DynamicQuantizeLinear(nn.Module):
         if self._packed is None or self._packed_key != key:
             self._packed = hip_ops.repack_w4g32_gemv(self.weight, self.weight_scale)
             self._packed_key = key
-        if rows > hip_ops.GEMV_MAX_ROWS and self.weight_scale.dtype in (torch.float16, torch.bfloat16):
+        if hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, self.weight_scale.dtype, _lib.STRICT_DEFAULT):
             self.tiled()
         return self
 
@@ -218,7 +218,7 @@ class DynamicQuantizeLinear(nn.Module):
             packed = tiled = None
             half = input.dtype in (torch.float16, torch.bfloat16)
             if (rows <= PACKED_MAX_ROWS or half) and self._packed_supported() and input.dtype == self.weight_scale.dtype:
-                if half and rows > hip_ops.GEMV_MAX_ROWS:
+                if half and hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, input.dtype, _lib.STRICT_DEFAULT):
                     tiled = self.tiled()
                 else:
                     packed = self.prepare()._packed

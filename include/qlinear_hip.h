@@ -139,6 +139,10 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * qlinear_w4g32_fwd_tiled (the few-row and MFMA GEMM kernels; workspace: qlinear_workspace_bytes(QL_OP_W4G32_FWD_PACKED)).
  * gemv_bytes + tiled_bytes == packed_bytes, and a buffer of qlinear_w4g32_repack is exactly gemv followed by tiled.
  * The host module (chatglm_q_amd/int4/qlinear.py) builds part 2 on the first forward with >= 3 rows. */
+/* 1 when qlinear_w4g32_fwd_packed serves this call from part 2 (a caller that keeps the parts apart then calls
+ * qlinear_w4g32_fwd_tiled), 0 when part 1 does: one or two rows (GEMV), 2..4 rows in the default arithmetic on the 4x4x4
+ * matrix instruction (w4_rows4.hip), fp32 at any row count. */
+int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags);
 size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, int64_t group, int dtype,

@@ -306,10 +306,14 @@ def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     gp, gb = layer.gated_tiled(hidden)
     assert layer.gated_tiled(hidden)[0] is gp
     got = H4.w4_forward_gated(x, gp, 2 * hidden, gb)
-    with torch.no_grad():
-        want = F_.silu_mul(layer(x), hidden)
+    # the same few-row kernel without the epilogue (the module itself may serve 3 / 4 rows through the 4x4x4-MFMA kernel,
+    # whose default arithmetic rounds differently: within tolerance of this, not bit-equal)
+    y = H4.w4_forward(x, layer.weight, layer.weight_scale, layer.bias, None, tiled=layer.tiled())
+    want = F_.silu_mul(y, hidden)
     assert got is not None and got.shape == (M, 1, hidden)
     assert torch.equal(got, want)
+    with torch.no_grad():
+        assert O.rel_l2(t2n(F_.silu_mul(layer(x), hidden)), t2n(want)) < (2e-3 if dtype == torch.float16 else 8e-3)
     # narrow matrices take K slabs + a reduce launch: not served
     small = DynamicQuantizeLinear(4096, 512, bias=False, dtype=dtype, device=DEV)
     small.weight.copy_(torch.randint(0, 256, small.weight.shape, dtype=torch.uint8, device=DEV, generator=g))

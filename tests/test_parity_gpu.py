@@ -149,6 +149,12 @@ W4_SHAPES = [
     (40, 512, 264, "bf16", False),
     (1, 4096, 4096, "f32", False),
     (7, 1024, 264, "f32", True),
+    (2, 13696, 4096, "f16", False),     # 2..4 rows: the 4x4x4-MFMA kernel (w4_rows4.hip); w_out, 4 K slices per quad
+    (3, 4096, 4608, "bf16", True),      # ... bf16 (activation-sum MFMA), qkv_proj
+    (4, 4096, 1024, "f16", True),       # ... all four rows of the instruction
+    (2, 96, 20, "bf16", False),         # ... 3 groups (13 of the 16 blocks idle), ragged N
+    (4, 2080, 36, "f16", True),         # ... 65 groups: a ragged last step; N % 8 != 0
+    (3, 13696, 256, "f16", False),      # ... 3 rows of 13696: staged rows too large -> few-row MFMA kernel
     (2, 64, 36, "f16", True),           # N % 8 != 0 -> generic kernel / packed padding
     (3, 96, 8, "f32", False),
 ]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One- and two-row int4g32 GEMV time per ChatGLM2-6B layer shape (rotating weight sets, one HIP graph)."""
+"""int4g32 forward time at 1, 2 (default; or argv) rows per ChatGLM2-6B layer shape (rotating weight sets, one HIP graph)."""
 import os
 import sys
 
@@ -14,7 +14,7 @@ for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 40
     n = max(4, min(40, (700 << 20) // (K * N // 2)))
     layers = [_w4_layer(torch, dev, K, N, False, gen) for _ in range(n)]
     row = [name]
-    for M in (1, 2):
+    for M in ([int(v) for v in sys.argv[1:]] or [1, 2]):
         x = torch.randn(M, K, device=dev, dtype=torch.float16)
         def f():
             with torch.no_grad():
