@@ -912,9 +912,9 @@ int w4_packed_residual(int dtype, const void* A, const void* packed, const void*
 // 2..4 rows in the default arithmetic: the 4x4x4-MFMA kernel on part 1 (w4_rows4.hip).  Measured against what served those
 // row counts before (us, fp16, ChatGLM2-6B shapes qkv / o / w_in / w_out; tools/gemv_rows.py):
 //   rows   GEMV (2) / few-row MFMA (3, 4)     rows4
-//   2      6.6 / 5.9 / 19.1 / 13.1            6.5 / 5.8 / 17.1 / 11.8
-//   3      8.8 / 8.4 / 19.6 / 13.8            6.9 / 6.2 / 17.9 / 15.4
-//   4      9.1 / 8.4 / 19.3 / 13.6            7.2 / 6.6 / 18.5 / 16.5
+//   2      6.6 / 5.9 / 19.1 / 13.1            5.9 / 5.2 / 15.9 / 12.0
+//   3      8.8 / 8.4 / 19.6 / 13.8            6.7 / 5.4 / 16.6 / (15.4)
+//   4      9.1 / 8.4 / 19.3 / 13.6            6.9 / 5.5 / 17.1 / (16.5)
 // (one row: 4.7 / 4.4 / 13.0 / 9.1 on the GEMV, 6.0 / 5.3 / 15.9 / 13.9 here) - so: 2 rows always, 3 and 4 rows while the
 // staged rows stay small (K <= 8192: w_out's 13696-deep rows are the case that loses).  QLINEAR_ROWS4_MIN / _MAX move the
 // row range (MAX = 0 turns the kernel off).

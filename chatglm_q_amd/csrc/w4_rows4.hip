@@ -20,6 +20,24 @@
 #include "launch.h"
 #include "ql_common.h"
 
+// Build-time switches (tools/ab).  QL_ROWS4_ABLATE bit 0 = no arithmetic (loaded words are folded into the sums as they are),
+// bit 1 = no activation reads from LDS: with both, w_in still takes 14.1 us at 2 rows and 17.6 at 4 (4 waves per block) -
+// the kernel is bound by its skeleton, above all by every block staging its own copy of the M activation rows (w_in:
+// 1 712 blocks x M x 8 KB = 56 MB at 4 rows, as much as the weights), not by the matrix or vector pipes.  Hence
+// QL_ROWS4_WAVES = 8 waves per block sharing one staged copy, and QL_ROWS4_RING = 2 weight steps in flight per wave
+// (more costs occupancy).  Measured, us at 2 / 4 rows for qkv, o, w_in (fp16):
+//   4 waves, ring 4: 6.5 5.8 17.1 / 7.3 6.5 19.1      8 waves, ring 4: 6.9 5.5 17.4 / 7.3 6.0 18.1     16 waves, ring 2: 6.0 6.0 17.0 / 6.3 6.1 17.2
+//   4 waves, ring 2: 6.6 5.6 16.9 / 7.3 6.1 18.4      8 waves, ring 2: 5.9 5.2 15.9 / 6.9 5.5 17.1     4 waves, ring 8: 10.0 6.9 21.2 / 11.6 7.7 23.4
+#ifndef QL_ROWS4_ABLATE
+#define QL_ROWS4_ABLATE 0
+#endif
+#ifndef QL_ROWS4_RING
+#define QL_ROWS4_RING 2
+#endif
+#ifndef QL_ROWS4_WAVES
+#define QL_ROWS4_WAVES 8          // waves per block: they share ONE staged copy of the activation rows
+#endif
+
 namespace ql {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -37,15 +55,15 @@ template <> struct Rows4<__bf16> {
     }
 };
 
-// KS: K slices per column quad inside the block (its 4 waves = 4 / KS quad sets x KS slices), as in the GEMV.
+// KS: K slices per column quad inside the block (its NW waves = NW / KS quad sets x KS slices), as in the GEMV.
 // NQ: column quads per wave: they share the activation fragments (LDS reads per weight / NQ), the staged rows and the
 // block's fixed costs (staging, barriers, reduction) are spread over NQ x the columns.
-template <typename T, int KS, int RING, int NQ>
-__global__ __launch_bounds__(256) void w4_rows4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+template <typename T, int KS, int RING, int NQ, int NW>
+__global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                        int N, int K, int M, int lda32, const T* __restrict__ bias,
                                                        T* __restrict__ C, int64_t ldc) {
     constexpr bool kF16 = Act<T>::code == QL_DTYPE_F16;
-    constexpr int QW = 4 / KS;                                 // quad sets per block
+    constexpr int QW = NW / KS;                                // quad sets per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int G = K >> 5, cpr = K >> 3;
     const int64_t lda = lda32;
@@ -89,7 +107,7 @@ __global__ __launch_bounds__(256) void w4_rows4_kernel(const T* __restrict__ A, 
     // stage the M rows: 16-byte chunk cc of row m (k = 8 cc .. 8 cc + 7) at m * rowb + 16 cc, its dwords in the order
     // (0, 2, 1, 3): the two dwords an MFMA takes as its A operand are then an aligned register pair of the ds_read_b128.
     // No swizzle: the 16 lanes of a ds_read_b128 phase are 4 blocks (64-byte stride) x 4 rows (16-byte row padding).
-    for (int c = tid; c < M * cpr; c += 256) {
+    for (int c = tid; c < M * cpr; c += NW * 64) {
         const int m = c / cpr, cc = c - m * cpr;
         const u32x4 v = *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + cc * 8);
         *reinterpret_cast<u32x4*>(smem + (int64_t)m * rowb + cc * 16) = u32x4{v[0], v[2], v[1], v[3]};
@@ -112,10 +130,21 @@ __global__ __launch_bounds__(256) void w4_rows4_kernel(const T* __restrict__ A, 
     auto load_a = [&](int it, u32x4 (&av)[4]) {
         const int gc = group_of(it < iters ? it : (iters > 0 ? iters - 1 : 0));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const u32x4*>(arow + gc * 64 + q * 16);
+        for (int q = 0; q < 4; ++q) {
+            if (QL_ROWS4_ABLATE & 2) av[q] = u32x4{(u32)gc, (u32)q, 0x3c003c00u, 0x3c003c00u};
+            else av[q] = *reinterpret_cast<const u32x4*>(arow + gc * 64 + q * 16);
+        }
     };
     auto step = [&](int it, int slot, const u32x4 (&av)[4]) {
         const int g = g_begin + it * 16 + b;
+        if (QL_ROWS4_ABLATE & 1) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[n][q] += u32_as_f32((wr[slot][n][q] ^ av[q][0] ^ av[q][1] ^ av[q][2] ^ av[q][3]) & 0x3fffffffu) + (float)sr[slot][n];
+            return;
+        }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 osum;                                            // bf16: the rows' activation sums, shared by the NQ quads
         if constexpr (!kF16) {
@@ -201,7 +230,7 @@ __global__ __launch_bounds__(256) void w4_rows4_kernel(const T* __restrict__ A, 
             for (int i = 0; i < 4; ++i) red[(((wave * NQ + n) * 4 + (lane >> 4)) * 4 + x) * 4 + i] = acc[n][i];
     }
     __syncthreads();
-    for (int o = tid; o < QW * NQ * 16; o += 256) {
+    for (int o = tid; o < QW * NQ * 16; o += NW * 64) {
         const int qs = o / (NQ * 16), n = (o >> 4) % NQ, j = (o >> 2) & 3, i = o & 3;
         float s = 0.f;
 #pragma unroll
@@ -219,16 +248,16 @@ static int launch_rows4_ks(const void* A, const void* packed, const void* bias, 
     const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
     const u32x4* Wt = (const u32x4*)packed;
     const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
-    constexpr int QW = 4 / KS, RING = 4;
+    constexpr int NW = QL_ROWS4_WAVES, QW = NW / KS, RING = QL_ROWS4_RING;
     const int quads = (int)(Npad / 4), per_block = QW * NQ;
     size_t lds = (size_t)M * (K * 2 + 16);
-    if (lds < (size_t)4 * NQ * 256) lds = (size_t)4 * NQ * 256;                 // the reduction scratch
+    if (lds < (size_t)NW * NQ * 256) lds = (size_t)NW * NQ * 256;               // the reduction scratch
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     }();
     (void)attr_set;
-    w4_rows4_kernel<T, KS, RING, NQ><<<(unsigned)((quads + per_block - 1) / per_block), 256, lds, st>>>(
+    w4_rows4_kernel<T, KS, RING, NQ, NW><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
         (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc);
     return finish_launch();
 }
