@@ -252,7 +252,7 @@ def e2e_generate(torch, device):
                 "position only; torch's fused SDPA measured slower here (0.236 s)"}
     # batched greedy decode (graph-replayed step, 32-token prompts): aggregate tokens per second
     bd = {}
-    for Bd in (8, 32):
+    for Bd in (2, 4, 8, 32):
         try:
             idsb = torch.randint(0, cfg.vocab_size, (Bd, 32), device=device)
             sb = DecodeSession(model, Bd, 128, use_graph=True)

@@ -733,3 +733,27 @@ def test_int4_derived_parts_are_built_lazily_and_equal_the_single_buffer(dt):
     assert layer._tiled is not t_old
     # fp32 has no MFMA path: no part 2 at all
     assert h4.tiled_nbytes(N, K, torch.float32) == 0
+
+
+def test_int4_rows_on_tiled_is_the_librarys_routing():
+    """qlinear_w4g32_rows_on_tiled answers which part of the derived layout a row count needs: part 1 for the GEMV rows
+    and for 2..4 rows in the default arithmetic (4x4x4-MFMA kernel; staged rows up to 64 KB), part 2 above, never for fp32;
+    a part-1-only buffer then really serves exactly the row counts it says."""
+    f16 = torch.float16
+    assert not h4.rows_on_tiled(1, 4096, 4096, f16) and not h4.rows_on_tiled(2, 4096, 13696, f16)
+    assert not h4.rows_on_tiled(4, 4096, 4096, f16)              # 4 rows x 8 KB staged
+    assert h4.rows_on_tiled(3, 4096, 13696, f16)                 # 3 rows x 27 KB: few-row MFMA kernel
+    assert h4.rows_on_tiled(5, 4096, 4096, f16) and h4.rows_on_tiled(4096, 4096, 4096, torch.bfloat16)
+    assert h4.rows_on_tiled(3, 4096, 4096, f16, True)            # strict rounding keeps the few-row kernel
+    assert not h4.rows_on_tiled(64, 4096, 4096, torch.float32)
+    K, N = 1024, 264
+    qw, sc = _rand_w4(K, N, "f16", 77)
+    part1 = h4.repack_w4g32_gemv(qw.to(DEV), sc.to(DEV))
+    for M in (1, 2, 3, 4, 5):
+        x = torch.randn(M, K).half().to(DEV)
+        if h4.rows_on_tiled(M, N, K, f16):
+            with pytest.raises(AssertionError):
+                h4.w4_forward(x, qw.to(DEV), sc.to(DEV), None, part1)
+        else:
+            assert_close(h4.w4_forward(x, qw.to(DEV), sc.to(DEV), None, part1),
+                         O.w4_matmul(t2n(x), qw.numpy(), t2n(sc), None, dtype="f16"), "f16")
