@@ -31,6 +31,19 @@
 
 namespace ql {
 
+// Build-time switches with their measurements (tools/ab, 8192 rows, TFLOP/s for qkv / o / w_in / w_out; product: 936 / 989 / 944 / 1070):
+//   QL_GEMM_PIN=1    MFMA / dequant interleave pinned instruction by instruction (fragment reads, then MFMA + one dword of the
+//                    next B fragment, sched_barrier after each pair): 903 / 962 / 920 / 1037 - the order hipcc finds from the
+//                    sched_group_barrier hints is not what holds the kernel back
+//   QL_GEMM_DEPTH    register ring depth (K steps of global loads in flight): 2: 919 / 989 / 942 / 1010, 4: 965 / 1025 / 989 / 1107
+//                    against 957 / 1015 / 982 / 1089 on the same run (noise level)
+//   QL_GEMM_WPE=2    amdgpu_waves_per_eu(2, 2): 888 / 944 / 924 / 1016 against 922 / 967 / 937 / 1037
+#ifndef QL_GEMM_PIN
+#define QL_GEMM_PIN 0
+#endif
+#ifndef QL_GEMM_DEPTH
+#define QL_GEMM_DEPTH 3
+#endif
 #ifndef QL_GEMM_WPE
 #define QL_GEMM_WPE 0
 #endif
@@ -165,6 +178,34 @@ void w4_packed_gemm_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt
             return MM::dequant(w, k_mask_lo, k_mask_hi, k_magic, sc);
         };
         u32x4 fa[2][MT];
+#if QL_GEMM_PIN
+        if constexpr (NT == 1 && !QL_GEMM_ABLATE) {
+            // exact instruction order, pinned with sched_barrier: the MT fragment reads of the next sub-step, then each MFMA
+            // followed by its slice of the next B fragment's dequant (4 dwords over MT MFMAs)
+            u32x4 fbr[2];
+            read_a(0, fa[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fbr[0][i] = MM::dequant_part(w_cur[0][0], i, k_mask_lo, k_mask_hi, k_magic, s[0]);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                if (sub < 3) read_a(sub + 1, fa[(sub + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][0] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[sub & 1][mt]),
+                                         __builtin_bit_cast(typename MM::frag, fbr[sub & 1]), acc[mt][0]);
+                    if (sub < 3) {
+                        constexpr int PER = MT >= 4 ? 1 : 4 / MT;
+#pragma unroll
+                        for (int i = mt * PER; i < (mt + 1) * PER && i < 4; ++i)
+                            fbr[(sub + 1) & 1][i] = MM::dequant_part(w_cur[0][sub + 1], i, k_mask_lo, k_mask_hi, k_magic, s[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
+#endif
         typename MM::frag fb[2][NT];
         read_a(0, fa[0]);
 #pragma unroll
@@ -274,7 +315,7 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
     constexpr int BN = NW * 32 * NT;
     const int nbx = (N + BN - 1) / BN, nby = (M + 32 * MT - 1) / (32 * MT);
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
-    w4_packed_gemm_kernel<T, MT, NT, NW, 3><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
+    w4_packed_gemm_kernel<T, MT, NT, NW, QL_GEMM_DEPTH><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
         xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5), (const T*)bias, (T*)C, ldc, part);
     const int rc = finish_launch();
     if (rc != 0 || !part) return rc;

@@ -30,6 +30,16 @@ template <> struct Mma<f16> {
         u32x4 r = {as_u32(e0), as_u32(e1), as_u32(e2), as_u32(e3)};
         return __builtin_bit_cast(frag, r);
     }
+    // dword i (0..3) of the same fragment alone: lets a kernel spread the dequant of the next fragment over the MFMAs of
+    // the current one, instruction by instruction
+    static __device__ __forceinline__ u32 dequant_part(u32 w, int i, u32 k_mask_lo, u32 k_mask_hi, u32 k_magic, h2 s2) {
+        const h2 k1032 = {(f16)1032.0f, (f16)1032.0f};
+        const h2 kInv16 = {(f16)0.0625f, (f16)0.0625f};
+        const h2 kM72 = {(f16)-72.0f, (f16)-72.0f};
+        const u32 v = i >= 2 ? w >> 8 : w;
+        if (i & 1) return as_u32((as_h2((v & k_mask_hi) | k_magic) * kInv16 + kM72) * s2);
+        return as_u32((as_h2((v & k_mask_lo) | k_magic) - k1032) * s2);
+    }
     static __device__ __forceinline__ h2 scale_pair(const f16* p, bool valid) {
         const f16 s = valid ? *p : (f16)0.f;
         return h2{s, s};
@@ -55,6 +65,15 @@ template <> struct Mma<__bf16> {
             r[i] = __builtin_bit_cast(u32, p);
         }
         return __builtin_bit_cast(frag, r);
+    }
+    static __device__ __forceinline__ u32 dequant_part(u32 w, int i, u32 k_mask_lo, u32, u32 k_magic, float s) {
+        const float m136s = -136.0f * s;
+        const u32 x = ((w >> (4 * i)) & k_mask_lo) | k_magic;
+        const float lo = __builtin_fmaf(u32_as_f32(x << 16), s, m136s);
+        const float hi = __builtin_fmaf(u32_as_f32(x & 0xFFFF0000u), s, m136s);
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        const bf2 p = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(u32, p);
     }
     static __device__ __forceinline__ float scale_pair(const __bf16* p, bool valid) { return valid ? (float)*p : 0.f; }
     static constexpr u32 kMagic = 0x43004300u;
