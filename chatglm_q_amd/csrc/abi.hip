@@ -209,6 +209,12 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
     if (!packed) return QL_ERR_NULL_POINTER;
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
     if (N <= 0 || K <= 0 || K % 32 != 0) return QL_ERR_BAD_SHAPE;
+    if (w4_rows4_serves(dtype, M, N, K, lda, false)) {          // 2..4 rows: part 1 of the gate-interleaved copy, 4x4x4 MFMA
+        if (!A || !C) return QL_ERR_NULL_POINTER;
+        if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || N % 4 != 0 || lda < K || ldc < N / 2) return QL_ERR_BAD_SHAPE;
+        if (!aligned(packed, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
+        return w4_rows4_gated(dtype, A, packed, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+    }
     return qlinear_w4g32_fwd_tiled_gated(A, (const char*)packed + w4_layout(N, K, 2).off_wm, bias, C, M, N, K, lda, ldc, dtype,
                                          stream);
 }

@@ -87,7 +87,9 @@ int w4_fewrow(int dtype, const void* A, const void* tiled, const void* bias, voi
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
 bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict);   // w4_packed.hip: the routing rule
 int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-             int64_t lda, int64_t ldc, hipStream_t st);
+             int64_t lda, int64_t ldc, hipStream_t st, bool gate = false);
+int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                   int64_t lda, int64_t ldc, hipStream_t st);                                   // w4_packed.hip: picks the K split
 
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,

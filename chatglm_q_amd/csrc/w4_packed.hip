@@ -923,6 +923,12 @@ bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bo
     return !strict && M >= r4_min && M <= r4_max && (M <= 2 || M * K * 2 <= 64 * 1024) && w4_rows4_supported(dtype, M, N, K, lda);
 }
 
+int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                   int64_t lda, int64_t ldc, hipStream_t st) {
+    const int64_t Npad = (N + 3) & ~(int64_t)3;
+    return w4_rows4(dtype, choose_ksplit(Npad / 4, K / 32, (int)M), A, packed, bias, C, M, N, K, lda, ldc, st, true);
+}
+
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return M > forced;

@@ -58,10 +58,14 @@ template <> struct Rows4<__bf16> {
 // KS: K slices per column quad inside the block (its NW waves = NW / KS quad sets x KS slices), as in the GEMV.
 // NQ: column quads per wave: they share the activation fragments (LDS reads per weight / NQ), the staged rows and the
 // block's fixed costs (staging, barriers, reduction) are spread over NQ x the columns.
-template <typename T, int KS, int RING, int NQ, int NW>
+// MR: groups of 4 rows per weight fragment (only 1 is instantiated, see w4_rows4_supported).
+// gate (run time): the packed columns come in quads (h_2t, h_2t+1, gate_2t, gate_2t+1) - the gate-interleaved copy of a
+// first MLP projection - and C gets N / 2 columns, C[m, 2t+i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias,
+// rounded): chatglm_q/model.py:200-201, the rounding sequence of the GEMV's and the few-row kernel's gate epilogues.
+template <typename T, int KS, int RING, int NQ, int NW, int MR>
 __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
-                                                       int N, int K, int M, int lda32, const T* __restrict__ bias,
-                                                       T* __restrict__ C, int64_t ldc) {
+                                                           int N, int K, int M, int lda32, const T* __restrict__ bias,
+                                                           T* __restrict__ C, int64_t ldc, int gate) {
     constexpr bool kF16 = Act<T>::code == QL_DTYPE_F16;
     constexpr int QW = NW / KS;                                // quad sets per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
     }
     __syncthreads();
 
-    const char* arow = smem + (int64_t)(x < M ? x : M - 1) * rowb;   // rows past M repeat the last one (their sums are dropped)
+    const char* arow[MR];                                      // rows past M repeat the last one (their sums are dropped)
+#pragma unroll
+    for (int r = 0; r < MR; ++r) arow[r] = smem + (int64_t)(4 * r + x < M ? 4 * r + x : M - 1) * rowb;
     u32 k_lo, k_hi, k_magic;
     asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_lo));
     asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_hi));
@@ -122,43 +128,49 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
     const h2 k1032 = {(f16)1032.0f, (f16)1032.0f}, kInv16 = {(f16)0.0625f, (f16)0.0625f}, kM72 = {(f16)-72.0f, (f16)-72.0f};
     const u32 kOnes = 0x3F803F80u;                             // bf16 (1, 1)
 
-    f32x4 acc[NQ];
+    f32x4 acc[NQ][MR];
 #pragma unroll
-    for (int n = 0; n < NQ; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the 4 activation chunks of a step are requested one step AHEAD (two register sets, alternating): issued in front of
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int r = 0; r < MR; ++r) acc[n][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the activation chunks of a step are requested one step AHEAD (two register sets, alternating): issued in front of
     // each MFMA they put a full LDS round trip on every one of them
-    auto load_a = [&](int it, u32x4 (&av)[4]) {
+    auto load_a = [&](int it, u32x4 (&av)[MR][4]) {
         const int gc = group_of(it < iters ? it : (iters > 0 ? iters - 1 : 0));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (QL_ROWS4_ABLATE & 2) av[q] = u32x4{(u32)gc, (u32)q, 0x3c003c00u, 0x3c003c00u};
-            else av[q] = *reinterpret_cast<const u32x4*>(arow + gc * 64 + q * 16);
-        }
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (QL_ROWS4_ABLATE & 2) av[r][q] = u32x4{(u32)gc, (u32)q, 0x3c003c00u, 0x3c003c00u};
+                else av[r][q] = *reinterpret_cast<const u32x4*>(arow[r] + gc * 64 + q * 16);
+            }
     };
-    auto step = [&](int it, int slot, const u32x4 (&av)[4]) {
+    auto step = [&](int it, int slot, const u32x4 (&av)[MR][4]) {
         const int g = g_begin + it * 16 + b;
         if (QL_ROWS4_ABLATE & 1) {
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    acc[n][q] += u32_as_f32((wr[slot][n][q] ^ av[q][0] ^ av[q][1] ^ av[q][2] ^ av[q][3]) & 0x3fffffffu) + (float)sr[slot][n];
+                    acc[n][0][q] += u32_as_f32((wr[slot][n][q] ^ av[0][q][0] ^ av[0][q][1] ^ av[0][q][2] ^ av[0][q][3]) & 0x3fffffffu) + (float)sr[slot][n];
             return;
         }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 osum;                                            // bf16: the rows' activation sums, shared by the NQ quads
+        f32x4 osum[MR];                                        // bf16: the rows' activation sums, shared by the NQ quads
         if constexpr (!kF16) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                osum = Rows4<T>::mma(av[q][0], av[q][1], kOnes, kOnes, q == 0 ? zero : osum);
-                osum = Rows4<T>::mma(av[q][2], av[q][3], kOnes, kOnes, osum);
-            }
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    osum[r] = Rows4<T>::mma(av[r][q][0], av[r][q][1], kOnes, kOnes, q == 0 ? zero : osum[r]);
+                    osum[r] = Rows4<T>::mma(av[r][q][2], av[r][q][3], kOnes, kOnes, osum[r]);
+                }
         }
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             const u32x4 wv = wr[slot][n];
             const float sc = g < g_end ? (float)sr[slot][n] : 0.f;       // lanes past the slice contribute 0
-            f32x4 e, o;
+            f32x4 e[MR], o[MR];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // word q holds k = 8 q .. 8 q + 7 at nibble positions p(k) = (k >> 1) + 4 (k & 1)  [w4_repack_kernel]:
@@ -166,33 +178,37 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
                 // with dwords 0 and 2 of the activation chunk (staged as registers 0, 1); the 0x00F000F0 masks give k (2, 3)
                 // and (6, 7): dwords 1 and 3 (registers 2, 3)
                 const u32 w = wv[q], w8 = w >> 8;
+                u32 b0, b1, b2, b3;
                 if constexpr (kF16) {
-                    const u32 b0 = as_u32(as_h2((w & k_lo) | k_magic) - k1032);
-                    const u32 b1 = as_u32(as_h2((w8 & k_lo) | k_magic) - k1032);
-                    const u32 b2 = as_u32(as_h2((w & k_hi) | k_magic) * kInv16 + kM72);
-                    const u32 b3 = as_u32(as_h2((w8 & k_hi) | k_magic) * kInv16 + kM72);
-                    e = Rows4<T>::mma(av[q][0], av[q][1], b0, b1, q == 0 ? zero : e);
-                    o = Rows4<T>::mma(av[q][2], av[q][3], b2, b3, q == 0 ? zero : o);
+                    b0 = as_u32(as_h2((w & k_lo) | k_magic) - k1032);
+                    b1 = as_u32(as_h2((w8 & k_lo) | k_magic) - k1032);
+                    b2 = as_u32(as_h2((w & k_hi) | k_magic) * kInv16 + kM72);
+                    b3 = as_u32(as_h2((w8 & k_hi) | k_magic) * kInv16 + kM72);
                 } else {
                     // bf16: 128 + n as spliced
-                    const u32 b0 = (w & k_lo) | k_magic, b1 = (w8 & k_lo) | k_magic;
-                    const u32 b2 = ((w >> 4) & k_lo) | k_magic, b3 = ((w8 >> 4) & k_lo) | k_magic;
-                    e = Rows4<T>::mma(av[q][0], av[q][1], b0, b1, q == 0 ? zero : e);
-                    o = Rows4<T>::mma(av[q][2], av[q][3], b2, b3, q == 0 ? zero : o);
+                    b0 = (w & k_lo) | k_magic, b1 = (w8 & k_lo) | k_magic;
+                    b2 = ((w >> 4) & k_lo) | k_magic, b3 = ((w8 >> 4) & k_lo) | k_magic;
+                }
+#pragma unroll
+                for (int r = 0; r < MR; ++r) {
+                    e[r] = Rows4<T>::mma(av[r][q][0], av[r][q][1], b0, b1, q == 0 ? zero : e[r]);
+                    o[r] = Rows4<T>::mma(av[r][q][2], av[r][q][3], b2, b3, q == 0 ? zero : o[r]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float grp = kF16 ? e[i] + o[i] : __builtin_fmaf(-136.0f, osum[i], e[i] + o[i]);
-                acc[n][i] = __builtin_fmaf(sc, grp, acc[n][i]);
-            }
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float grp = kF16 ? e[r][i] + o[r][i] : __builtin_fmaf(-136.0f, osum[r][i], e[r][i] + o[r][i]);
+                    acc[n][r][i] = __builtin_fmaf(sc, grp, acc[n][r][i]);
+                }
         }
     };
 
     // ring walk: slot r serves steps r, r + RING, ...; the refill is issued right behind the step that freed the slot.
     // Whole rounds only contain unconditional loads (hipcc then counts its vmcnt waits); the last round is peeled.
     static_assert(RING % 2 == 0, "the activation register sets alternate with the step parity");
-    u32x4 av[2][4];
+    u32x4 av[2][MR][4];
     load_a(0, av[0]);
     int it = 0;
     for (; it + 2 * RING <= iters; it += RING) {
@@ -217,77 +233,97 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[n][i] += dpp_move<0x128>(acc[n][i]);            // row_ror:8
-            acc[n][i] += dpp_move<0x124>(acc[n][i]);            // row_ror:4
-        }
+        for (int r = 0; r < MR; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[n][r][i] += dpp_move<0x128>(acc[n][r][i]);  // row_ror:8
+                acc[n][r][i] += dpp_move<0x124>(acc[n][r][i]);  // row_ror:4
+            }
     __syncthreads();                                            // every wave is done with the staged rows
-    float* red = reinterpret_cast<float*>(smem);               // [wave][quad of the wave][16-lane row][x][i]
+    float* red = reinterpret_cast<float*>(smem);               // [wave][quad of the wave][row group][16-lane row][x][i]
     if ((lane & 12) == 0) {
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[(((wave * NQ + n) * 4 + (lane >> 4)) * 4 + x) * 4 + i] = acc[n][i];
+            for (int r = 0; r < MR; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[((((wave * NQ + n) * MR + r) * 4 + (lane >> 4)) * 4 + x) * 4 + i] = acc[n][r][i];
     }
     __syncthreads();
-    for (int o = tid; o < QW * NQ * 16; o += NW * 64) {
-        const int qs = o / (NQ * 16), n = (o >> 4) % NQ, j = (o >> 2) & 3, i = o & 3;
+    auto total = [&](int qs, int n, int r, int j, int i) {      // sum over the K slices and the four 16-lane rows
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KS; ++k)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s += red[((((qs * KS + k) * NQ + n) * 4 + r) * 4 + j) * 4 + i];
-        const int col = ((blockIdx.x * QW + qs) * NQ + n) * 4 + j;
-        if (i < M && col < N) store_out<T>(C + (int64_t)i * ldc + col, s, bias ? bias + col : nullptr);
+            for (int l = 0; l < 4; ++l) s += red[(((((qs * KS + k) * NQ + n) * MR + r) * 4 + l) * 4 + j) * 4 + i];
+        return s;
+    };
+    for (int o = tid; o < QW * NQ * MR * 16; o += NW * 64) {
+        const int i = o & 3, j = (o >> 2) & 3, r = (o >> 4) % MR, n = (o / (16 * MR)) % NQ, qs = o / (16 * MR * NQ);
+        const int m = 4 * r + i, quad = (blockIdx.x * QW + qs) * NQ + n, col = quad * 4 + j;
+        if (m >= M || col >= N) continue;
+        if (!gate) {
+            store_out<T>(C + (int64_t)m * ldc + col, total(qs, n, r, j, i), bias ? bias + col : nullptr);
+        } else if (j < 2) {
+            float yh = Act<T>::round(total(qs, n, r, j, i)), yg = Act<T>::round(total(qs, n, r, j + 2, i));
+            if (bias) {
+                yh = Act<T>::round(yh + Act<T>::load(bias + col));
+                yg = Act<T>::round(yg + Act<T>::load(bias + col + 2));
+            }
+            Act<T>::store(C + (int64_t)m * ldc + quad * 2 + j, Act<T>::round(Act<T>::round(yh / (1.0f + __expf(-yh))) * yg));
+        }
     }
 }
 
-template <typename T, int KS, int NQ>
+template <typename T, int KS, int NQ, int MR>
 static int launch_rows4_ks(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                           int64_t ldc, hipStream_t st) {
+                           int64_t ldc, bool gate, hipStream_t st) {
     const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
     const u32x4* Wt = (const u32x4*)packed;
     const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
     constexpr int NW = QL_ROWS4_WAVES, QW = NW / KS, RING = QL_ROWS4_RING;
     const int quads = (int)(Npad / 4), per_block = QW * NQ;
     size_t lds = (size_t)M * (K * 2 + 16);
-    if (lds < (size_t)NW * NQ * 256) lds = (size_t)NW * NQ * 256;               // the reduction scratch
+    if (lds < (size_t)NW * NQ * MR * 256) lds = (size_t)NW * NQ * MR * 256;     // the reduction scratch
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ, NW>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ, NW, MR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     }();
     (void)attr_set;
-    w4_rows4_kernel<T, KS, RING, NQ, NW><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
-        (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc);
+    w4_rows4_kernel<T, KS, RING, NQ, NW, MR><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
+        (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc, gate ? 1 : 0);
     return finish_launch();
 }
 
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda) {
     // the M staged rows (+ 16 bytes each) live in LDS; one block per CU is the floor for the widest layer
+    // (two row groups per weight fragment - MR = 2, 5..8 rows - were built and measured: qkv 7.6 - 8.1 us against the few-row
+    // kernel's 8.9 - 9.3, but w_in 20.9 - 22.1 against 19.2 - 19.3 and batch-8 decode 1.91 against 1.78 ms per step: not instantiated)
     return (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && M >= 1 && M <= 4 && K % 32 == 0 && K >= 32 && lda <= 0x7fffffff &&
            (size_t)M * (K * 2 + 16) <= 150 * 1024;
 }
 
-// ks: K slices per column quad (1, 2 or 4: w4_packed.hip's choose_ksplit)
+// ks: K slices per column quad (1, 2 or 4: w4_packed.hip's choose_ksplit); gate: SiLU * gate epilogue on a gate-interleaved
+// copy (N % 4 == 0, C gets N / 2 columns)
 int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-             int64_t lda, int64_t ldc, hipStream_t st) {
-#define QL_R4(T_)                                                                                                       \
-    if (nq == 2) switch (ks) {                                                                                          \
-    case 4: return launch_rows4_ks<T_, 4, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
-    case 2: return launch_rows4_ks<T_, 2, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
-    default: return launch_rows4_ks<T_, 1, 2>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                \
-    }                                                                                                                   \
+             int64_t lda, int64_t ldc, hipStream_t st, bool gate) {
+#define QL_R4K(T_, NQ_, MR_)                                                                                            \
     switch (ks) {                                                                                                       \
-    case 4: return launch_rows4_ks<T_, 4, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
-    case 2: return launch_rows4_ks<T_, 2, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                 \
-    default: return launch_rows4_ks<T_, 1, 1>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);                \
+    case 4: return launch_rows4_ks<T_, 4, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);    \
+    case 2: return launch_rows4_ks<T_, 2, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);    \
+    default: return launch_rows4_ks<T_, 1, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);   \
     }
+#define QL_R4(T_)                                                                                                       \
+    if (nq == 2) { QL_R4K(T_, 2, 1) }                                                                                   \
+    QL_R4K(T_, 1, 1)
     // one quad per wave; two (QLINEAR_ROWS4_NQ=2: shared activation fragments, half the blocks) measured slower on every
     // layer shape but w_out at one row (2 rows: 7.2 / 5.8 / 18.4 / 13.3 us against 6.5 / 5.8 / 17.1 / 11.8)
     static const int nq = [] { const char* e = getenv("QLINEAR_ROWS4_NQ"); return e && atoi(e) == 2 ? 2 : 1; }();
+    if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
     if (dtype == QL_DTYPE_F16) { QL_R4(f16) }
     if (dtype == QL_DTYPE_BF16) { QL_R4(__bf16) }
 #undef QL_R4
+#undef QL_R4K
     return QL_ERR_BAD_DTYPE;
 }
 

@@ -346,27 +346,34 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     return c
 
 
-def w4_forward_gated(a: Tensor, gated_tiled: Tensor, n_out: int, bias: Tensor | None) -> Tensor | None:
-    """Few rows (3..32) through a gate-interleaved first MLP projection with SiLU * gate in the kernel's epilogue
-    (``qlinear_w4g32_fwd_tiled_gated``): (..., K) -> (..., n_out / 2).  ``gated_tiled``: part 2 of the gate-interleaved
-    copy (``DynamicQuantizeLinear.gated_tiled``).  None when the library does not serve the shape that way (the caller
-    then runs the projection and ``silu_mul`` separately)."""
+def w4_forward_gated(a: Tensor, gated: Tensor, n_out: int, bias: Tensor | None, part1: bool = False) -> Tensor | None:
+    """Few rows through a gate-interleaved first MLP projection with SiLU * gate in the kernel's epilogue: (..., K) ->
+    (..., n_out / 2).  ``gated``: part 2 of the gate-interleaved copy (``DynamicQuantizeLinear.gated_tiled``; 3..32 rows,
+    ``qlinear_w4g32_fwd_tiled_gated``) or, with ``part1``, its part 1 (``gated_packed``; the row counts for which
+    ``rows_on_tiled`` is False, ``qlinear_w4g32_fwd_packed_gated`` -> the 4x4x4-MFMA kernel).  None when the library does
+    not serve the shape that way (the caller then runs the projection and ``silu_mul`` separately)."""
     lib = _lib.get_lib()
     K = a.shape[-1]
     _check_row_operands("w4_forward_gated", a, K, bias=bias)
-    if gated_tiled.device != a.device or gated_tiled.numel() < tiled_nbytes(n_out, K, a.dtype):
-        raise AssertionError("w4_forward_gated: tile-major buffer on another device or too small for (n_out, K)")
     a2 = a.reshape(-1, K)
     if a2.stride(1) != 1 or a2.stride(0) % 8:
         a2 = a2.contiguous()
-    c = torch.empty((a2.shape[0], n_out // 2), device=a.device, dtype=a.dtype)
+    M = a2.shape[0]
+    if part1:
+        if rows_on_tiled(M, n_out, K, a.dtype) or n_out % 4:
+            return None
+        need, entry = gemv_nbytes(n_out, K, a.dtype), "qlinear_w4g32_fwd_packed_gated"
+    else:
+        need, entry = tiled_nbytes(n_out, K, a.dtype), "qlinear_w4g32_fwd_tiled_gated"
+    if gated.device != a.device or gated.numel() < need:
+        raise AssertionError("w4_forward_gated: derived buffer on another device or too small for (n_out, K)")
+    c = torch.empty((M, n_out // 2), device=a.device, dtype=a.dtype)
     with torch.cuda.device(a.device):
-        st = lib.qlinear_w4g32_fwd_tiled_gated(a2.data_ptr(), gated_tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(),
-                                               a2.shape[0], n_out, K, a2.stride(0), n_out // 2,
-                                               _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+        st = getattr(lib, entry)(a2.data_ptr(), gated.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out, K, a2.stride(0),
+                                 n_out // 2, _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
     if st == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(st, "qlinear_w4g32_fwd_tiled_gated")
+    _lib.check(st, entry)
     return c.reshape(*a.shape[:-1], n_out // 2)
 
 

@@ -265,7 +265,7 @@ class ChatGLM2Model(nn.Module):
                                      cache.k[i], cache.v[i], H, G, D)
                 att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
             h, x = F_.add_rmsnorm(h, layer.attn.o_proj(att), layer.ffn_ln.weight, layer.ffn_ln.eps)
-            y = self._gated_w_in(layer.ffn, x) if S == 1 and 3 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
+            y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
             if y is None:
                 y = F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim)
             delta = layer.ffn.w_out(y)
@@ -276,14 +276,19 @@ class ChatGLM2Model(nn.Module):
 
     @staticmethod
     def _gated_w_in(ffn, x: Tensor) -> Optional[Tensor]:
-        """Batched decode (3..32 rows): w_in on its gate-interleaved int4g32 layout with SiLU * gate in the few-row
-        kernel's epilogue - one launch instead of two; None when layer / shape are not served that way."""
+        """Batched decode (2..32 rows): w_in on its gate-interleaved int4g32 layout with SiLU * gate in the epilogue of the
+        4x4x4-MFMA kernel (few rows, part 1 of that copy) or of the few-row kernel (part 2) - one launch instead of two; None
+        when layer / shape are not served that way."""
         from .int4 import hip_ops as H4
         from .int4.qlinear import DynamicQuantizeLinear as Q4
         w_in = ffn.w_in
         if not (isinstance(w_in, Q4) and x.dtype in (torch.float16, torch.bfloat16) and w_in._packed_supported()
                 and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0):
             return None
+        rows = x.numel() // x.shape[-1]
+        if not H4.rows_on_tiled(rows, w_in.out_features, w_in.in_features, x.dtype):
+            packed, bias = w_in.gated_packed(ffn.hidden_dim)
+            return H4.w4_forward_gated(x, packed, w_in.out_features, bias, part1=True)
         tiled, bias = w_in.gated_tiled(ffn.hidden_dim)
         return H4.w4_forward_gated(x, tiled, w_in.out_features, bias)
 

@@ -141,7 +141,7 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * The host module (chatglm_q_amd/int4/qlinear.py) builds part 2 on the first forward with >= 3 rows. */
 /* 1 when qlinear_w4g32_fwd_packed serves this call from part 2 (a caller that keeps the parts apart then calls
  * qlinear_w4g32_fwd_tiled), 0 when part 1 does: one or two rows (GEMV), 2..4 rows in the default arithmetic on the 4x4x4
- * matrix instruction (w4_rows4.hip), fp32 at any row count. */
+ * matrix instruction while the staged rows stay within 64 KB (w4_rows4.hip), fp32 at any row count. */
 int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags);
 size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype);
@@ -193,14 +193,16 @@ int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t 
 int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Few rows (batched decode: 3..32) through a first MLP projection with the SiLU * gate EPILOGUE: `packed` holds the
+/* Few rows (batched decode: 2..32) through a first MLP projection with the SiLU * gate EPILOGUE: `packed` holds the
  * gate-interleaved column order (h_2t, h_2t+1, gate_2t, gate_2t+1), C gets N / 2 columns,
  * C[m, 2t+i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias, rounded) - chatglm_q/model.py:200-201.
  * QL_ERR_UNSUPPORTED when the shape is not served by the few-row kernel without K slabs (N % 32 != 0, narrow
  * matrices, other row counts): run qlinear_w4g32_fwd_packed + qlinear_silu_mul instead.  fp16 / bf16. */
 int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                    int64_t lda, int64_t ldc, int dtype, void* stream);
-/* the same on part 2 alone (qlinear_w4g32_tile of the gate-interleaved part 1) */
+/* Row counts for which qlinear_w4g32_rows_on_tiled is 0 (2..4 rows while the staged rows stay within 64 KB) are served from part 1
+ * by the 4x4x4-MFMA kernel - `packed` may then be a part-1-only buffer (qlinear_w4g32_repack_gemv of the permuted weights).
+ * The same on part 2 alone (qlinear_w4g32_tile of the gate-interleaved part 1): */
 int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                   int64_t lda, int64_t ldc, int dtype, void* stream);
 

@@ -214,6 +214,34 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
     assert O.rel_l2(t2n(got_split), t2n(want)) < {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_rows4_gate_epilogue_equals_separate_ops(M, bias, dtype):
+    """SiLU * gate in the epilogue of the 4x4x4-MFMA kernel (2..4 rows, part 1 of the gate-interleaved copy,
+    qlinear_w4g32_fwd_packed_gated) against the same kernel without the epilogue followed by silu_mul: same sums, same
+    rounding sequence - bit for bit."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(70 + M)
+    for K, hidden in ((4096, 13696), (256, 96)):
+        layer = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+        layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        if bias:
+            layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+        x = torch.randn(M, 1, K, device=DEV, generator=g).to(dtype)
+        assert not H4.rows_on_tiled(M, 2 * hidden, K, dtype)
+        gp, gb = layer.gated_packed(hidden)
+        got = H4.w4_forward_gated(x, gp, 2 * hidden, gb, part1=True)
+        with torch.no_grad():
+            want = F_.silu_mul(layer(x), hidden)               # the module serves these row counts with the same kernel
+        assert got is not None and got.shape == (M, 1, hidden)
+        assert torch.equal(got, want)
+        assert layer._gated_tiled is None and layer._tiled is None   # part 2 of neither copy was needed
+
+
 @pytest.mark.parametrize("geom", [(2, 32, 2, 128, 64), (1, 4, 1, 32, 40)])
 def test_rotary_entry_points_stay_inside_table_and_cache(geom):
     """No table length crosses the ABI: positions past the cache are clamped to `capacity` (the last row the table must

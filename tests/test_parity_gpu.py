@@ -155,6 +155,8 @@ W4_SHAPES = [
     (2, 96, 20, "bf16", False),         # ... 3 groups (13 of the 16 blocks idle), ragged N
     (4, 2080, 36, "f16", True),         # ... 65 groups: a ragged last step; N % 8 != 0
     (3, 13696, 256, "f16", False),      # ... 3 rows of 13696: staged rows too large -> few-row MFMA kernel
+    (7, 4096, 520, "bf16", True),       # 5..8 rows: few-row MFMA kernel; ragged N
+    (6, 1056, 64, "f16", False),        # ... 33 groups
     (2, 64, 36, "f16", True),           # N % 8 != 0 -> generic kernel / packed padding
     (3, 96, 8, "f32", False),
 ]
@@ -749,7 +751,7 @@ def test_int4_rows_on_tiled_is_the_librarys_routing():
     K, N = 1024, 264
     qw, sc = _rand_w4(K, N, "f16", 77)
     part1 = h4.repack_w4g32_gemv(qw.to(DEV), sc.to(DEV))
-    for M in (1, 2, 3, 4, 5):
+    for M in (1, 2, 3, 4, 5, 8, 9):
         x = torch.randn(M, K).half().to(DEV)
         if h4.rows_on_tiled(M, N, K, f16):
             with pytest.raises(AssertionError):
