@@ -219,6 +219,23 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
                                          stream);
 }
 
+size_t qlinear_w4g32_mlp_pair_workspace_bytes(void) { return w4_mlp_pair_workspace_bytes(); }
+
+int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                           const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, const void* residual, void* mid,
+                           void* Out, void* workspace, int dtype, void* stream) {
+    if (!X || !ln_weight || !packed_in || !packed_out || !residual || !mid || !Out || !workspace) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N_in) || !fits_i32(N_out) || !fits_i32(K) || N_in <= 0 || N_out <= 0 || K <= 0 || K % 32 != 0 || N_in % 4 != 0 ||
+        (N_in / 2) % 32 != 0)
+        return QL_ERR_BAD_SHAPE;
+    if (!aligned(X, 16) || !aligned(ln_weight, 16) || !aligned(packed_in, 16) || !aligned(packed_out, 16) || !aligned(mid, 16) ||
+        !aligned(workspace, 64))
+        return QL_ERR_MISALIGNED;
+    return w4_mlp_pair(dtype, X, ln_weight, eps, packed_in, bias_in, N_in, K, packed_out, bias_out, N_out, N_in / 2, residual, mid, Out,
+                       workspace, (hipStream_t)stream);
+}
+
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
                                       int64_t N, int64_t K, int dtype, void* stream) {
     if (!A || !packed || !C || !residual) return QL_ERR_NULL_POINTER;

@@ -83,6 +83,12 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int w4_fewrow(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate = false);   // tiled: part 2
 
+// w4_packed.hip: the two MLP projections of a one-row decode step in one launch (experiment); ws: w4_mlp_pair_workspace_bytes() zeroed once
+size_t w4_mlp_pair_workspace_bytes();
+int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, const void* packed_a, const void* bias_a, int64_t Na,
+                int64_t Ka, const void* packed_b, const void* bias_b, int64_t Nb, int64_t Kb, const void* resid, void* mid,
+                void* out, void* ws, hipStream_t st);
+
 // w4_rows4.hip (1..4 rows, fp16 / bf16, exact-dequant arithmetic): 4x4x4 MFMA on part 1 of the derived layout; ks = K slices per quad
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
 bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict);   // w4_packed.hip: the routing rule

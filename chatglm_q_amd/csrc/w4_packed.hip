@@ -160,7 +160,7 @@ struct PackedTile16 {
 #ifdef QL_SPAN_PROBE
 constexpr int kSpanWaves = 1 << 16;                       // one (start, end) slot per wave: plain stores, no contention
 __device__ unsigned long long ql_span_slots[2 * kSpanWaves];
-#define QL_SPAN_SLOT() (((int)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6)) & (kSpanWaves - 1))
+#define QL_SPAN_SLOT() (((int)(by * gridDim.x + bx) * 4 + (int)(threadIdx.x >> 6)) & (kSpanWaves - 1))
 #define QL_SPAN_START() do { if ((threadIdx.x & 63) == 0) ql_span_slots[2 * QL_SPAN_SLOT()] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #define QL_SPAN_END() do { if ((threadIdx.x & 63) == 0) ql_span_slots[2 * QL_SPAN_SLOT() + 1] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -168,13 +168,30 @@ __device__ unsigned long long ql_span_slots[2 * kSpanWaves];
 #define QL_SPAN_END() do { } while (0)
 #endif
 
-template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
-__global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
-                                                                const T* __restrict__ Sp, const void* pro_delta,
-                                                                const void* pro_ln_weight, int N, int K, int M, int lda32,
-                                                                const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
-                                                                void* pro_hout, float pro_eps, int pro_gate,
-                                                                const T* __restrict__ resid = nullptr) {
+// The kernel body is a device function taking its block coordinates as arguments, so that ONE launch can run two
+// projections (w4_mlp_pair_kernel below: blocks [0, nA) = the first, the rest = the second, chained through counters).
+// CHAIN: 0 none; 1 = this projection's outputs feed a chained consumer in the same launch (outputs stored, block arrives on
+// chain->cnt); 2 = this projection's activation row is produced in the same launch (weight tiles requested first, then the
+// block waits for the producers, then stages the row).
+#ifndef QL_CHAIN_ABLATE
+#define QL_CHAIN_ABLATE 0         // timing experiments (results wrong): 1 = consumers do not wait, 2 = no acquire fence
+#endif
+struct ChainArgs {
+    unsigned* cnt;        // 64 slot counters, 64 bytes apart (cnt[16 * s]); done counter cnt[16 * 64]; error word cnt[16 * 65]; top counter cnt[16 * 66]
+    int producers;        // blocks of the producing projection
+    int consumers;        // blocks of the consuming projection (the last one to pass its wait resets the counters)
+};
+constexpr int kChainSlots = 64;
+constexpr int kChainWords = 16 * (kChainSlots + 3);
+
+template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE, int CHAIN = 0>   // ACH: 16-byte A chunks staged per thread; 0 = A from global
+__device__ __forceinline__ void w4_packed_gemv_16_body(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+                                                       const T* __restrict__ Sp, const void* pro_delta,
+                                                       const void* pro_ln_weight, int N, int K, int M, int lda32,
+                                                       const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                       void* pro_hout, float pro_eps, int pro_gate,
+                                                       const T* __restrict__ resid, const int bx, const int by,
+                                                       const ChainArgs chain = ChainArgs{nullptr, 0, 0}) {
     // resid (one row, nullable): the residual stream the output is added to in the epilogue - out = round(y + resid),
     // y = rounded sum (+ bias) - so that the NEXT projection's RMSNorm prologue needs no delta operand
     // (chatglm_q/model.py:243,245: hidden = hidden + sublayer(...)).
@@ -192,10 +209,10 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QL_SPAN_START();
     const int ks = wave % KS;
-    const int t_raw = blockIdx.x * QW + wave / KS;
+    const int t_raw = bx * QW + wave / KS;
     const bool wave_active = t_raw * 4 < N;
     const int t = wave_active ? t_raw : 0;     // inactive waves shadow quad 0 (they must reach the barriers)
-    const int m0 = blockIdx.y * MB;
+    const int m0 = by * MB;
     const int gs = (G + KS - 1) / KS;          // groups per K slice
     const int g_begin = ks * gs;
     const int g_end = min(G, g_begin + gs);
@@ -217,20 +234,23 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     u32x4 areg[A_LDS ? ACH : 1];
     constexpr bool kNorm = PRO == PRO_ADDNORM || PRO == PRO_NORM;
     u32x4 xreg[PRO != PRO_NONE ? ACH : 1], yreg[PRO == PRO_ADDNORM ? ACH : 1];   // prologue operands
-    if constexpr (A_LDS && VAR != 4 && VAR != 5) {
+    auto issue_staging_loads = [&] {
+        if constexpr (A_LDS && VAR != 4 && VAR != 5) {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) {
-            // unconditional (clamped) load: a load under a per-element condition makes hipcc branch
-            // around it and drain the queue (vmcnt(0)) per element
-            const int c = min(tid + i * 256, MB * cpr - 1);
-            const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
-            areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
-            if constexpr (PRO == PRO_SILU) xreg[i] = *reinterpret_cast<const u32x4*>(arow[0] + K + cc * 8);
-            if constexpr (kNorm) xreg[i] = *reinterpret_cast<const u32x4*>((const T*)pro.ln_weight + cc * 8);
-            if constexpr (PRO == PRO_ADDNORM)
-                yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const T*)pro.delta : arow[0]) + cc * 8);
+            for (int i = 0; i < ACH; ++i) {
+                // unconditional (clamped) load: a load under a per-element condition makes hipcc branch
+                // around it and drain the queue (vmcnt(0)) per element
+                const int c = min(tid + i * 256, MB * cpr - 1);
+                const int m = MB == 1 ? 0 : c / cpr, cc = c - m * cpr;
+                areg[i] = *reinterpret_cast<const u32x4*>(arow[m] + cc * 8);
+                if constexpr (PRO == PRO_SILU) xreg[i] = *reinterpret_cast<const u32x4*>(arow[0] + K + cc * 8);
+                if constexpr (kNorm) xreg[i] = *reinterpret_cast<const u32x4*>((const T*)pro.ln_weight + cc * 8);
+                if constexpr (PRO == PRO_ADDNORM)
+                    yreg[i] = *reinterpret_cast<const u32x4*>((pro.delta ? (const T*)pro.delta : arow[0]) + cc * 8);
+            }
         }
-    }
+    };
+    if constexpr (CHAIN != 2) issue_staging_loads();
 
     const u32x4* wbase = Wt + (int64_t)t * 4 * G;
     const T* sbase = Sp + (int64_t)t * G * 4;
@@ -270,6 +290,37 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     }
 
 
+    if constexpr (CHAIN == 2) {
+        // The activation row is being produced by lower-numbered blocks of this launch (dispatched before this one, so they
+        // make progress whatever this block does).  This block's weight tiles are already in flight; wave 0 polls the 64
+        // arrival counters (one per lane, relaxed agent-scope loads, s_sleep between polls, bounded), ONE acquire, then the
+        // block stages the row.  The last consumer block to get here resets the counters for the next launch.
+        if (wave == 0) {
+            // ONE word is polled (by one lane): the top counter, which the last arriver of each of the 64 slot counters
+            // increments (1 024 consumer blocks polling 64 words each slowed the producers down 5x: 105 us for the pair)
+            const unsigned want = (unsigned)(chain.producers < kChainSlots ? chain.producers : kChainSlots);
+            unsigned spins = 0;
+            for (; !(QL_CHAIN_ABLATE & 1);) {
+                const unsigned v = __hip_atomic_load(chain.cnt + 16 * (kChainSlots + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= want) break;
+                if (++spins > (1u << 16)) {                       // tens of ms: give up loudly instead of hanging the GPU
+                    if (lane == 0) __hip_atomic_store(chain.cnt + 16 * (kChainSlots + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (!(QL_CHAIN_ABLATE & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane == 0) {
+                const unsigned d = __hip_atomic_fetch_add(chain.cnt + 16 * kChainSlots, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == (unsigned)chain.consumers - 1) {
+                    for (int i = 0; i <= kChainSlots + 2; ++i)
+                        if (i != kChainSlots + 1) __hip_atomic_store(chain.cnt + 16 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+        issue_staging_loads();
+    }
     // (3) stage the activations (waits only for the staging loads, which are older than the tiles)
     if constexpr (PRO == PRO_SILU) {
 #pragma unroll
@@ -302,7 +353,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[i][e], hv[i][e], ss);
                 if constexpr (PRO == PRO_ADDNORM) {
-                    if (blockIdx.x == 0 && pro.hout) *reinterpret_cast<u32x4*>((T*)pro.hout + c * 8) = pack8<T>(hv[i]);
+                    if (bx == 0 && pro.hout) *reinterpret_cast<u32x4*>((T*)pro.hout + c * 8) = pack8<T>(hv[i]);
                 }
             }
         }
@@ -503,6 +554,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
     }
 
     QL_SPAN_END();
+    auto epilogue = [&] {
     if (wave_active && ks == 0 && lane == 0) {
         float bq[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
         if (quad_early) {
@@ -518,6 +570,14 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             for (int c = 0; c < 4; ++c) {
                 y[c] = Act<T>::round(acc[0][c]);
                 if (bias) y[c] = Act<T>::round(y[c] + (quad_early ? bq[c] : Act<T>::load(bias + t * 4 + c)));
+            }
+            if constexpr (CHAIN == 1) {
+                // write-through (agent-scope) 4-byte store of the pair: visible to the consumer blocks without a release fence
+                // (a buffer_wbl2 per producer block - 1 712 of them - made the one-launch MLP take 105 us instead of 23)
+                const float o0 = Act<T>::round(Act<T>::round(y[0] / (1.0f + __expf(-y[0]))) * y[2]);
+                const float o1 = Act<T>::round(Act<T>::round(y[1] / (1.0f + __expf(-y[1]))) * y[3]);
+                __hip_atomic_store(reinterpret_cast<u32*>(C + t * 2), pack2<T>(o0, o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -552,6 +612,31 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restr
             }
         }
     }
+    };
+    epilogue();
+    if constexpr (CHAIN == 1) {
+        // outputs -> visible to the consumer blocks of this launch (cdna_hip_programming.md Guideline 16, R1): the payload went
+        // out write-through, every storing wave drains its stores, block barrier, one lane arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int slot = bx & (kChainSlots - 1);
+            const unsigned want = (unsigned)(chain.producers + kChainSlots - 1 - slot) / kChainSlots;   // producers of this slot
+            if (__hip_atomic_fetch_add(chain.cnt + 16 * slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == want)
+                __hip_atomic_fetch_add(chain.cnt + 16 * (kChainSlots + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>
+__global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+                                                                const T* __restrict__ Sp, const void* pro_delta,
+                                                                const void* pro_ln_weight, int N, int K, int M, int lda32,
+                                                                const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                                void* pro_hout, float pro_eps, int pro_gate,
+                                                                const T* __restrict__ resid = nullptr) {
+    w4_packed_gemv_16_body<T, MB, ACH, KS, STRICT, VAR, PRO>(A, Wt, Sp, pro_delta, pro_ln_weight, N, K, M, lda32, bias, C, ldc, pro_hout,
+                                                              pro_eps, pro_gate, resid, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -838,6 +923,71 @@ static int launch_16_pro_any(const PackedArgs& p, const Prologue& pro) {
     if (chunks <= 4 * 256) { QL_PRO(4) }
     QL_PRO(8)
 #undef QL_PRO
+}
+
+// ---------------------------------------------------------------------------------------------
+// The MLP of a decode step in ONE launch (experiment): blocks [0, nA) run the first projection (RMSNorm
+// prologue, SiLU * gate epilogue on the gate-interleaved copy) and publish its (1, hidden) row; the remaining blocks run
+// the second projection (residual epilogue): their weight tiles are requested at once, then they wait for the row.
+// Workgroups are dispatched in index order, so every producer is resident or done before the first consumer starts:
+// the waits cannot deadlock (they are bounded all the same).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct PairArgs {
+    const T* x;            // (1, Ka) hidden state
+    const T* ln_weight;
+    float eps;
+    const u32x4* Wa; const T* Sa; const T* bias_a; int Na, Ka;     // gate-interleaved first projection (Na packed columns)
+    T* mid;                // (1, Na / 2)
+    const u32x4* Wb; const T* Sb; const T* bias_b; int Nb, Kb;     // second projection, Kb == Na / 2
+    const T* resid; T* out;
+    int nA;
+    ChainArgs chain;
+};
+
+template <typename T, int ACH_A, int KS_A, int ACH_B, int KS_B>
+__global__ __launch_bounds__(256) void w4_mlp_pair_kernel(const PairArgs<T> p) {
+    if ((int)blockIdx.x < p.nA)
+        w4_packed_gemv_16_body<T, 1, ACH_A, KS_A, false, 0, PRO_NORM, 1>(p.x, p.Wa, p.Sa, nullptr, p.ln_weight, p.Na, p.Ka, 1, p.Ka, p.bias_a,
+                                                                      p.mid, p.Na, nullptr, p.eps, 1, nullptr, (int)blockIdx.x, 0, p.chain);
+    else
+        w4_packed_gemv_16_body<T, 1, ACH_B, KS_B, false, 0, PRO_NONE, 2>(p.mid, p.Wb, p.Sb, nullptr, nullptr, p.Nb, p.Kb, 1, p.Kb, p.bias_b,
+                                                                      p.out, p.Nb, nullptr, 0.f, 0, p.resid, (int)blockIdx.x - p.nA, 0,
+                                                                      p.chain);
+}
+
+size_t w4_mlp_pair_workspace_bytes() { return sizeof(unsigned) * kChainWords; }
+
+template <typename T>
+static int launch_mlp_pair(const void* x, const void* ln_weight, float eps, const void* packed_a, const void* bias_a, int64_t Na,
+                           int64_t Ka, const void* packed_b, const void* bias_b, int64_t Nb, int64_t Kb, const void* resid,
+                           void* mid, void* out, void* ws, hipStream_t st) {
+    const int64_t Ga = Ka / 32, Gb = Kb / 32, NpA = (Na + 3) & ~(int64_t)3, NpB = (Nb + 3) & ~(int64_t)3;
+    const int ks_a = choose_ksplit(NpA / 4, Ga), ks_b = choose_ksplit(NpB / 4, Gb);
+    // the one combination a ChatGLM2-6B layer needs (4096 -> 2 x 13696 -> 4096); everything else: two launches
+    if (!(Ka / 8 <= 2 * 256 && ks_a == 1 && Kb / 8 > 4 * 256 && Kb / 8 <= 8 * 256 && ks_b == 4 && (size_t)Kb * sizeof(T) <= 60 * 1024))
+        return QL_ERR_UNSUPPORTED;
+    PairArgs<T> p;
+    p.x = (const T*)x; p.ln_weight = (const T*)ln_weight; p.eps = eps;
+    p.Wa = (const u32x4*)packed_a; p.Sa = (const T*)((const char*)packed_a + NpA * Ga * 16); p.bias_a = (const T*)bias_a;
+    p.Na = (int)Na; p.Ka = (int)Ka; p.mid = (T*)mid;
+    p.Wb = (const u32x4*)packed_b; p.Sb = (const T*)((const char*)packed_b + NpB * Gb * 16); p.bias_b = (const T*)bias_b;
+    p.Nb = (int)Nb; p.Kb = (int)Kb; p.resid = (const T*)resid; p.out = (T*)out;
+    const int nA = (int)((NpA / 4 + 3) / 4), nB = (int)(NpB / 4);           // KS_A = 1: 4 quads per block; KS_B = 4: one quad per block
+    p.nA = nA;
+    p.chain = ChainArgs{(unsigned*)ws, nA, nB};
+    const size_t lds_a = (((size_t)Ka * sizeof(T) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float) + 4 * sizeof(float);
+    const size_t lds_b = (((size_t)Kb * sizeof(T) + 15) & ~(size_t)15) + (size_t)4 * 4 * sizeof(float);
+    w4_mlp_pair_kernel<T, 2, 1, 8, 4><<<(unsigned)(nA + nB), 256, lds_a > lds_b ? lds_a : lds_b, st>>>(p);
+    return finish_launch();
+}
+
+int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, const void* packed_a, const void* bias_a, int64_t Na,
+                int64_t Ka, const void* packed_b, const void* bias_b, int64_t Nb, int64_t Kb, const void* resid, void* mid,
+                void* out, void* ws, hipStream_t st) {
+    if (dtype == QL_DTYPE_F16) return launch_mlp_pair<f16>(x, ln_weight, eps, packed_a, bias_a, Na, Ka, packed_b, bias_b, Nb, Kb, resid, mid, out, ws, st);
+    if (dtype == QL_DTYPE_BF16) return launch_mlp_pair<__bf16>(x, ln_weight, eps, packed_a, bias_a, Na, Ka, packed_b, bias_b, Nb, Kb, resid, mid, out, ws, st);
+    return QL_ERR_BAD_DTYPE;
 }
 
 int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,

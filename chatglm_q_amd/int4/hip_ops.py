@@ -397,6 +397,50 @@ def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | No
     return c
 
 
+_PAIR_WS: dict = {}
+
+
+def w4_mlp_pair(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, bias_in: Tensor | None, n_in: int,
+                packed_out: Tensor, bias_out: Tensor | None, n_out: int, residual: Tensor) -> Tensor | None:
+    """EXPERIMENT (``qlinear_w4g32_mlp_pair``): the MLP of a one-row decode step in ONE launch - RMSNorm + w_in + SiLU * gate
+    and w_out + residual, the second projection's workgroups waiting inside the launch for the first one's row.  Bit-equal
+    to ``w4_forward_fused(PRO_ADDNORM | EPI_SILU_GATE)`` followed by ``w4_forward_residual``.  None when the library does
+    not serve the shape (the caller then issues the two launches)."""
+    lib = _lib.get_lib()
+    K = x.shape[-1]
+    if x.numel() != K or residual.numel() != n_out:
+        raise ValueError("the MLP pair serves exactly one row")
+    _check_row_operands("w4_mlp_pair", x, K, ln_weight=ln_weight, bias_in=bias_in, bias_out=bias_out, residual=residual)
+    if gated_packed.numel() < gemv_nbytes(n_in, K, x.dtype) or packed_out.numel() < gemv_nbytes(n_out, n_in // 2, x.dtype):
+        raise AssertionError("w4_mlp_pair: derived buffers too small for the two projections")
+    ws = _PAIR_WS.get(x.device)
+    if ws is None:                                        # arrival counters: zeroed once, reset by the kernel itself
+        ws = _PAIR_WS[x.device] = torch.zeros(int(lib.qlinear_w4g32_mlp_pair_workspace_bytes()) + 64, dtype=torch.uint8, device=x.device)
+    off = (-ws.data_ptr()) % 64
+    x = x.contiguous()
+    residual = residual.contiguous()
+    mid = torch.empty(n_in // 2, device=x.device, dtype=x.dtype)
+    out = torch.empty((*x.shape[:-1], n_out), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        st = lib.qlinear_w4g32_mlp_pair(x.data_ptr(), ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
+                                        packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, residual.data_ptr(), mid.data_ptr(),
+                                        out.data_ptr(), ws.data_ptr() + off, _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w4g32_mlp_pair")
+    return out
+
+
+def mlp_pair_timed_out(device) -> bool:
+    """True when a consumer workgroup of an earlier ``w4_mlp_pair`` launch gave up waiting (host-synchronous read of the
+    error word; the results of that launch are then garbage)."""
+    ws = _PAIR_WS.get(torch.device(device))
+    if ws is None:
+        return False
+    off = (-ws.data_ptr()) % 64
+    return bool(ws[off + 4 * 16 * 65: off + 4 * 16 * 65 + 4].view(torch.int32).item())
+
+
 def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:
     """Same contract as the reference wrapper (chatglm_q/int4/triton_ops.py:90-139).
 

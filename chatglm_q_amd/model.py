@@ -24,6 +24,8 @@ from torch import Tensor, nn
 
 # QLINEAR_FUSED_DECODE=0 keeps every op around the QLinear calls in plain torch (A/B measurements)
 FUSED_DECODE_OPS = os.environ.get("QLINEAR_FUSED_DECODE", "1") not in ("0", "false", "False")
+# experiment: the two MLP projections of a one-row int4 decode step in ONE launch (qlinear_w4g32_mlp_pair)
+MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False")
 
 
 @dataclass
@@ -346,8 +348,15 @@ class ChatGLM2Model(nn.Module):
             att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i],
                                            mask, H, G, D, prefetch=nxt)
             h = residual_linear(at.o_proj, att, h)
-            y = norm_linear(ff.w_in, h, None, layer.ffn_ln, None, gate_hidden=ff.hidden_dim)
-            h = residual_linear(ff.w_out, y, h)
+            hn = None
+            if kind == "int4" and MLP_PAIR:                    # experiment: both MLP projections in one launch
+                gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
+                hn = H4.w4_mlp_pair(h, layer.ffn_ln.weight, layer.ffn_ln.eps, gp, gb, ff.w_in.out_features,
+                                    ff.w_out.prepare()._packed, ff.w_out.bias, ff.w_out.out_features, h)
+            if hn is None:
+                y = norm_linear(ff.w_in, h, None, layer.ffn_ln, None, gate_hidden=ff.hidden_dim)
+                hn = residual_linear(ff.w_out, y, h)
+            h = hn
         return norm_linear(self.lm_head, h, None, self.final_ln, None)
 
     # -- reference-shaped call ----------------------------------------------------------------------

@@ -206,6 +206,19 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
 int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                   int64_t lda, int64_t ldc, int dtype, void* stream);
 
+/* EXPERIMENT (one launch instead of two): the MLP of a one-row decode step,
+ *   Out = round(w_out(round(silu(h) * gate)) + residual),  (h | gate) = w_in(rmsnorm(X) * ln_weight),
+ * i.e. qlinear_w4g32_fwd_packed_fused(QL_PRO_ADDNORM | QL_EPI_SILU_GATE) followed by qlinear_w4g32_fwd_packed_residual, bit
+ * for bit, with the second projection's workgroups in the SAME launch behind the first one's: they request their weights
+ * at once and wait (bounded) for the (1, N_in / 2) row `mid` through arrival counters in `workspace`
+ * (qlinear_w4g32_mlp_pair_workspace_bytes() bytes, 64-byte aligned, zeroed ONCE by the caller; the kernel resets it).
+ * packed_in: gate-interleaved part 1 of the (K, N_in) projection; packed_out: part 1 of the (N_in / 2, N_out) projection.
+ * QL_ERR_UNSUPPORTED for shapes other than the ChatGLM2-6B layer's kernel configuration: use the two calls. */
+size_t qlinear_w4g32_mlp_pair_workspace_bytes(void);
+int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                           const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, const void* residual, void* mid,
+                           void* Out, void* workspace, int dtype, void* stream);
+
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
  * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then
