@@ -759,3 +759,28 @@ def test_int4_rows_on_tiled_is_the_librarys_routing():
         else:
             assert_close(h4.w4_forward(x, qw.to(DEV), sc.to(DEV), None, part1),
                          O.w4_matmul(t2n(x), qw.numpy(), t2n(sc), None, dtype="f16"), "f16")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_int4_rows4_one_hot_rows_read_back_exact_weights(M, dt):
+    """2..4 rows on the 4x4x4 matrix instruction (w4_rows4.hip) at a full layer size: every row is a different one-hot
+    activation, so every output row must be exactly one dequantised weight row - the (block, lane) <-> (group, column, row)
+    mapping, the nibble -> k order inside a word and the bf16 offset trick (second MFMA against ones) checked bit for bit;
+    and scaling the activations by 2 scales the outputs by 2 exactly."""
+    K, N = 4096, 4608
+    tdt = TDT[dt]
+    qw, sc = _rand_w4(K, N, dt, 5151 + M)
+    qd, sd = qw.to(DEV), sc.to(DEV)
+    assert not h4.rows_on_tiled(M, N, K, tdt)
+    part1 = h4.repack_w4g32_gemv(qd, sd)
+    dense = O.unpack_int4(qw.numpy(), t2n(sc), dtype=dt)
+    for ks in ((0, 1, 2, 3), (31, 32, 33, 63), (4095, 2048, 513, 7), (100, 100, 100, 100)):
+        a = torch.zeros(M, K, dtype=tdt, device=DEV)
+        for m in range(M):
+            a[m, ks[m]] = 1.0
+        y = t2n(h4.w4_forward(a, qd, sd, None, part1))
+        for m in range(M):
+            assert np.array_equal(y[m], dense[ks[m]].astype(np.float32)), (m, ks[m])
+    a = torch.randn(M, K, generator=torch.Generator().manual_seed(2)).to(tdt).to(DEV)
+    assert torch.equal(h4.w4_forward(a * 2, qd, sd, None, part1), h4.w4_forward(a, qd, sd, None, part1) * 2)
