@@ -95,6 +95,8 @@ EXPORTS = {
     "qlinear_decode_attention_split_bytes": (c_size_t, [c_int64] * 4),
     "qlinear_decode_attention_rope": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w4g32_fwd_packed_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
+    "qlinear_w4g32_fwd_rows_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                             c_void_p, c_float, c_int, c_void_p]),
     "qlinear_w4g32_mlp_pair_workspace_bytes": (c_size_t, []),
     "qlinear_w4g32_mlp_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

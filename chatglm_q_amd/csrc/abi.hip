@@ -219,6 +219,20 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
                                          stream);
 }
 
+int qlinear_w4g32_fwd_rows_fused(int prologue, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+                                 int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, int dtype, void* stream) {
+    if (!A || !packed || !C || !ln_weight) return QL_ERR_NULL_POINTER;
+    const bool gate = (prologue & QL_EPI_SILU_GATE) != 0;
+    if ((prologue & ~QL_EPI_SILU_GATE) != QL_PRO_ADDNORM) return QL_ERR_UNSUPPORTED;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || (gate && N % 4 != 0))
+        return QL_ERR_BAD_SHAPE;
+    if (!aligned(packed, 16) || !aligned(A, 16) || (delta && !aligned(delta, 16)) || !aligned(ln_weight, 16) || (hout && !aligned(hout, 16)))
+        return QL_ERR_MISALIGNED;
+    if (M < 2 || K > 8192 || !w4_rows4_serves(dtype, M, N, K, K, false)) return QL_ERR_UNSUPPORTED;
+    return w4_rows4_fused(dtype, gate, A, packed, bias, C, M, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
+}
+
 size_t qlinear_w4g32_mlp_pair_workspace_bytes(void) { return w4_mlp_pair_workspace_bytes(); }
 
 int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,

@@ -93,7 +93,10 @@ int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, cons
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
 bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict);   // w4_packed.hip: the routing rule
 int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-             int64_t lda, int64_t ldc, hipStream_t st, bool gate = false);
+             int64_t lda, int64_t ldc, hipStream_t st, bool gate = false, const void* delta = nullptr, const void* ln_weight = nullptr,
+             void* hout = nullptr, float eps = 0.f);
+int w4_rows4_fused(int dtype, bool gate, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                   const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);   // w4_packed.hip: picks the K split
 int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                    int64_t lda, int64_t ldc, hipStream_t st);                                   // w4_packed.hip: picks the K split
 

@@ -1079,6 +1079,13 @@ int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bia
     return w4_rows4(dtype, choose_ksplit(Npad / 4, K / 32, (int)M), A, packed, bias, C, M, N, K, lda, ldc, st, true);
 }
 
+int w4_rows4_fused(int dtype, bool gate, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                   const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
+    const int64_t Npad = (N + 3) & ~(int64_t)3;
+    return w4_rows4(dtype, choose_ksplit(Npad / 4, K / 32, (int)M), A, packed, bias, C, M, N, K, K, gate ? N / 2 : N, st, gate, delta,
+                    ln_weight, hout, eps);
+}
+
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
     static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return M > forced;

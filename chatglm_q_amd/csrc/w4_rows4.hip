@@ -62,10 +62,15 @@ template <> struct Rows4<__bf16> {
 // gate (run time): the packed columns come in quads (h_2t, h_2t+1, gate_2t, gate_2t+1) - the gate-interleaved copy of a
 // first MLP projection - and C gets N / 2 columns, C[m, 2t+i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias,
 // rounded): chatglm_q/model.py:200-201, the rounding sequence of the GEMV's and the few-row kernel's gate epilogues.
-template <typename T, int KS, int RING, int NQ, int NW, int MR>
+// PRO = 1: the rows are staged through the residual add + RMSNorm of the model graph (chatglm_q/model.py:62-73,243-245),
+//   hnew = round(A + delta) (delta nullable; written to hout by block 0), staged = round(round(hnew * rsqrt(mean(hnew^2) + eps)) *
+//   ln_weight) - with the summation order of rmsnorm_kernel (decode_ops.hip: 256 threads per row, chunks tid + 256 u, wave
+//   sums combined as (0 + 1) + (2 + 3)), so that the fused launch is bit-equal to qlinear_add_rmsnorm + the projection.
+template <typename T, int KS, int RING, int NQ, int NW, int MR, int PRO>
 __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                            int N, int K, int M, int lda32, const T* __restrict__ bias,
-                                                           T* __restrict__ C, int64_t ldc, int gate) {
+                                                           T* __restrict__ C, int64_t ldc, int gate, const T* __restrict__ delta,
+                                                           const T* __restrict__ ln_weight, T* __restrict__ hout, float eps) {
     constexpr bool kF16 = Act<T>::code == QL_DTYPE_F16;
     constexpr int QW = NW / KS;                                // quad sets per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,12 +116,59 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
     // stage the M rows: 16-byte chunk cc of row m (k = 8 cc .. 8 cc + 7) at m * rowb + 16 cc, its dwords in the order
     // (0, 2, 1, 3): the two dwords an MFMA takes as its A operand are then an aligned register pair of the ds_read_b128.
     // No swizzle: the 16 lanes of a ds_read_b128 phase are 4 blocks (64-byte stride) x 4 rows (16-byte row padding).
-    for (int c = tid; c < M * cpr; c += NW * 64) {
-        const int m = c / cpr, cc = c - m * cpr;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + cc * 8);
-        *reinterpret_cast<u32x4*>(smem + (int64_t)m * rowb + cc * 16) = u32x4{v[0], v[2], v[1], v[3]};
+    if constexpr (PRO == 1) {
+        static_assert(NW == 8, "two rows at a time, 256 threads each (rmsnorm_kernel's summation order)");
+        constexpr int VPT = 4;                                 // K <= 8192
+        float* nred = reinterpret_cast<float*>(smem + (int64_t)M * rowb);
+        const int half = tid >> 8, ht = tid & 255;
+        for (int mp = 0; mp < M; mp += 2) {                    // block-uniform trip count
+            const int m = mp + half;
+            const bool live = m < M;
+            float v[VPT][8];
+            float ss = 0.f;
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) {
+                const int i = ht + u * 256;
+                if (live && i < cpr) {
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + i * 8), v[u]);
+                    if (delta) {
+                        float d[8];
+                        unpack8<T>(*reinterpret_cast<const u32x4*>(delta + (int64_t)m * K + i * 8), d);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[u][e] = Act<T>::round(v[u][e] + d[e]);
+                        if (blockIdx.x == 0 && hout) *reinterpret_cast<u32x4*>(hout + (int64_t)m * K + i * 8) = pack8<T>(v[u]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[u][e], v[u][e], ss);
+                }
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) nred[wave] = ss;
+            __syncthreads();
+            const float tot = half ? (nred[4] + nred[5]) + (nred[6] + nred[7]) : (nred[0] + nred[1]) + (nred[2] + nred[3]);
+            const float r = rsqrtf(tot / (float)K + eps);
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) {
+                const int i = ht + u * 256;
+                if (live && i < cpr) {
+                    float w[8], y[8];
+                    unpack8<T>(*reinterpret_cast<const u32x4*>(ln_weight + i * 8), w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = Act<T>::round(v[u][e] * r) * w[e];
+                    const u32x4 pk = pack8<T>(y);
+                    *reinterpret_cast<u32x4*>(smem + (int64_t)m * rowb + i * 16) = u32x4{pk[0], pk[2], pk[1], pk[3]};
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int c = tid; c < M * cpr; c += NW * 64) {
+            const int m = c / cpr, cc = c - m * cpr;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + cc * 8);
+            *reinterpret_cast<u32x4*>(smem + (int64_t)m * rowb + cc * 16) = u32x4{v[0], v[2], v[1], v[3]};
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const char* arow[MR];                                      // rows past M repeat the last one (their sums are dropped)
 #pragma unroll
@@ -275,23 +327,31 @@ __global__ __launch_bounds__(NW * 64) void w4_rows4_kernel(const T* __restrict__
     }
 }
 
-template <typename T, int KS, int NQ, int MR>
+struct Rows4Pro {
+    const void* delta;
+    const void* ln_weight;     // non-null selects the prologue
+    void* hout;
+    float eps;
+};
+
+template <typename T, int KS, int NQ, int MR, int PRO>
 static int launch_rows4_ks(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                           int64_t ldc, bool gate, hipStream_t st) {
+                           int64_t ldc, bool gate, const Rows4Pro& pro, hipStream_t st) {
     const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
     const u32x4* Wt = (const u32x4*)packed;
     const T* Sp = (const T*)((const char*)packed + Npad * G * 16);
     constexpr int NW = QL_ROWS4_WAVES, QW = NW / KS, RING = QL_ROWS4_RING;
     const int quads = (int)(Npad / 4), per_block = QW * NQ;
-    size_t lds = (size_t)M * (K * 2 + 16);
+    size_t lds = (size_t)M * (K * 2 + 16) + 64;                                 // + the prologue's eight wave sums
     if (lds < (size_t)NW * NQ * MR * 256) lds = (size_t)NW * NQ * MR * 256;     // the reduction scratch
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ, NW, MR>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows4_kernel<T, KS, RING, NQ, NW, MR, PRO>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     }();
     (void)attr_set;
-    w4_rows4_kernel<T, KS, RING, NQ, NW, MR><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
-        (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc, gate ? 1 : 0);
+    w4_rows4_kernel<T, KS, RING, NQ, NW, MR, PRO><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
+        (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc, gate ? 1 : 0, (const T*)pro.delta, (const T*)pro.ln_weight,
+        (T*)pro.hout, pro.eps);
     return finish_launch();
 }
 
@@ -304,22 +364,25 @@ bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda)
 }
 
 // ks: K slices per column quad (1, 2 or 4: w4_packed.hip's choose_ksplit); gate: SiLU * gate epilogue on a gate-interleaved
-// copy (N % 4 == 0, C gets N / 2 columns)
+// copy (N % 4 == 0, C gets N / 2 columns); ln_weight != nullptr: residual add + RMSNorm prologue (rows contiguous, K <= 8192)
 int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-             int64_t lda, int64_t ldc, hipStream_t st, bool gate) {
-#define QL_R4K(T_, NQ_, MR_)                                                                                            \
-    switch (ks) {                                                                                                       \
-    case 4: return launch_rows4_ks<T_, 4, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);    \
-    case 2: return launch_rows4_ks<T_, 2, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);    \
-    default: return launch_rows4_ks<T_, 1, NQ_, MR_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, st);   \
+             int64_t lda, int64_t ldc, hipStream_t st, bool gate, const void* delta, const void* ln_weight, void* hout, float eps) {
+    const Rows4Pro pro{delta, ln_weight, hout, eps};
+#define QL_R4K(T_, NQ_, PRO_)                                                                                               \
+    switch (ks) {                                                                                                           \
+    case 4: return launch_rows4_ks<T_, 4, NQ_, 1, PRO_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, pro, st);   \
+    case 2: return launch_rows4_ks<T_, 2, NQ_, 1, PRO_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, pro, st);   \
+    default: return launch_rows4_ks<T_, 1, NQ_, 1, PRO_>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, gate, pro, st);  \
     }
 #define QL_R4(T_)                                                                                                       \
-    if (nq == 2) { QL_R4K(T_, 2, 1) }                                                                                   \
-    QL_R4K(T_, 1, 1)
+    if (ln_weight) { QL_R4K(T_, 1, 1) }                                                                                 \
+    if (nq == 2) { QL_R4K(T_, 2, 0) }                                                                                   \
+    QL_R4K(T_, 1, 0)
     // one quad per wave; two (QLINEAR_ROWS4_NQ=2: shared activation fragments, half the blocks) measured slower on every
     // layer shape but w_out at one row (2 rows: 7.2 / 5.8 / 18.4 / 13.3 us against 6.5 / 5.8 / 17.1 / 11.8)
     static const int nq = [] { const char* e = getenv("QLINEAR_ROWS4_NQ"); return e && atoi(e) == 2 ? 2 : 1; }();
     if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
+    if (ln_weight && (K > 8192 || QL_ROWS4_WAVES != 8)) return QL_ERR_UNSUPPORTED;
     if (dtype == QL_DTYPE_F16) { QL_R4(f16) }
     if (dtype == QL_DTYPE_BF16) { QL_R4(__bf16) }
 #undef QL_R4

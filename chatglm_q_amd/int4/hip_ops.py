@@ -397,6 +397,38 @@ def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | No
     return c
 
 
+def w4_forward_rows_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, delta: Tensor | None,
+                          ln_weight: Tensor, eps: float, want_hout: bool = True):
+    """2..4 rows (batched decode) with the residual add + RMSNorm prologue, optionally the SiLU * gate epilogue
+    (``kind = _lib.PRO_ADDNORM [| _lib.EPI_SILU_GATE]``), in ONE launch of the 4x4x4-MFMA kernel (``qlinear_w4g32_fwd_rows_fused``):
+    bit-equal to ``add_rmsnorm`` (``rmsnorm`` when ``delta`` is None) followed by the projection (and ``silu_mul``).
+    ``a``, ``delta``: (..., K) with 2..4 rows in total.  Returns (out, hnew) - hnew is None when ``delta`` is None - or None
+    when the library does not serve the shape that way."""
+    lib = _lib.get_lib()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K).contiguous()
+    M = a2.shape[0]
+    if M < 2 or K > 8192 or rows_on_tiled(M, n_out, K, a.dtype):
+        return None
+    _check_row_operands("w4_forward_rows_fused", a, K, bias=bias, delta=delta, ln_weight=ln_weight)
+    if packed.device != a.device or packed.numel() < gemv_nbytes(n_out, K, a.dtype):
+        raise AssertionError("w4_forward_rows_fused: packed buffer on another device or too small for (n_out, K)")
+    d2 = delta.reshape(-1, K).contiguous() if delta is not None else None
+    if d2 is not None and d2.shape != a2.shape:
+        raise AssertionError("w4_forward_rows_fused: delta shape differs from the activations'")
+    hout = torch.empty_like(a2) if (d2 is not None and want_hout) else None
+    cols = n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out
+    c = torch.empty((M, cols), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_rows_fused(kind, a2.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out, K,
+                                              _lib.ptr(d2), ln_weight.data_ptr(), _lib.ptr(hout), float(eps), _lib.dtype_code(a.dtype),
+                                              _lib.stream_ptr(a.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w4g32_fwd_rows_fused")
+    return c.reshape(*a.shape[:-1], cols), (hout.reshape(a.shape) if hout is not None else None)
+
+
 _PAIR_WS: dict = {}
 
 

@@ -24,6 +24,8 @@ from torch import Tensor, nn
 
 # QLINEAR_FUSED_DECODE=0 keeps every op around the QLinear calls in plain torch (A/B measurements)
 FUSED_DECODE_OPS = os.environ.get("QLINEAR_FUSED_DECODE", "1") not in ("0", "false", "False")
+# batched decode at 2..4 rows: residual add + RMSNorm inside the projections' launches (qlinear_w4g32_fwd_rows_fused)
+ROWS_FUSED_MAX = int(os.environ.get("QLINEAR_ROWS_FUSED_MAX", "2"))      # largest batch that takes it (0 / 1: off)
 # experiment: the two MLP projections of a one-row int4 decode step in ONE launch (qlinear_w4g32_mlp_pair)
 MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False")
 
@@ -253,28 +255,64 @@ class ChatGLM2Model(nn.Module):
             kind = self._one_row_kind(h.dtype)
             if kind:
                 return self._step_one_row(h, cache, write_index, position_ids, mask, kind)
+        # batched decode at 2 rows: residual add + RMSNorm inside the projections' launches (the entry point serves 2..4 rows, but the
+        # prologue handles two rows per pass: measured 1.45 -> 1.41 ms per step at 2 rows, 1.56 -> 1.59 / 1.61 -> 1.64 at 3 / 4)
+        few = S == 1 and 2 <= B <= ROWS_FUSED_MAX and h.dtype in (torch.float16, torch.bfloat16)
         delta = None                                   # pending residual contribution of the previous sub-block
         for i, layer in enumerate(self.layers):
-            if delta is None:
-                x = F_.rmsnorm(h, layer.attn_ln.weight, layer.attn_ln.eps)
-            else:                                      # h += delta and the next norm in one launch
-                h, x = F_.add_rmsnorm(h, delta, layer.attn_ln.weight, layer.attn_ln.eps)
+            qkv = self._rows_fused(layer.attn.qkv_proj, h, delta, layer.attn_ln) if few else None
+            if qkv is not None:                        # h += delta, RMSNorm and qkv_proj: one launch
+                qkv, hn = qkv
+                h = hn if hn is not None else h
+            else:
+                if delta is None:
+                    x = F_.rmsnorm(h, layer.attn_ln.weight, layer.attn_ln.eps)
+                else:                                  # h += delta and the next norm in one launch
+                    h, x = F_.add_rmsnorm(h, delta, layer.attn_ln.weight, layer.attn_ln.eps)
+                qkv = layer.attn.qkv_proj(x)
             if S == 1:                                 # rotary + cache write + attention: one launch
-                att = F_.decode_attention_rope(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
+                att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index,
                                                cache.k[i], cache.v[i], mask, H, G, D)
             else:
-                q = F_.rope_kv_write(layer.attn.qkv_proj(x), self.freqs_cis_cache, position_ids, write_index,
+                q = F_.rope_kv_write(qkv, self.freqs_cis_cache, position_ids, write_index,
                                      cache.k[i], cache.v[i], H, G, D)
                 att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
-            h, x = F_.add_rmsnorm(h, layer.attn.o_proj(att), layer.ffn_ln.weight, layer.ffn_ln.eps)
-            y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
-            if y is None:
-                y = F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim)
+            o = layer.attn.o_proj(att)
+            y = self._rows_fused(layer.ffn.w_in, h, o, layer.ffn_ln, gate_hidden=layer.ffn.hidden_dim) if few else None
+            if y is not None:                          # h += o, RMSNorm, w_in and SiLU * gate: one launch
+                y, h = y
+            else:
+                h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
+                y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
+                if y is None:
+                    y = F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim)
             delta = layer.ffn.w_out(y)
         if last_only:
             h, delta = h[:, -1:], delta[:, -1:]
+        out = self._rows_fused(self.lm_head, h, delta, self.final_ln, want_hout=False) if few else None
+        if out is not None:
+            return out[0]
         _, x = F_.add_rmsnorm(h, delta, self.final_ln.weight, self.final_ln.eps)
         return self.lm_head(x)
+
+    @staticmethod
+    def _rows_fused(mod, h: Tensor, delta: Optional[Tensor], ln, gate_hidden: Optional[int] = None, want_hout: bool = True):
+        """Batched decode at 2..4 rows: ``mod(rmsnorm(h + delta))`` (optionally SiLU * gate on a first MLP projection) in ONE
+        launch of the 4x4x4-MFMA kernel; (out, hnew) or None when module / shape are not served that way."""
+        from . import _lib
+        from .int4 import hip_ops as H4
+        from .int4.qlinear import DynamicQuantizeLinear as Q4
+        if not (isinstance(mod, Q4) and mod._packed_supported() and not mod.act_quant and mod.weight_scale.dtype == h.dtype
+                and not _lib.STRICT_DEFAULT):
+            return None
+        if gate_hidden:
+            if mod.out_features != 2 * gate_hidden or gate_hidden % 2:
+                return None
+            packed, bias = mod.gated_packed(gate_hidden)
+            kind = _lib.PRO_ADDNORM | _lib.EPI_SILU_GATE
+        else:
+            packed, bias, kind = mod.prepare()._packed, mod.bias, _lib.PRO_ADDNORM
+        return H4.w4_forward_rows_fused(kind, h, packed, mod.out_features, bias, delta, ln.weight, ln.eps, want_hout)
 
     @staticmethod
     def _gated_w_in(ffn, x: Tensor) -> Optional[Tensor]:

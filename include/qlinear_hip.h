@@ -206,6 +206,13 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
 int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                   int64_t lda, int64_t ldc, int dtype, void* stream);
 
+/* The same prologue (QL_PRO_ADDNORM, optionally | QL_EPI_SILU_GATE) for 2..4 contiguous rows (batched decode), on the 4x4x4-MFMA
+ * kernel: A, delta (nullable), hout (nullable; written when delta is given) are (M, K), C is (M, N) or (M, N / 2) with the gate
+ * epilogue; bit-equal to qlinear_add_rmsnorm (qlinear_rmsnorm without delta) followed by the projection (and qlinear_silu_mul).
+ * QL_ERR_UNSUPPORTED outside the row counts / shapes for which qlinear_w4g32_rows_on_tiled is 0, or K > 8192. */
+int qlinear_w4g32_fwd_rows_fused(int prologue, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
+                                 int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, int dtype, void* stream);
+
 /* EXPERIMENT (one launch instead of two): the MLP of a one-row decode step,
  *   Out = round(w_out(round(silu(h) * gate)) + residual),  (h | gate) = w_in(rmsnorm(X) * ln_weight),
  * i.e. qlinear_w4g32_fwd_packed_fused(QL_PRO_ADDNORM | QL_EPI_SILU_GATE) followed by qlinear_w4g32_fwd_packed_residual, bit

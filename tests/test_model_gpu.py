@@ -571,3 +571,48 @@ def test_mlp_pair_one_launch_equals_two(dtype, bias):
     s_out.weight_scale.fill_(0.01)
     x = torch.randn(1, 1, 256, device=DEV, generator=g).to(dtype)
     assert H4.w4_mlp_pair(x, ln[:256].contiguous(), 1e-5, small.gated_packed(256)[0], None, 512, s_out.prepare()._packed, None, 256, x) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_rows_fused_prologue_equals_separate_ops(M, with_delta, dtype):
+    """qlinear_w4g32_fwd_rows_fused (2..4 rows: residual add + RMSNorm in the staging of the 4x4x4-MFMA kernel, optional
+    SiLU * gate epilogue) against add_rmsnorm / rmsnorm followed by the module (and silu_mul): bit for bit, hnew included."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(300 + M)
+    for K, N, hidden in ((4096, 4608, None), (4096, 2 * 13696, 13696), (256, 200, None), (1024, 512, 256)):
+        layer = DynamicQuantizeLinear(K, N, bias=True, dtype=dtype, device=DEV)
+        layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+        h = torch.randn(M, 1, K, device=DEV, generator=g).to(dtype)
+        d = torch.randn(M, 1, K, device=DEV, generator=g).to(dtype) if with_delta else None
+        w = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+        if with_delta:
+            want_h, x = F_.add_rmsnorm(h, d, w, 1e-5)
+        else:
+            want_h, x = None, F_.rmsnorm(h, w, 1e-5)
+        with torch.no_grad():
+            want = layer(x)
+        if hidden:
+            want = F_.silu_mul(want, hidden)
+            packed, bias = layer.gated_packed(hidden)
+            kind = _lib.PRO_ADDNORM | _lib.EPI_SILU_GATE
+        else:
+            packed, bias, kind = layer.prepare()._packed, layer.bias, _lib.PRO_ADDNORM
+        res = H4.w4_forward_rows_fused(kind, h, packed, N, bias, d, w, 1e-5)
+        assert res is not None
+        got, got_h = res
+        assert torch.equal(got, want)
+        assert (got_h is None) == (not with_delta)
+        if with_delta:
+            assert torch.equal(got_h, want_h)
+    # 5 rows are not served this way
+    h5 = torch.randn(5, 1, 256, device=DEV, generator=g).to(dtype)
+    small = DynamicQuantizeLinear(256, 64, bias=False, dtype=dtype, device=DEV)
+    small.weight.fill_(0x88)
+    small.weight_scale.fill_(0.01)
+    assert H4.w4_forward_rows_fused(_lib.PRO_ADDNORM, h5, small.prepare()._packed, 64, None, None, w[:256].contiguous(), 1e-5) is None
