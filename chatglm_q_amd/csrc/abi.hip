@@ -177,8 +177,8 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
                                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout,
                                    float eps, int dtype, void* stream) {
     if (!A || !packed || !C) return QL_ERR_NULL_POINTER;
-    const bool gate = (prologue & QL_EPI_SILU_GATE) != 0;
-    prologue &= ~QL_EPI_SILU_GATE;
+    const bool gate = (prologue & QL_EPI_SILU_GATE) != 0, strict = (prologue & QL_FUSED_STRICT) != 0;
+    prologue &= ~(QL_EPI_SILU_GATE | QL_FUSED_STRICT);
     if (prologue == QL_PRO_ADDNORM && !ln_weight) return QL_ERR_NULL_POINTER;
     if (prologue != QL_PRO_SILU && prologue != QL_PRO_ADDNORM) return QL_ERR_UNSUPPORTED;
     if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
@@ -187,7 +187,7 @@ int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* pack
     if (!aligned(packed, 16) || !aligned(A, 16) || (delta && !aligned(delta, 16)) || (ln_weight && !aligned(ln_weight, 16)) ||
         (hout && !aligned(hout, 16)))
         return QL_ERR_MISALIGNED;
-    return w4_packed_fused(dtype, prologue, gate, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
+    return w4_packed_fused(dtype, prologue, gate, strict, A, packed, bias, C, N, K, delta, ln_weight, hout, eps, (hipStream_t)stream);
 }
 
 int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
@@ -251,12 +251,13 @@ int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, cons
 }
 
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
-                                      int64_t N, int64_t K, int dtype, void* stream) {
+                                      int64_t N, int64_t K, int dtype, int flags, void* stream) {
     if (!A || !packed || !C || !residual) return QL_ERR_NULL_POINTER;
+    if (flags & ~QL_FLAG_STRICT_ROUNDING) return QL_ERR_UNSUPPORTED;
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
     if (!fits_i32(N) || !fits_i32(K) || N <= 0 || K <= 0 || K % 32 != 0) return QL_ERR_BAD_SHAPE;
     if (!aligned(packed, 16) || !aligned(A, 16)) return QL_ERR_MISALIGNED;
-    return w4_packed_residual(dtype, A, packed, bias, residual, C, N, K, (hipStream_t)stream);
+    return w4_packed_residual(dtype, (flags & QL_FLAG_STRICT_ROUNDING) != 0, A, packed, bias, residual, C, N, K, (hipStream_t)stream);
 }
 
 int qlinear_w8_fwd_residual(const void* A, const int8_t* W, const void* S, const void* bias, const void* residual, void* C,

@@ -66,9 +66,9 @@ int w4_tiled(int dtype, const void* A, const void* tiled, const void* bias, void
 int w4_packed(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldc, bool strict, void* ws, size_t ws_bytes, hipStream_t st);
 
-int w4_packed_residual(int dtype, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
+int w4_packed_residual(int dtype, bool strict, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
                        int64_t K, hipStream_t st);
-int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,
+int w4_packed_fused(int dtype, int kind, bool gate_epilogue, bool strict, const void* A, const void* packed, const void* bias, void* C,
                     int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st);
 
 // w4_gemm.hip (M > 4, fp16 / bf16, MFMA)
@@ -88,6 +88,15 @@ size_t w4_mlp_pair_workspace_bytes();
 int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, const void* packed_a, const void* bias_a, int64_t Na,
                 int64_t Ka, const void* packed_b, const void* bias_b, int64_t Nb, int64_t Kb, const void* resid, void* mid,
                 void* out, void* ws, hipStream_t st);
+
+// w4_engine.hip: the MLP of a one-row decode step as ONE persistent launch (LDS-DMA loader wave + consumer waves per CU, granule
+// hand-off of the row between the projections); bit-equal to w4_packed_fused(PRO_NORM, gate) + w4_packed_residual
+int w4_gemv_ksplit(int64_t quads, int64_t G);                 // w4_packed.hip: K slices per quad of the one-row GEMV for a shape
+bool w4_mlp_engine_supported(int64_t Na, int64_t Ka, int64_t Nb, int64_t Kb);
+size_t w4_mlp_engine_workspace_bytes(int64_t N_in);
+int w4_mlp_engine(int dtype, bool strict, const void* x, const void* ln_weight, float eps, const void* packed_a, const void* bias_a,
+                  int64_t Na, int64_t Ka, const void* packed_b, const void* bias_b, int64_t Nb, int64_t Kb, void* out, void* ws,
+                  void* trace, hipStream_t st);
 
 // w4_rows4.hip (1..4 rows, fp16 / bf16, exact-dequant arithmetic): 4x4x4 MFMA on part 1 of the derived layout; ks = K slices per quad
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);

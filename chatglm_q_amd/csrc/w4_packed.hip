@@ -21,6 +21,7 @@
 
 #include "launch.h"
 #include "w4_dequant.h"
+#include "w4_splice.h"
 
 namespace ql {
 
@@ -96,39 +97,6 @@ __global__ __launch_bounds__(256) void w4_tile_kernel(const u32x4* __restrict__ 
 // position  m * K/8 + 4 g + (j ^ ((g >> 2) & 3))  with g = cc >> 2 (its group), j = cc & 3.
 // A lane reads the 4 chunks of ITS group (64-byte lane stride); the XOR spreads each 16-lane
 // ds_read_b128 service group over all 16 four-bank slots.
-__device__ __forceinline__ int a_chunk_pos(int g, int j) { return 4 * g + (j ^ ((g >> 2) & 3)); }
-
-template <typename T> struct Splice;
-template <> struct Splice<f16> {
-    // 0x6400 | n = 1024 + n for a nibble at mantissa bits 0..3, 0x6400 | (n << 4) = 1024 + 16 n for one at bits 4..7:
-    // nibble pairs 0 and 1 of a word (bits 0..3 / 16..19 and 4..7 / 20..23) are spliced where they lie, pairs 2 and
-    // 3 after ONE shift by 8 (one shift per word instead of three to bring every pair to the same bits).  The even
-    // pairs feed the `e` chain (unit weight), the odd pairs the `o` chain (16 x): sum (n - 8) a =
-    //   e + o / 16 - (1032 sum_e a + 72 sum_o a)
-    static constexpr u32 kMagic = 0x64006400u, kMask = 0x000F000Fu, kMaskOdd = 0x00F000F0u, kOnes = 0x3C003C00u;
-    static constexpr bool kSplitChains = true;
-    static __device__ __forceinline__ float combine(float e, float o) { return __builtin_fmaf(o, 0.0625f, e); }
-    static __device__ __forceinline__ float offset(float ae, float ao) { return __builtin_fmaf(1032.0f, ae, 72.0f * ao); }
-    static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
-        return __builtin_amdgcn_fdot2(as_h2(x), as_h2(a), acc, false);
-    }
-    static __device__ __forceinline__ float lo(u32 s) { return (float)as_h2(s).x; }
-    static __device__ __forceinline__ float hi(u32 s) { return (float)as_h2(s).y; }
-};
-template <> struct Splice<__bf16> {
-    // 0x4300 | n = 128 + n (7 mantissa bits: only the low nibble position splices); every pair is shifted to bits 0..3
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    static constexpr u32 kMagic = 0x43004300u, kMask = 0x000F000Fu, kMaskOdd = 0x000F000Fu, kOnes = 0x3F803F80u;
-    static constexpr bool kSplitChains = false;
-    static __device__ __forceinline__ float combine(float e, float o) { return e + o; }
-    static __device__ __forceinline__ float offset(float ae, float ao) { return 136.0f * (ae + ao); }
-    static __device__ __forceinline__ float dot(u32 x, u32 a, float acc) {
-        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x), __builtin_bit_cast(bf2, a), acc, false);
-    }
-    static __device__ __forceinline__ float lo(u32 s) { return u32_as_f32(s << 16); }
-    static __device__ __forceinline__ float hi(u32 s) { return u32_as_f32(s & 0xFFFF0000u); }
-};
-
 template <int MB, bool A_LDS>
 struct PackedTile16 {
     u32x4 w[4];
@@ -806,6 +774,8 @@ static int choose_ksplit(int64_t quads, int64_t G, int mb = 1) {
     return ks;
 }
 
+int w4_gemv_ksplit(int64_t quads, int64_t G) { return choose_ksplit(quads, G); }
+
 template <typename T, int MB, int ACH, int KS, bool STRICT>
 static int launch_16(const PackedArgs& p) {
     const int64_t G = p.K / 32, Npad = (p.N + 3) & ~(int64_t)3;
@@ -893,7 +863,7 @@ static int launch_generic_mb(const PackedArgs& p) {
 }
 
 // one-row forward with an activation prologue (decode step)
-template <typename T, int ACH, int KS, int PRO>
+template <typename T, int ACH, int KS, int PRO, bool STRICT>
 static int launch_16_pro(const PackedArgs& p, const Prologue& pro) {
     const int64_t G = p.K / 32, Npad = (p.N + 3) & ~(int64_t)3;
     const u32x4* Wt = (const u32x4*)p.packed;
@@ -902,22 +872,22 @@ static int launch_16_pro(const PackedArgs& p, const Prologue& pro) {
     constexpr int QW = 4 / KS;
     dim3 grid((unsigned)((quads + QW - 1) / QW), 1);
     const size_t lds = (((size_t)p.K * sizeof(T) + 15) & ~(size_t)15) + 4 * 4 * sizeof(float) + 4 * sizeof(float);
-    w4_packed_gemv_16_kernel<T, 1, ACH, KS, false, 0, PRO><<<grid, 256, lds, p.st>>>(
+    w4_packed_gemv_16_kernel<T, 1, ACH, KS, STRICT, 0, PRO><<<grid, 256, lds, p.st>>>(
         (const T*)p.A, Wt, Sp, pro.delta, pro.ln_weight, p.N, p.K, 1, (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, pro.hout, pro.eps,
         pro.gate_epilogue);
     return finish_launch();
 }
 
-template <typename T, int PRO>
+template <typename T, int PRO, bool STRICT>
 static int launch_16_pro_any(const PackedArgs& p, const Prologue& pro) {
     const int64_t chunks = p.K / 8, Npad = (p.N + 3) & ~(int64_t)3;
     if ((size_t)p.K * sizeof(T) > 60 * 1024 || chunks > 8 * 256) return QL_ERR_UNSUPPORTED;
     const int ks = choose_ksplit(Npad / 4, p.K / 32);
 #define QL_PRO(ACH_)                                                        \
     switch (ks) {                                                           \
-    case 4: return launch_16_pro<T, ACH_, 4, PRO>(p, pro);                  \
-    case 2: return launch_16_pro<T, ACH_, 2, PRO>(p, pro);                  \
-    default: return launch_16_pro<T, ACH_, 1, PRO>(p, pro);                 \
+    case 4: return launch_16_pro<T, ACH_, 4, PRO, STRICT>(p, pro);          \
+    case 2: return launch_16_pro<T, ACH_, 2, PRO, STRICT>(p, pro);          \
+    default: return launch_16_pro<T, ACH_, 1, PRO, STRICT>(p, pro);         \
     }
     if (chunks <= 2 * 256) { QL_PRO(2) }
     if (chunks <= 4 * 256) { QL_PRO(4) }
@@ -990,22 +960,21 @@ int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, cons
     return QL_ERR_BAD_DTYPE;
 }
 
-int w4_packed_fused(int dtype, int kind, bool gate_epilogue, const void* A, const void* packed, const void* bias, void* C,
-                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
-    const PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, false, st};
-    const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
-    if (dtype == QL_DTYPE_F16) {
-        if (kind == PRO_SILU) return launch_16_pro_any<f16, PRO_SILU>(p, pro);
-        if (kind == PRO_ADDNORM)
-            return !delta && !hout ? launch_16_pro_any<f16, PRO_NORM>(p, pro) : launch_16_pro_any<f16, PRO_ADDNORM>(p, pro);
-    } else if (dtype == QL_DTYPE_BF16) {
-        if (kind == PRO_SILU) return launch_16_pro_any<__bf16, PRO_SILU>(p, pro);
-        if (kind == PRO_ADDNORM)
-            return !delta && !hout ? launch_16_pro_any<__bf16, PRO_NORM>(p, pro) : launch_16_pro_any<__bf16, PRO_ADDNORM>(p, pro);
-    } else {
-        return QL_ERR_BAD_DTYPE;
-    }
+template <typename T, bool STRICT>
+static int w4_packed_fused_t(int kind, const PackedArgs& p, const Prologue& pro) {
+    if (kind == PRO_SILU) return launch_16_pro_any<T, PRO_SILU, STRICT>(p, pro);
+    if (kind == PRO_ADDNORM)
+        return !pro.delta && !pro.hout ? launch_16_pro_any<T, PRO_NORM, STRICT>(p, pro) : launch_16_pro_any<T, PRO_ADDNORM, STRICT>(p, pro);
     return QL_ERR_UNSUPPORTED;
+}
+
+int w4_packed_fused(int dtype, int kind, bool gate_epilogue, bool strict, const void* A, const void* packed, const void* bias, void* C,
+                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, hipStream_t st) {
+    const PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, strict, st};
+    const Prologue pro{delta, ln_weight, hout, eps, gate_epilogue ? 1 : 0};
+    if (dtype == QL_DTYPE_F16) return strict ? w4_packed_fused_t<f16, true>(kind, p, pro) : w4_packed_fused_t<f16, false>(kind, p, pro);
+    if (dtype == QL_DTYPE_BF16) return strict ? w4_packed_fused_t<__bf16, true>(kind, p, pro) : w4_packed_fused_t<__bf16, false>(kind, p, pro);
+    return QL_ERR_BAD_DTYPE;
 }
 
 int w4_repack_gemv(int dtype, const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st) {
@@ -1050,12 +1019,12 @@ void w4_gemv_blocks(int64_t N, int64_t K, int64_t* w_block_bytes, int64_t* s_blo
 }
 
 // one-row forward whose output is added to the residual stream: C = round(y + resid), y = rounded sum (+ bias)
-int w4_packed_residual(int dtype, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
+int w4_packed_residual(int dtype, bool strict, const void* A, const void* packed, const void* bias, const void* resid, void* C, int64_t N,
                        int64_t K, hipStream_t st) {
-    PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, false, st};
+    PackedArgs p{A, packed, bias, C, 1, (int)N, (int)K, K, N, strict, st};
     p.resid = resid;
-    if (dtype == QL_DTYPE_F16) return launch_16_any<f16, false>(p);
-    if (dtype == QL_DTYPE_BF16) return launch_16_any<__bf16, false>(p);
+    if (dtype == QL_DTYPE_F16) return strict ? launch_16_any<f16, true>(p) : launch_16_any<f16, false>(p);
+    if (dtype == QL_DTYPE_BF16) return strict ? launch_16_any<__bf16, true>(p) : launch_16_any<__bf16, false>(p);
     return QL_ERR_UNSUPPORTED;
 }
 

@@ -71,7 +71,9 @@ class DecodeSession:
         self.n_tokens = torch.zeros(batch, dtype=torch.long, device=dev)             # real tokens per sequence so far
         self.logits: Optional[Tensor] = None
         self.graph = None
+        self._graph_key = None
         self.length = 0
+        self.busy = False                                       # a generate_ids generator is running on this session
 
     def reset(self):
         """Forget the sequences (not the captured graph): the session can serve the next generation.  Cache rows need no
@@ -144,13 +146,36 @@ class DecodeSession:
         self.pos.add_(1)
         self.mask.index_fill_(2, torch.clamp(self.write_index, max=self.capacity - 1), 0.0)
 
+    def _layout_fingerprint(self):
+        """What a captured step bakes in besides this session's own buffers: the canonical buffers' identity + version and the
+        derived layouts' addresses of every quantized module, and which path (``act_quant``) each one takes.  A graph captured
+        under another fingerprint would replay against freed / stale derived buffers (``load_state_dict`` /
+        ``apply_weights_`` / ``invalidate()`` drop them, the next forward allocates new ones) - ADVICE r2."""
+        from . import _lib
+        key = []
+        for m in self.model.modules():
+            if hasattr(m, "weight_scale") and hasattr(m, "weight"):
+                derived = tuple(None if t is None else (t[0] if isinstance(t, tuple) else t).data_ptr()
+                                for t in (getattr(m, a, None) for a in ("_packed", "_tiled", "_gated", "_gated_tiled", "_a8")))
+                key.append((_lib.buffer_key(m.weight, m.weight_scale, getattr(m, "bias", None)), derived,
+                            getattr(m, "act_quant", None)))
+        return tuple(key)
+
     @torch.no_grad()
     def capture(self, greedy: bool = True):
-        """Capture one decode step.  Every weight's derived layout must already exist (module.prepare())."""
+        """Capture one decode step (or keep the captured one while nothing it bakes in has changed)."""
         if not self.use_graph:
             return
-        if self.graph is not None and self._captured_greedy == greedy:
-            return                                              # a reused session keeps its graph (static addresses)
+        from . import _lib
+        if self.graph is not None:
+            # cheap test first (a process-wide counter every derived-layout build / drop bumps), the full fingerprint when it moved
+            if self._captured_greedy == greedy and (self._graph_epoch == _lib.layout_epoch() and
+                                                    self._graph_versions == self._canonical_versions()):
+                return                                          # a reused session keeps its graph (static addresses)
+            if self._captured_greedy == greedy and self._graph_key == self._layout_fingerprint():
+                self._graph_epoch, self._graph_versions = _lib.layout_epoch(), self._canonical_versions()
+                return
+            self.graph = None                                   # weights / layouts moved under the graph: re-capture
         saved = (self.tok.clone(), self.write_index.clone(), self.pos.clone(), self.mask.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -164,6 +189,22 @@ class DecodeSession:
         for dst, src in zip((self.tok, self.write_index, self.pos, self.mask), saved):
             dst.copy_(src)
         self._captured_greedy = greedy
+        self._graph_key = self._layout_fingerprint()            # AFTER the warm-up built the lazy layouts
+        self._graph_epoch, self._graph_versions = _lib.layout_epoch(), self._canonical_versions()
+
+    def _canonical_versions(self):
+        """Sum of the canonical buffers' version counters: moves on every in-place write autograd's bookkeeping sees
+        (``copy_`` from a loader) even when no derived layout has been rebuilt yet."""
+        total = 0
+        for m in self.model.modules():
+            if hasattr(m, "weight_scale") and hasattr(m, "weight"):
+                for t in (m.weight, m.weight_scale, getattr(m, "bias", None)):
+                    if t is not None:
+                        try:
+                            total += t._version
+                        except RuntimeError:
+                            pass
+        return total
 
     @torch.no_grad()
     def decode_step(self, token: Optional[Tensor] = None, greedy: bool = True) -> Tensor:
@@ -174,6 +215,10 @@ class DecodeSession:
         if token is not None:
             self.tok.copy_(token.to(self.device))
         if self.graph is not None and self._captured_greedy == greedy:
+            from . import _lib
+            if self._graph_epoch != _lib.layout_epoch():        # a derived layout was rebuilt / dropped since the capture
+                self.graph = None
+                self.capture(greedy)
             self.graph.replay()
         else:
             self._step_body(greedy)
@@ -200,8 +245,10 @@ class ChatGLMDecoder:
         p = self.model.final_ln.weight
         key = (p.device, p.dtype, p.data_ptr(), use_graph)
         sess = getattr(self, "_session", None)
-        if sess is not None and self._session_key == key and sess.capacity >= capacity:
+        if sess is not None and self._session_key == key and sess.capacity >= capacity and not sess.busy:
             return sess.reset()
+        if sess is not None and sess.busy:                      # an unfinished generator still owns it: leave it alone
+            return DecodeSession(self.model, 1, capacity, use_graph)
         self._session, self._session_key = DecodeSession(self.model, 1, capacity, use_graph), key
         return self._session
 
@@ -211,11 +258,21 @@ class ChatGLMDecoder:
                      prefill_chunk: Optional[int] = None, use_graph: Optional[bool] = None, sync_every_token: bool = True):
         """Yields generated token ids one by one (batch 1, like the reference, chatglm_q/decoder.py:70)."""
         prefix = list(prefix_ids)
-        budget = min(max_generated_tokens, self.max_sequence_length - len(prefix))
+        limit = min(self.max_sequence_length, self.model.config.max_sequence_length)   # the cache cannot outgrow the rotary table
+        budget = min(max_generated_tokens, limit - len(prefix))
         if budget <= 0:
             return
         capacity = min(-(-(len(prefix) + budget) // 64) * 64, self.model.config.max_sequence_length)
         sess = self._session_for(capacity, use_graph)
+        sess.busy = True
+        try:
+            yield from self._generate(sess, prefix, budget, top_k, top_p, temperature, greedy, ignore_eos, prefill_chunk,
+                                      sync_every_token)
+        finally:
+            sess.busy = False
+
+    def _generate(self, sess: DecodeSession, prefix, budget: int, top_k: int, top_p: float, temperature: float, greedy: bool,
+                  ignore_eos: bool, prefill_chunk: Optional[int], sync_every_token: bool):
         times = []
         sync = (lambda: torch.cuda.synchronize(sess.device)) if sess.device.type == "cuda" else (lambda: None)
 

@@ -87,12 +87,13 @@ SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "448")
 
 def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: Tensor, k_cache: Tensor, v_cache: Tensor,
                           mask: Tensor, n_head: int, n_groups: int, d_head: int, split: bool | None = None,
-                          prefetch: tuple | None = None) -> Tensor:
+                          prefetch: tuple | None = None, plan_out: list | None = None) -> Tensor:
     """``decode_attention(rope_kv_write(qkv, ...), ...)`` for one position per sequence in a single launch:
     qkv (B, 1, (H+2G) D) -> (B, 1, H*D); the rotated key and the value are written into the caches at
     ``write_index[0]``.  ``prefetch = (weights, kind, N, K)``: the weights of the next one-row linear on the stream
     (kind ``_lib.NEXT_W4G32_PACKED`` / ``_lib.NEXT_W8_ROWS``) are pulled into the caches by spare workgroups of this
-    launch (include/qlinear_hip.h)."""
+    launch (include/qlinear_hip.h).  ``plan_out``: a list receiving a pre-bound launch ``run(qkv)`` (``_lib.make_plan``) that
+    is valid while table / pos / write_index / caches / mask / prefetched weights stay at their addresses - the caller's key."""
     lib = _lib.get_lib()
     B, S, W = qkv.shape
     if S != 1:
@@ -101,24 +102,32 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     qkv = qkv.contiguous()
     out = torch.empty((B, 1, n_head * d_head), device=qkv.device, dtype=qkv.dtype)
     capacity = k_cache.shape[1]
+    # the kernel reads mask row b at b * capacity: a mask sliced to the filled prefix and compacted would make rows b >= 1
+    # read other sequences' columns
+    if mask.dtype != torch.float32 or mask.numel() != B * capacity or mask.shape[-1] != capacity or not mask.is_contiguous():
+        raise ValueError(f"decode_attention_rope: mask must be a contiguous fp32 (B, 1, capacity) = ({B}, 1, {capacity}) tensor, "
+                         f"got {tuple(mask.shape)} {mask.dtype}")
     if split is None:
         # 16 heads per key/value group (16-bit, D = 128): the group kernel takes one 256-position window per block
         group_kernel = qkv.dtype != torch.float32 and d_head == 128 and n_head == 16 * n_groups and GROUP_ATTENTION
         split = capacity > 256 if group_kernel else capacity >= SPLIT_ATTENTION_FROM
+    pos_c = pos.contiguous()
     with torch.cuda.device(qkv.device):
         ws_bytes = int(lib.qlinear_decode_attention_split_bytes(B, n_head, d_head, capacity)) if split else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes else None
-        args = (qkv.data_ptr(), table.data_ptr(), pos.contiguous().data_ptr(), write_index.data_ptr(), k_cache.data_ptr(),
-                v_cache.data_ptr(), mask.data_ptr(), out.data_ptr(), B, n_head, n_groups, d_head, capacity, W,
-                _lib.dtype_code(qkv.dtype), _lib.ptr(ws), ws_bytes)
+        const = (table.data_ptr(), pos_c.data_ptr(), write_index.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), mask.data_ptr())
+        shape = (B, n_head, n_groups, d_head, capacity, W, _lib.dtype_code(qkv.dtype))
         if prefetch is not None and PREFETCH_NEXT:
             weights, kind, n_next, k_next = prefetch
-            st = lib.qlinear_decode_attention_rope_prefetch(*args, weights.data_ptr(), kind, n_next, k_next,
-                                                            _lib.stream_ptr(qkv.device))
-            _lib.check(st, "qlinear_decode_attention_rope_prefetch")
+            name, tail = "qlinear_decode_attention_rope_prefetch", (weights.data_ptr(), kind, n_next, k_next)
         else:
-            st = lib.qlinear_decode_attention_rope(*args, _lib.stream_ptr(qkv.device))
-            _lib.check(st, "qlinear_decode_attention_rope")
+            weights, name, tail = None, "qlinear_decode_attention_rope", ()
+        st = getattr(lib, name)(qkv.data_ptr(), *const, out.data_ptr(), *shape, _lib.ptr(ws), ws_bytes, *tail, _lib.stream_ptr(qkv.device))
+        _lib.check(st, name)
+    if plan_out is not None and pos_c is pos:
+        plan_out.append(_lib.make_plan(name, (None, *const, None, *shape, None, ws_bytes, *tail, None), 0, 7, 17 + len(tail), B, W,
+                                       n_head * d_head, qkv.dtype, qkv.device, (), ws_slot=15 if ws_bytes else None, ws_bytes=ws_bytes,
+                                       keep=(table, pos, write_index, k_cache, v_cache, mask, weights)))
     return out
 
 

@@ -152,11 +152,14 @@ def tile_w4g32(gemv: Tensor, N: int, K: int, dtype: torch.dtype) -> Tensor:
 
 
 def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
-               packed: Tensor | None = None, strict: bool | None = None, tiled: Tensor | None = None) -> Tensor:
+               packed: Tensor | None = None, strict: bool | None = None, tiled: Tensor | None = None,
+               plan_out: list | None = None) -> Tensor:
     """``a @ dequant(b, b_scale) (+ bias)`` on the GPU.  ``packed`` selects the derived-layout kernels: a buffer of
     ``repack_w4g32`` (both parts, any row count) or of ``repack_w4g32_gemv`` (part 1: rows <= GEMV_MAX_ROWS, fp32 any);
-    ``tiled`` (part 2, ``tile_w4g32``) serves fp16 / bf16 at any row count.  ``strict`` (default: env QLINEAR_STRICT) asks
-    for the reference's per-weight rounding bit for bit (the canonical-layout and MFMA kernels always round that way)."""
+    ``tiled`` (part 2, ``tile_w4g32``) serves fp16 / bf16 at any row count.  ``strict`` asks for the reference's per-weight
+    rounding bit for bit (the canonical-layout and MFMA kernels always round that way); default: the package policy
+    (``_lib.strict_for``: env QLINEAR_STRICT, else strict for bf16 only).  ``plan_out``: a list that receives a pre-bound
+    launch (``_lib.make_plan``) for later calls of the same shape when the call went through a derived layout."""
     _check_w4_args(a, b, b_scale)
     _check_row_operands("w4_forward", a, a.shape[-1], bias=bias)
     lib = _lib.get_lib()
@@ -169,9 +172,10 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     if M == 0:
         return c.reshape(out_shape)
     code = _lib.dtype_code(a.dtype)
-    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.STRICT_DEFAULT if strict is None else strict) else 0
+    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.strict_for(a.dtype) if strict is None else strict) else 0
     if bias is not None:
         bias = bias.contiguous()
+    plannable = plan_out is not None and a.is_contiguous() and a.data_ptr() % 16 == 0
     with torch.cuda.device(a.device):
         stream = _lib.stream_ptr(a.device)
         mfma_rows = group == 32 and rows_on_tiled(M, N, K, a.dtype, bool(flags & _lib.FLAG_STRICT_ROUNDING))
@@ -184,6 +188,11 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
             st = lib.qlinear_w4g32_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K, group,
                                              a2.stride(0) if M > 1 else K, N, code, _lib.ptr(ws), ws_bytes, stream)
             _lib.check(st, "qlinear_w4g32_fwd_tiled")
+            if plannable:
+                plan_out.append(_lib.make_plan(
+                    "qlinear_w4g32_fwd_tiled", (None, tiled.data_ptr(), _lib.ptr(bias), None, M, N, K, group, K, N, code, None, ws_bytes, None),
+                    0, 3, 13, M, K, N, a.dtype, a.device, (b, b_scale, bias), ws_slot=11 if ws_bytes else None, ws_bytes=ws_bytes,
+                    keep=(tiled, bias)))
         elif packed is not None:
             need = packed_nbytes(N, K, a.dtype, group) if mfma_rows else gemv_nbytes(N, K, a.dtype, group)
             if packed.device != a.device or packed.numel() < need:
@@ -196,6 +205,12 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
                                               group, a2.stride(0) if M > 1 else K, N, code, flags, _lib.ptr(ws),
                                               ws_bytes, stream)
             _lib.check(st, "qlinear_w4g32_fwd_packed")
+            if plannable:
+                plan_out.append(_lib.make_plan(
+                    "qlinear_w4g32_fwd_packed", (None, packed.data_ptr(), _lib.ptr(bias), None, M, N, K, group, K, N, code, flags, None,
+                                                 ws_bytes, None),
+                    0, 3, 14, M, K, N, a.dtype, a.device, (b, b_scale, bias), ws_slot=12 if ws_bytes else None, ws_bytes=ws_bytes,
+                    keep=(packed, bias)))
         else:
             if not b.is_contiguous():
                 b = b.contiguous()
@@ -324,11 +339,13 @@ def gate_interleave(hidden: int, device=None) -> Tensor:
 
 def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None = None,
                      delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
-                     eps: float = 0.0) -> Tensor:
+                     eps: float = 0.0, strict: bool | None = None, plan_out: list | None = None, guards=()) -> Tensor:
     """One-row forward with an activation prologue (``_lib.PRO_SILU`` / ``_lib.PRO_ADDNORM``, optionally OR-ed with
     ``_lib.EPI_SILU_GATE``) on the derived layout.  ``a``: (..., K) for ADDNORM, (..., 2K) for SILU, exactly one
     row; ``n_out`` = number of packed columns.  Returns (..., n_out), or (..., n_out / 2) with the gate epilogue
-    (``packed`` then holds the gate-interleaved column order, see ``gate_interleave``)."""
+    (``packed`` then holds the gate-interleaved column order, see ``gate_interleave``).  ``strict``: as ``w4_forward``.
+    ``plan_out`` / ``guards``: a list receiving a pre-bound launch ``run(a, delta, hout)`` valid while ``guards`` (the
+    canonical buffers ``packed`` was built from) stay unchanged."""
     lib = _lib.get_lib()
     K = a.shape[-1] // 2 if (kind & 0xFF) == _lib.PRO_SILU else a.shape[-1]
     if a.numel() != a.shape[-1]:
@@ -336,13 +353,23 @@ def w4_forward_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias: Ten
     _check_row_operands("w4_forward_fused", a, a.shape[-1], bias=bias, delta=delta, ln_weight=ln_weight, hout=hout)
     if packed.device != a.device or packed.numel() < gemv_nbytes(n_out, K, a.dtype):
         raise AssertionError("w4_forward_fused: packed buffer on another device or too small for (n_out, K)")
+    if _lib.strict_for(a.dtype) if strict is None else strict:
+        kind |= _lib.FUSED_STRICT
     a = a.contiguous()
-    c = torch.empty((*a.shape[:-1], n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out), device=a.device, dtype=a.dtype)
+    cols = n_out // 2 if kind & _lib.EPI_SILU_GATE else n_out
+    c = torch.empty((*a.shape[:-1], cols), device=a.device, dtype=a.dtype)
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w4g32_fwd_packed_fused(kind, a.data_ptr(), packed.data_ptr(), _lib.ptr(bias), c.data_ptr(),
                                                 n_out, K, _lib.ptr(delta), _lib.ptr(ln_weight), _lib.ptr(hout),
-                                                float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+                                                float(eps), code, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w4g32_fwd_packed_fused")
+    if plan_out is not None:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w4g32_fwd_packed_fused", (kind, None, packed.data_ptr(), _lib.ptr(bias), None, n_out, K, None, _lib.ptr(ln_weight),
+                                               None, float(eps), code, None),
+            1, 4, 12, 1, a.shape[-1], cols, a.dtype, a.device, (*guards, bias, ln_weight), keep=(packed, bias, ln_weight),
+            extras=((7, K), (9, K))))
     return c
 
 
@@ -377,23 +404,30 @@ def w4_forward_gated(a: Tensor, gated: Tensor, n_out: int, bias: Tensor | None, 
     return c.reshape(*a.shape[:-1], n_out // 2)
 
 
-def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, residual: Tensor) -> Tensor:
+def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, residual: Tensor,
+                        strict: bool | None = None, plan_out: list | None = None, guards=()) -> Tensor:
     """One-row forward added to the residual stream in the kernel's epilogue: round(y + residual), y = the layer's
-    rounded output (``qlinear_w4g32_fwd_packed_residual``)."""
+    rounded output (``qlinear_w4g32_fwd_packed_residual``).  ``plan_out`` / ``guards``: as ``w4_forward_fused``; the plan is
+    ``run(a, residual)``."""
     lib = _lib.get_lib()
     if a.numel() != a.shape[-1] or residual.numel() != n_out:
         raise ValueError("the residual epilogue serves exactly one row")
     _check_row_operands("w4_forward_residual", a, a.shape[-1], bias=bias, residual=residual)
     if packed.device != a.device or packed.numel() < gemv_nbytes(n_out, a.shape[-1], a.dtype):
         raise AssertionError("w4_forward_residual: packed buffer on another device or too small for (n_out, K)")
+    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.strict_for(a.dtype) if strict is None else strict) else 0
     a = a.contiguous()
     residual = residual.contiguous()
     c = torch.empty((*a.shape[:-1], n_out), device=a.device, dtype=a.dtype)
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w4g32_fwd_packed_residual(a.data_ptr(), packed.data_ptr(), _lib.ptr(bias), residual.data_ptr(),
-                                                   c.data_ptr(), n_out, a.shape[-1], _lib.dtype_code(a.dtype),
-                                                   _lib.stream_ptr(a.device))
+                                                   c.data_ptr(), n_out, a.shape[-1], code, flags, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w4g32_fwd_packed_residual")
+    if plan_out is not None:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w4g32_fwd_packed_residual", (None, packed.data_ptr(), _lib.ptr(bias), None, None, n_out, a.shape[-1], code, flags, None),
+            0, 4, 9, 1, a.shape[-1], n_out, a.dtype, a.device, (*guards, bias), keep=(packed, bias), extras=((3, n_out),)))
     return c
 
 

@@ -116,6 +116,10 @@ class DynamicQuantizeLinear(nn.Module):
         self._gated, self._gated_key = None, None
         self._gated_tiled, self._gated_tiled_key = None, None
         self._a8, self._a8_key = None, None
+        # pre-bound launches (``_lib.make_plan``): forward() by input.numel(), the fused one-row launches of the decode step by
+        # call site; built by the checked path after it served a call, dropped with the derived layouts
+        self._plans: dict = {}
+        self._fast: dict = {}
         # opt-in int8-activation path (W4A8, i8 MFMA): False | True (row-wise scales) | "per_tensor".  NOT bit-compatible
         # with the weight-only path (activation quantisation error ~1e-2 relative): include/qlinear_hip.h
         self.act_quant = False
@@ -132,7 +136,38 @@ class DynamicQuantizeLinear(nn.Module):
         self._gated, self._gated_key = None, None
         self._gated_tiled, self._gated_tiled_key = None, None
         self._a8, self._a8_key = None, None
+        self._plans, self._fast = {}, {}
+        _lib.bump_layout_epoch()
         return self
+
+    def release(self, *parts: str):
+        """Free derived layouts a deployment no longer needs (they are caches: anything released is rebuilt on demand).
+        ``parts``: any of "packed" (part 1, the GEMVs), "tiled" (part 2, the MFMA kernels), "gated" (gate-interleaved part 1 of
+        a first MLP projection), "gated_tiled", "a8" (W4A8 copy).  E.g. a decode-only session keeps "packed" for
+        qkv_proj / o_proj / w_out / lm_head and only "gated" for w_in: ``w_in.release("packed", "tiled", "gated_tiled")``."""
+        for part in parts:
+            if part not in ("packed", "tiled", "gated", "gated_tiled", "a8"):
+                raise ValueError(f"unknown derived layout {part!r}")
+            setattr(self, "_" + part, None)
+            setattr(self, "_" + part + "_key", None)
+        self._plans, self._fast = {}, {}
+        _lib.bump_layout_epoch()
+        return self
+
+    def derived_nbytes(self) -> dict:
+        """Resident bytes of each derived layout (0 when not built) next to the canonical buffers'."""
+        def nb(t):
+            t = t[0] if isinstance(t, tuple) else t
+            return 0 if t is None else t.numel() * t.element_size()
+        out = {k: nb(getattr(self, "_" + k)) for k in ("packed", "tiled", "gated", "gated_tiled", "a8")}
+        out["canonical"] = nb(self.weight) + nb(self.weight_scale)
+        return out
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name in ("weight", "weight_scale", "bias", "act_quant") and "_plans" in self.__dict__:
+            self._plans, self._fast = {}, {}        # a replaced buffer / another path: the pre-bound launches are stale
+            _lib.bump_layout_epoch()
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -158,7 +193,10 @@ class DynamicQuantizeLinear(nn.Module):
         if self._packed is None or self._packed_key != key:
             self._packed = hip_ops.repack_w4g32_gemv(self.weight, self.weight_scale)
             self._packed_key = key
-        if hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, self.weight_scale.dtype, _lib.STRICT_DEFAULT):
+            self._plans, self._fast = {}, {}
+            _lib.bump_layout_epoch()
+        dt = self.weight_scale.dtype
+        if hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, dt, _lib.strict_for(dt)):
             self.tiled()
         return self
 
@@ -171,6 +209,7 @@ class DynamicQuantizeLinear(nn.Module):
             self.prepare()
             self._tiled = hip_ops.tile_w4g32(self._packed, self.out_features, self.in_features, self.weight_scale.dtype)
             self._tiled_key = key
+            _lib.bump_layout_epoch()
         return self._tiled
 
     @torch.no_grad()
@@ -188,6 +227,8 @@ class DynamicQuantizeLinear(nn.Module):
             bias = self.bias.index_select(0, perm) if self.bias is not None else None
             self._gated, self._gated_key = (packed, bias), key
             self._gated_tiled, self._gated_tiled_key = None, None
+            self._fast = {}
+            _lib.bump_layout_epoch()
         return self._gated
 
     @torch.no_grad()
@@ -199,9 +240,17 @@ class DynamicQuantizeLinear(nn.Module):
         if self._gated_tiled is None or self._gated_tiled_key != key:
             self._gated_tiled = hip_ops.tile_w4g32(packed, self.out_features, self.in_features, self.weight_scale.dtype)
             self._gated_tiled_key = key
+            _lib.bump_layout_epoch()
         return self._gated_tiled, bias
 
     def forward(self, input: Tensor):
+        # fast path: a pre-bound launch for this row count (built below by the checked path); it re-validates input layout,
+        # buffer identity and version counters itself and returns None when anything moved
+        plan = self._plans.get(input.numel())
+        if plan is not None:
+            out = plan(input)
+            if out is not None:
+                return out
         if check_input(input):
             if input.requires_grad and torch.is_grad_enabled():
                 out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
@@ -212,19 +261,26 @@ class DynamicQuantizeLinear(nn.Module):
                 key = self._canonical_key()
                 if self._a8 is None or self._a8_key != key:
                     self._a8, self._a8_key = hip_ops.pack_w4a8(self.weight, self.weight_scale), key
+                    _lib.bump_layout_epoch()
                 return hip_ops.w4a8_forward(input, self._a8, self.out_features, self.bias,
                                             per_tensor=self.act_quant == "per_tensor")
             rows = input.numel() // max(input.shape[-1], 1)
             packed = tiled = None
             half = input.dtype in (torch.float16, torch.bfloat16)
             if (rows <= PACKED_MAX_ROWS or half) and self._packed_supported() and input.dtype == self.weight_scale.dtype:
-                if half and hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, input.dtype, _lib.STRICT_DEFAULT):
+                if half and hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, input.dtype, _lib.strict_for(input.dtype)):
                     tiled = self.tiled()
                 else:
                     packed = self.prepare()._packed
             # bias is added inside the kernel epilogue AFTER the rounding to the output dtype,
             # i.e. the same two roundings as "out = matmul(); out += bias" (qlinear.py:90-94)
-            return hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed, tiled=tiled)
+            plan_out = [] if (packed is not None or tiled is not None) and rows > 0 and not self.act_quant else None
+            out = hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed, tiled=tiled, plan_out=plan_out)
+            if plan_out and plan_out[0] is not None:
+                if len(self._plans) >= 16:                 # row counts seen so far (prefill chunks): keep the table small
+                    self._plans.clear()
+                self._plans[input.numel()] = plan_out[0]
+            return out
         out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
         if self.bias is not None:
             out += self.bias

@@ -40,7 +40,7 @@ def _check_w8_args(a: Tensor, b: Tensor, b_scale: Tensor):
 
 
 def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
-               strict: bool | None = None) -> Tensor:
+               strict: bool | None = None, plan_out: list | None = None, guards=()) -> Tensor:
     """``a @ (b * b_scale) (+ bias)``; ``b`` is the logical (K, N) int8 matrix with ANY strides - the
     module passes ``weight.t()`` (strides (1, K)), the reference test a contiguous (K, N)."""
     _check_w8_args(a, b, b_scale)
@@ -61,15 +61,22 @@ def w8_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
         bias = bias.contiguous()
     ldw_k = b.stride(0) if K > 1 else 1
     ldw_n = b.stride(1) if N > 1 else max(K, 1)
+    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.strict_for(a.dtype) if strict is None else strict) else 0
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         # few-row GEMMs split K over workgroups into an fp32 workspace (0 bytes for M <= 4 and for large M)
         ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8_FWD, M, N, K, 0)) if M > 4 and ldw_k == 1 else 0
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
         st = lib.qlinear_w8_fwd(a2.data_ptr(), b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, N, K,
-                                ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, _lib.dtype_code(a.dtype),
-                                _lib.FLAG_STRICT_ROUNDING if (_lib.STRICT_DEFAULT if strict is None else strict) else 0,
+                                ldw_k, ldw_n, a2.stride(0) if M > 1 else K, N, code, flags,
                                 _lib.ptr(ws), ws_bytes, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd")
+    if plan_out is not None and a.is_contiguous() and a.data_ptr() % 16 == 0:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w8_fwd", (None, b.data_ptr(), b_scale.data_ptr(), _lib.ptr(bias), None, M, N, K, ldw_k, ldw_n, K, N, code, flags,
+                               None, ws_bytes, None),
+            0, 4, 16, M, K, N, a.dtype, a.device, (*guards, b_scale, bias), ws_slot=14 if ws_bytes else None, ws_bytes=ws_bytes,
+            keep=(b, b_scale, bias)))
     return c.reshape(out_shape)
 
 
@@ -97,7 +104,8 @@ def w8_tiled_supported(a: Tensor, weight_nk: Tensor) -> bool:
             and a.numel() // max(a.shape[-1], 1) > 2)
 
 
-def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None,
+                     plan_out: list | None = None, guards=()) -> Tensor:
     """``a @ (W * scale).T (+ bias)`` for >= 3 rows on the tile-major copy (few-row kernel / tiled MFMA GEMM)."""
     lib = _lib.get_lib()
     a2 = _rows(a)
@@ -110,19 +118,27 @@ def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias
     c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
     if bias is not None:
         bias = bias.contiguous()
+    w_scale = w_scale.contiguous()
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W8_FWD_TILED, M, n_out, K, 0))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
-        st = lib.qlinear_w8_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(), _lib.ptr(bias), c.data_ptr(),
-                                      M, n_out, K, a2.stride(0) if M > 1 else K, n_out, _lib.dtype_code(a.dtype), _lib.ptr(ws),
+        st = lib.qlinear_w8_fwd_tiled(a2.data_ptr(), tiled.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                      M, n_out, K, a2.stride(0) if M > 1 else K, n_out, code, _lib.ptr(ws),
                                       ws_bytes, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd_tiled")
+    if plan_out is not None and a.is_contiguous() and a.data_ptr() % 16 == 0:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w8_fwd_tiled", (None, tiled.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), None, M, n_out, K, K, n_out, code, None,
+                                     ws_bytes, None),
+            0, 4, 13, M, K, n_out, a.dtype, a.device, (*guards, w_scale, bias), ws_slot=11 if ws_bytes else None, ws_bytes=ws_bytes,
+            keep=(tiled, w_scale, bias)))
     return c.reshape(*a.shape[:-1], n_out)
 
 
 def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None,
                      delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
-                     eps: float = 0.0) -> Tensor:
+                     eps: float = 0.0, plan_out: list | None = None, guards=()) -> Tensor:
     """One-row fp16 forward with the add + RMSNorm prologue (``_lib.PRO_ADDNORM``, optionally ``| _lib.EPI_SILU_GATE``
     on gate-interleaved rows, see ``int4.hip_ops.gate_interleave``).  ``weight_nk``: the module's (N, K) buffer."""
     lib = _lib.get_lib()
@@ -133,16 +149,25 @@ def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, b
     if weight_nk.dtype != torch.int8 or weight_nk.device != a.device or w_scale.numel() != N:
         raise AssertionError("w8_forward_fused: weight must be int8 (N, K) on the activations' device with N scales")
     a = a.contiguous()
-    c = torch.empty((*a.shape[:-1], N // 2 if kind & _lib.EPI_SILU_GATE else N), device=a.device, dtype=a.dtype)
+    cols = N // 2 if kind & _lib.EPI_SILU_GATE else N
+    c = torch.empty((*a.shape[:-1], cols), device=a.device, dtype=a.dtype)
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w8_fwd_fused(kind, a.data_ptr(), weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(),
                                       N, K, weight_nk.stride(0), _lib.ptr(delta), _lib.ptr(ln_weight), _lib.ptr(hout),
-                                      float(eps), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+                                      float(eps), code, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd_fused")
+    if plan_out is not None:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w8_fwd_fused", (kind, None, weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), None, N, K, weight_nk.stride(0),
+                                     None, _lib.ptr(ln_weight), None, float(eps), code, None),
+            1, 5, 14, 1, K, cols, a.dtype, a.device, (*guards, weight_nk, w_scale, bias, ln_weight),
+            keep=(weight_nk, w_scale, bias, ln_weight), extras=((9, K), (11, K))))
     return c
 
 
-def w8_forward_residual(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None, residual: Tensor) -> Tensor:
+def w8_forward_residual(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None, residual: Tensor,
+                        plan_out: list | None = None, guards=()) -> Tensor:
     """One-row fp16 forward added to the residual stream in the kernel's epilogue (``qlinear_w8_fwd_residual``)."""
     lib = _lib.get_lib()
     N, K = weight_nk.shape
@@ -154,11 +179,18 @@ def w8_forward_residual(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Ten
     a = a.contiguous()
     residual = residual.contiguous()
     c = torch.empty((*a.shape[:-1], N), device=a.device, dtype=a.dtype)
+    code = _lib.dtype_code(a.dtype)
     with torch.cuda.device(a.device):
         st = lib.qlinear_w8_fwd_residual(a.data_ptr(), weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias),
                                          residual.data_ptr(), c.data_ptr(), N, K, weight_nk.stride(0),
-                                         _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+                                         code, _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_w8_fwd_residual")
+    if plan_out is not None:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w8_fwd_residual", (None, weight_nk.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), None, None, N, K,
+                                        weight_nk.stride(0), code, None),
+            0, 5, 10, 1, K, N, a.dtype, a.device, (*guards, weight_nk, w_scale, bias), keep=(weight_nk, w_scale, bias),
+            extras=((4, N),)))
     return c
 
 

@@ -67,16 +67,44 @@ class DynamicQuantizeLinear(nn.Module):
             self.register_buffer("bias", torch.empty(out_features, device=device, dtype=dtype))
         else:
             self.register_buffer("bias", None)
-        self.act_quant = False
         self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._plans: dict = {}            # pre-bound launches (``_lib.make_plan``): forward() by input.numel() ...
+        self._fast: dict = {}             # ... and the fused one-row launches of the decode step by call site
+        self.act_quant = False
 
     def invalidate(self):
         """Drop the derived copies (tile-major weights, gate-interleaved rows); rebuilt on the next GPU forward.  Needed
         only after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
         self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._plans, self._fast = {}, {}
+        _lib.bump_layout_epoch()
         return self
+
+    def release(self, *parts: str):
+        """Free derived copies a deployment no longer needs ("tiled", "gated"); rebuilt on demand."""
+        for part in parts:
+            if part not in ("tiled", "gated"):
+                raise ValueError(f"unknown derived layout {part!r}")
+            setattr(self, "_" + part, None)
+            setattr(self, "_" + part + "_key", None)
+        self._plans, self._fast = {}, {}
+        _lib.bump_layout_epoch()
+        return self
+
+    def derived_nbytes(self) -> dict:
+        def nb(t):
+            if isinstance(t, tuple):
+                return sum(nb(x) for x in t)
+            return 0 if t is None else t.numel() * t.element_size()
+        return {"tiled": nb(self._tiled), "gated": nb(self._gated), "canonical": nb(self.weight) + nb(self.weight_scale)}
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name in ("weight", "weight_scale", "bias", "act_quant") and "_plans" in self.__dict__:
+            self._plans, self._fast = {}, {}
+            _lib.bump_layout_epoch()
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -87,6 +115,11 @@ class DynamicQuantizeLinear(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def forward(self, input: Tensor):
+        plan = self._plans.get(input.numel())      # pre-bound launch for this row count (re-validates buffers and input)
+        if plan is not None:
+            out = plan(input)
+            if out is not None:
+                return out
         if check_input(input) and not (input.requires_grad and torch.is_grad_enabled()):
             if self.act_quant:
                 if self.in_features % 16 == 0:
@@ -95,11 +128,20 @@ class DynamicQuantizeLinear(nn.Module):
                     return hip_ops.w8a8_forward_tiled(input, self.prepare()._tiled, self.out_features, self.weight_scale,
                                                       self.bias, per_tensor=self.act_quant == "per_tensor")
                 return hip_ops.w8a8_forward(input, self.weight, self.weight_scale, self.bias)
+            plan_out = [] if input.numel() else None
             if hip_ops.w8_tiled_supported(input, self.weight):
                 # >= 3 rows: MFMA kernels on the tile-major derived copy (built lazily, keyed on the buffer's version)
-                return hip_ops.w8_forward_tiled(input, self.prepare()._tiled, self.out_features, self.weight_scale, self.bias)
-            # bias fused after the output rounding: same two roundings as qlinear.py:90-93
-            return hip_ops.w8_forward(input, self.weight.t(), self.weight_scale, self.bias)
+                out = hip_ops.w8_forward_tiled(input, self.prepare()._tiled, self.out_features, self.weight_scale, self.bias,
+                                               plan_out=plan_out, guards=(self.weight,))
+            else:
+                # bias fused after the output rounding: same two roundings as qlinear.py:90-93
+                out = hip_ops.w8_forward(input, self.weight.t(), self.weight_scale, self.bias, plan_out=plan_out,
+                                         guards=(self.weight,))
+            if plan_out and plan_out[0] is not None:
+                if len(self._plans) >= 16:
+                    self._plans.clear()
+                self._plans[input.numel()] = plan_out[0]
+            return out
         out = dynamic_quant_matmul(input, self.weight.t(), self.weight_scale)
         if self.bias is not None:
             out = out + self.bias              # not in place: the Function's output may be a view
@@ -112,6 +154,8 @@ class DynamicQuantizeLinear(nn.Module):
         if self._tiled is None or self._tiled_key != key:
             self._tiled = hip_ops.tile_w8(self.weight) if self.weight.is_cuda and self.in_features % 16 == 0 else None
             self._tiled_key = key
+            self._plans, self._fast = {}, {}
+            _lib.bump_layout_epoch()
         return self
 
     @torch.no_grad()
@@ -128,6 +172,8 @@ class DynamicQuantizeLinear(nn.Module):
             self._gated = (self.weight.index_select(0, perm).contiguous(), self.weight_scale.index_select(0, perm).contiguous(),
                            None if self.bias is None else self.bias.index_select(0, perm).contiguous())
             self._gated_key = key
+            self._fast = {}
+            _lib.bump_layout_epoch()
         return self._gated
 
     @torch.no_grad()

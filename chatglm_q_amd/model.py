@@ -100,6 +100,7 @@ class KVCache:
         self.v = [torch.zeros(batch, capacity, groups, d_head, device=device, dtype=dtype) for _ in range(n_layers)]
         self.capacity = capacity
         self.length = 0            # host-side count of valid positions (not used inside captured graphs)
+        self.att_plans: dict = {}  # layer -> (layout epoch, operand addresses, pre-bound attention launch); model._step_one_row
 
     def as_tuples(self):
         """Reference-shaped view: tuple of (k, v) each (batch, length, groups, 1, d_head)."""
@@ -226,9 +227,12 @@ class ChatGLM2Model(nn.Module):
         steps) promises that every cache row >= kv_len is masked: attention then reads only the first kv_len
         rows - the same sums, since a masked column's probability is exactly 0 (prefill uses this)."""
         h = self.word_embedding(input_ids)
+        fused = FUSED_DECODE_OPS and h.is_cuda
+        if fused and h.shape[1] == 1:
+            kv_len = None                              # the one-position kernels take the whole cache + the FULL-capacity mask
         if kv_len is not None:
             mask = mask[..., :kv_len]
-        if FUSED_DECODE_OPS and h.is_cuda:
+        if fused:
             return self._step_fused(h, cache, write_index, position_ids, mask, last_only, kv_len)
         cs = self._rotary(position_ids)
         for i, layer in enumerate(self.layers):
@@ -248,8 +252,8 @@ class ChatGLM2Model(nn.Module):
         c = self.config
         H, G, D = c.num_attention_heads, c.num_multi_query_groups, c.head_hidden_size
         B, S, _ = h.shape
-        if S == 1:
-            kv_len = None                              # the one-position kernels take the whole cache + mask
+        if S == 1 and (kv_len is not None or mask.shape[-1] != cache.capacity):
+            raise ValueError("one-position steps take the full-capacity mask (B, 1, capacity) and no kv_len")
         mask = mask.contiguous()
         if B * S == 1 and h.dtype in (torch.float16, torch.bfloat16):
             kind = self._one_row_kind(h.dtype)
@@ -303,7 +307,7 @@ class ChatGLM2Model(nn.Module):
         from .int4 import hip_ops as H4
         from .int4.qlinear import DynamicQuantizeLinear as Q4
         if not (isinstance(mod, Q4) and mod._packed_supported() and not mod.act_quant and mod.weight_scale.dtype == h.dtype
-                and not _lib.STRICT_DEFAULT):
+                and not _lib.strict_for(h.dtype)):         # the 4x4x4-MFMA kernel computes in the exact-dequant arithmetic only
             return None
         if gate_hidden:
             if mod.out_features != 2 * gate_hidden or gate_hidden % 2:
@@ -321,12 +325,17 @@ class ChatGLM2Model(nn.Module):
         when layer / shape are not served that way."""
         from .int4 import hip_ops as H4
         from .int4.qlinear import DynamicQuantizeLinear as Q4
+        from . import _lib
         w_in = ffn.w_in
         if not (isinstance(w_in, Q4) and x.dtype in (torch.float16, torch.bfloat16) and w_in._packed_supported()
+                and not w_in.act_quant and w_in.weight_scale.dtype == x.dtype
                 and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0):
             return None
         rows = x.numel() // x.shape[-1]
-        if not H4.rows_on_tiled(rows, w_in.out_features, w_in.in_features, x.dtype):
+        strict = _lib.strict_for(x.dtype)
+        if not H4.rows_on_tiled(rows, w_in.out_features, w_in.in_features, x.dtype, strict):
+            if strict:                                     # rows the strict policy keeps on the VALU GEMV: no gated variant of it
+                return None
             packed, bias = w_in.gated_packed(ffn.hidden_dim)
             return H4.w4_forward_gated(x, packed, w_in.out_features, bias, part1=True)
         tiled, bias = w_in.gated_tiled(ffn.hidden_dim)
@@ -336,13 +345,18 @@ class ChatGLM2Model(nn.Module):
         """"int4" / "int8" when every QLinear of the graph can take the fused one-row launches, else None."""
         from .int4.qlinear import DynamicQuantizeLinear as Q4
         from .int8.qlinear import DynamicQuantizeLinear as Q8
+        from . import _lib
+        cached = self.__dict__.get("_kind_cache")          # 113 isinstance / layout checks per token otherwise; every change
+        if cached is not None and cached[0] == (_lib.layout_epoch(), dtype):   # they depend on bumps the layout epoch
+            return cached[1]
         mods = [self.lm_head] + [m for l in self.layers for m in (l.attn.qkv_proj, l.attn.o_proj, l.ffn.w_in, l.ffn.w_out)]
         kind = None
-        if all(isinstance(m, Q4) and m._packed_supported() for m in mods):
+        if all(isinstance(m, Q4) and m._packed_supported() and not m.act_quant and m.weight_scale.dtype == dtype for m in mods):
             kind = "int4"
         elif dtype == torch.float16 and self.config.hidden_size <= 16384 and all(
                 isinstance(m, Q8) and not m.act_quant and m.in_features % 16 == 0 and m.weight.is_contiguous() for m in mods):
             kind = "int8"
+        self.__dict__["_kind_cache"] = ((_lib.layout_epoch(), dtype), kind)
         return kind
 
     def _step_one_row(self, h: Tensor, cache: KVCache, write_index: Tensor, position_ids: Tensor, mask: Tensor,
@@ -356,14 +370,30 @@ class ChatGLM2Model(nn.Module):
         c = self.config
         H, G, D = c.num_attention_heads, c.num_multi_query_groups, c.head_hidden_size
 
-        def norm_linear(mod, x, delta, ln, hout, gate_hidden=None):
-            """mod(rmsnorm(x + delta)) with the updated residual stream written to hout; optional SiLU * gate."""
+        # Every launch of the step goes through a pre-bound plan (``_lib.make_plan``) once the checked wrapper has served the
+        # call site: mod._fast[site] for the QLinear launches, cache.att_plans[layer] for the attention launch.  A plan
+        # re-validates buffers / operands itself and returns None to fall back to the checked wrapper (which rebuilds it).
+        def norm_linear(mod, x, ln, gate_hidden=None):
+            """mod(rmsnorm(x)) (the residual adds run in the epilogues of o_proj / w_out); optional SiLU * gate epilogue."""
+            site = ("norm", gate_hidden)
+            plan = mod._fast.get(site)
+            if plan is not None:
+                out = plan(x, None, None)
+                if out is not None:
+                    return out
             flags = _lib.PRO_ADDNORM | (_lib.EPI_SILU_GATE if gate_hidden else 0)
+            plan_out = []
             if kind == "int4":
                 packed, bias = mod.gated_packed(gate_hidden) if gate_hidden else (mod.prepare()._packed, mod.bias)
-                return H4.w4_forward_fused(flags, x, packed, mod.out_features, bias, delta, ln.weight, hout, ln.eps)
-            w, sc, bias = mod.gated(gate_hidden) if gate_hidden else (mod.weight, mod.weight_scale, mod.bias)
-            return H8.w8_forward_fused(flags, x, w, sc, bias, delta, ln.weight, hout, ln.eps)
+                out = H4.w4_forward_fused(flags, x, packed, mod.out_features, bias, None, ln.weight, None, ln.eps,
+                                          plan_out=plan_out, guards=(mod.weight, mod.weight_scale))
+            else:
+                w, sc, bias = mod.gated(gate_hidden) if gate_hidden else (mod.weight, mod.weight_scale, mod.bias)
+                out = H8.w8_forward_fused(flags, x, w, sc, bias, None, ln.weight, None, ln.eps, plan_out=plan_out,
+                                          guards=(mod.weight, mod.weight_scale, mod.bias))
+            if plan_out[0] is not None:
+                mod._fast[site] = plan_out[0]
+            return out
 
         # The residual adds run in the EPILOGUES of o_proj / w_out (round(y + h)), so the RMSNorm prologues of qkv_proj /
         # w_in / lm_head stage two operands instead of three in every workgroup.  SiLU * gate runs in w_in's EPILOGUE on a
@@ -372,30 +402,66 @@ class ChatGLM2Model(nn.Module):
         # redid the 13696 exponentials.)  The attention launch is a chain of round trips on B * G workgroups: its spare
         # workgroups read o_proj's weights into the caches meanwhile.
         def residual_linear(mod, x, resid):
+            plan = mod._fast.get("resid")
+            if plan is not None:
+                out = plan(x, resid)
+                if out is not None:
+                    return out
+            plan_out = []
             if kind == "int4":
-                return H4.w4_forward_residual(x, mod.prepare()._packed, mod.out_features, mod.bias, resid)
-            return H8.w8_forward_residual(x, mod.weight, mod.weight_scale, mod.bias, resid)
-
-        for i, layer in enumerate(self.layers):
-            at, ff = layer.attn, layer.ffn
-            qkv = norm_linear(at.qkv_proj, h, None, layer.attn_ln, None)
-            if kind == "int4":
-                nxt = (at.o_proj.prepare()._packed, _lib.NEXT_W4G32_PACKED, at.o_proj.out_features, at.o_proj.in_features)
+                out = H4.w4_forward_residual(x, mod.prepare()._packed, mod.out_features, mod.bias, resid, plan_out=plan_out,
+                                             guards=(mod.weight, mod.weight_scale))
             else:
-                nxt = (at.o_proj.weight, _lib.NEXT_W8_ROWS, at.o_proj.out_features, at.o_proj.in_features)
-            att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i],
-                                           mask, H, G, D, prefetch=nxt)
+                out = H8.w8_forward_residual(x, mod.weight, mod.weight_scale, mod.bias, resid, plan_out=plan_out)
+            if plan_out[0] is not None:
+                mod._fast["resid"] = plan_out[0]
+            return out
+
+        epoch = _lib.layout_epoch()
+        att_key = (position_ids.data_ptr(), write_index.data_ptr(), mask.data_ptr(), cache.capacity)
+        for i, layer in enumerate(self._layer_sites()):
+            at, ff, attn_ln, ffn_ln = layer
+            qkv = norm_linear(at.qkv_proj, h, attn_ln)
+            att = None
+            ap = cache.att_plans.get(i)
+            if ap is not None and ap[0] == epoch and ap[1] == att_key:
+                att = ap[2](qkv)
+            if att is None:
+                if kind == "int4":
+                    nxt = (at.o_proj.prepare()._packed, _lib.NEXT_W4G32_PACKED, at.o_proj.out_features, at.o_proj.in_features)
+                else:
+                    nxt = (at.o_proj.weight, _lib.NEXT_W8_ROWS, at.o_proj.out_features, at.o_proj.in_features)
+                plan_out = []
+                att = F_.decode_attention_rope(qkv, self.freqs_cis_cache, position_ids, write_index, cache.k[i], cache.v[i],
+                                               mask, H, G, D, prefetch=nxt, plan_out=plan_out)
+                if plan_out and plan_out[0] is not None:
+                    cache.att_plans[i] = (_lib.layout_epoch(), att_key, plan_out[0])
+                epoch = _lib.layout_epoch()                 # prepare() above may have built a layout
             h = residual_linear(at.o_proj, att, h)
             hn = None
-            if kind == "int4" and MLP_PAIR:                    # experiment: both MLP projections in one launch
+            if kind == "int4" and MLP_PAIR and not _lib.strict_for(h.dtype):   # round-2 experiment (chained grids), exact-dequant only
                 gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
-                hn = H4.w4_mlp_pair(h, layer.ffn_ln.weight, layer.ffn_ln.eps, gp, gb, ff.w_in.out_features,
+                hn = H4.w4_mlp_pair(h, ffn_ln.weight, ffn_ln.eps, gp, gb, ff.w_in.out_features,
                                     ff.w_out.prepare()._packed, ff.w_out.bias, ff.w_out.out_features, h)
             if hn is None:
-                y = norm_linear(ff.w_in, h, None, layer.ffn_ln, None, gate_hidden=ff.hidden_dim)
+                y = norm_linear(ff.w_in, h, ffn_ln, gate_hidden=ff.hidden_dim)
                 hn = residual_linear(ff.w_out, y, h)
             h = hn
-        return norm_linear(self.lm_head, h, None, self.final_ln, None)
+        return norm_linear(self.lm_head, h, self.final_ln)
+
+    def _layer_sites(self):
+        """(attn, ffn, attn_ln, ffn_ln) per layer as a plain list: the decode step walks it 28 times per token, and every
+        ``layer.attn`` through nn.Module.__getattr__ costs as much as a pre-bound launch.  Dropped by ``_apply``."""
+        sites = self.__dict__.get("_sites")
+        if sites is None:
+            sites = [(l.attn, l.ffn, l.attn_ln, l.ffn_ln) for l in self.layers]
+            self.__dict__["_sites"] = sites
+        return sites
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_sites", None)
+        self.__dict__.pop("_kind_cache", None)
+        return super()._apply(fn, *args, **kwargs)
 
     # -- reference-shaped call ----------------------------------------------------------------------
     def forward(self, input_ids: Optional[Tensor] = None, input_embeddings: Optional[Tensor] = None,

@@ -154,7 +154,9 @@ int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, 
 
 /* One-row (decode) forward on the derived layout with an activation PROLOGUE fused into the staging of the
  * activation row, so that the small op in front of the QLinear call costs no launch of its own (SURVEY.md 8f
- * N1).  fp16 / bf16, group 32, exact-dequant arithmetic.  Rounding sequence as the model graph's:
+ * N1).  fp16 / bf16, group 32; exact-dequant arithmetic unless QL_FUSED_STRICT is OR-ed into `prologue` (then every
+ * dequantised weight is rounded to the activation dtype first, as QL_FLAG_STRICT_ROUNDING does for qlinear_w4g32_fwd_packed:
+ * what the host module asks for with bf16 activations).  Rounding sequence as the model graph's:
  *   QL_PRO_SILU     A is (h | gate), 2K values: row = round(round(silu(h)) * gate)            chatglm_q/model.py:200-201
  *   QL_PRO_ADDNORM  hnew = round(A + delta) (delta nullable), written to hout (nullable);
  *                   row = round(round(hnew * rsqrt(mean(hnew^2) + eps)) * ln_weight)          chatglm_q/model.py:62-73,243-245
@@ -166,6 +168,7 @@ int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, 
 #define QL_PRO_SILU 1
 #define QL_PRO_ADDNORM 2
 #define QL_EPI_SILU_GATE 0x100
+#define QL_FUSED_STRICT 0x200
 int qlinear_w4g32_fwd_packed_fused(int prologue, const void* A, const void* packed, const void* bias, void* C,
                                    int64_t N, int64_t K, const void* delta, const void* ln_weight, void* hout,
                                    float eps, int dtype, void* stream);
@@ -229,9 +232,10 @@ int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, cons
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
  * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then
- * runs without delta / hout (one operand less to stage in every workgroup).  C may alias residual.  fp16 / bf16. */
+ * runs without delta / hout (one operand less to stage in every workgroup).  C may alias residual.  fp16 / bf16.
+ * flags: 0 or QL_FLAG_STRICT_ROUNDING. */
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
-                                      int64_t N, int64_t K, int dtype, void* stream);
+                                      int64_t N, int64_t K, int dtype, int flags, void* stream);
 
 /* The int8 twin (fp16 activations, K-contiguous weight rows of stride ldw, per-channel scales S). */
 int qlinear_w8_fwd_residual(const void* A, const int8_t* W, const void* S, const void* bias, const void* residual, void* C,

@@ -87,3 +87,38 @@ def fill_seeded_(state_dict, seed: int = REAL_DIM_SEED):
                 raise KeyError(f"unexpected state_dict entry {key}")
             buf.copy_(val.to(buf.dtype))
     return state_dict
+
+
+def fill_seeded_int8_(state_dict, seed: int = REAL_DIM_SEED + 17):
+    """In-place synthetic int8 per-channel weights for the int8 model fixtures (tests/golden/model_r3.npz): codes uniform
+    over -127..127 (std 73.3), per-channel scales sized so activations stay O(1); a pure function of (seed, key, shape,
+    dtype) like fill_seeded_."""
+    import math
+    import zlib
+
+    import torch
+    with torch.no_grad():
+        for key in sorted(state_dict.keys()):
+            buf = state_dict[key]
+            gen = torch.Generator().manual_seed(seed + zlib.crc32(key.encode()))
+            if buf.dtype == torch.int8:
+                val = torch.randint(-127, 128, buf.shape, dtype=torch.int8, generator=gen)
+            elif key.endswith("weight_scale"):
+                if key.startswith("word_embedding"):
+                    amp = 1.0 / 73.3                              # embedding rows ~ unit variance
+                else:
+                    fan_in = state_dict[key[: -len("_scale")]].shape[1]
+                    amp = 1.0 / (73.3 * math.sqrt(fan_in))
+                val = (torch.rand(buf.shape, generator=gen) * 0.5 + 0.75) * amp
+            elif key.endswith("bias"):
+                val = torch.randn(buf.shape, generator=gen) * 0.05
+            elif "ln" in key:
+                val = 1.0 + 0.1 * torch.randn(buf.shape, generator=gen)
+            else:
+                raise KeyError(f"unexpected state_dict entry {key}")
+            buf.copy_(val.to(buf.dtype))
+    return state_dict
+
+
+TINY_INT8_CONFIG = dict(hidden_size=256, inner_hidden_size=384, head_hidden_size=32, num_multi_query_groups=2,
+                        num_attention_heads=8, num_layers=2, vocab_size=320, max_sequence_length=64)

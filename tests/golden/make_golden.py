@@ -447,6 +447,79 @@ def gen_model_real():
     np.savez_compressed(os.path.join(OUT, "real_model.npz"), **d)
 
 
+def gen_model_r3():
+    """Round-3 additions, in a file of their own (tests/golden/model_r3.npz) so that the round-1/2 fixtures stay byte
+    identical.  All through the REFERENCE model on CPU, weights from tests/_golden.py seeded fills:
+      long   int4g32, fp16, real layer dimensions, batch 1: prefill of 320 ids + 3 cached decode steps - more than 256
+             cached positions, i.e. the build's window-split attention + combine launch (decode_ops.hip) against reference logits
+      bf16   int4g32, bf16, real layer dimensions, batch 1: prefill of 9 ids + 3 decode steps (bf16 is pinned through the
+             reference's torch route only: its Triton kernel does not run in bf16, see triton_int4 above)
+      i8     int8 per-channel model (chatglm_q/loader.py:41-50 create_quant_int8_model), fp16, real layer dimensions, batch 1:
+             prefill of 9 ids + 3 decode steps
+      i8tiny the int8 model at a tiny config in fp32 and fp16 (prefill 12 ids + 1 decode step + chunked prefill 7 + 5)"""
+    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import _golden as G
+    from chatglm_q import model as refm
+    from chatglm_q import loader as refl
+    torch.set_num_threads(8)
+    d = {}
+
+    def b1_case(m, tag, n_prefill, seed, V):
+        gen = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, V, (1, n_prefill), generator=gen)
+        nxt = torch.randint(0, V, (3,), generator=gen)
+        with torch.no_grad():
+            _, lg, kv = m(input_ids=ids)
+        d[f"{tag}/ids"] = ids.numpy().astype(np.int16); d[f"{tag}/next_ids"] = nxt.numpy()
+        put(d, f"{tag}/prefill_last_logits", lg[:, -1])
+        for t in range(3):
+            with torch.no_grad():
+                _, lg, kv = m(input_ids=nxt[t].view(1, 1), past_key_values=kv)
+            put(d, f"{tag}/decode_logits_{t}", lg[:, -1])
+        pos = torch.tensor([0, n_prefill // 2, n_prefill - 1, n_prefill + 2])
+        d[f"{tag}/kv_positions"] = pos.numpy()
+        put(d, f"{tag}/kv1_k", kv[1][0][:, pos]); put(d, f"{tag}/kv1_v", kv[1][1][:, pos])
+        print(tag, "done")
+
+    cfg = refm.ChatGLM2Config(**G.REAL_DIM_CONFIG)
+    m = refl.create_quant_int4_model(cfg, dtype=torch.float16)
+    G.fill_seeded_(m.state_dict())
+    m.eval()
+    b1_case(m, "long", 320, 8300, cfg.vocab_size)
+    del m
+    m = refl.create_quant_int4_model(cfg, dtype=torch.bfloat16)
+    G.fill_seeded_(m.state_dict())
+    m.eval()
+    b1_case(m, "bf16", 9, 8301, cfg.vocab_size)
+    del m
+    m = refl.create_quant_int8_model(cfg, dtype=torch.float16)
+    G.fill_seeded_int8_(m.state_dict())
+    m.eval()
+    b1_case(m, "i8", 9, 8302, cfg.vocab_size)
+    del m
+
+    tcfg = refm.ChatGLM2Config(**G.TINY_INT8_CONFIG)
+    for dt in ("f32", "f16"):
+        m = refl.create_quant_int8_model(tcfg, dtype=DT[dt])
+        G.fill_seeded_int8_(m.state_dict(), seed=8400)
+        m.eval()
+        gen = torch.Generator().manual_seed(8401)
+        ids = torch.randint(0, tcfg.vocab_size, (1, 12), generator=gen)
+        nxt = torch.randint(0, tcfg.vocab_size, (1, 1), generator=gen)
+        with torch.no_grad():
+            _, logits, kv = m(input_ids=ids)
+            _, logits2, kv2 = m(input_ids=nxt, past_key_values=kv)
+            _, la, kva = m(input_ids=ids[:, :7])
+            _, lb, kvb = m(input_ids=ids[:, 7:], past_key_values=kva)
+        p = f"i8tiny/{dt}/"
+        d[p + "ids"] = ids.numpy(); d[p + "next_id"] = nxt.numpy()
+        put(d, p + "prefill_logits", logits); put(d, p + "decode_logits", logits2)
+        put(d, p + "chunked_last_logits", lb[:, -1])
+        put(d, p + "kv0_k", kv2[0][0]); put(d, p + "kv0_v", kv2[0][1])
+    np.savez_compressed(os.path.join(OUT, "model_r3.npz"), **d)
+
+
 def gen_backward():
     """grad_A of both quantized matmuls through the reference's own autograd functions (CPU route:
     chatglm_q/int4/qlinear.py:53-64, chatglm_q/int8/qlinear.py:41-52)."""
@@ -502,11 +575,11 @@ def gen_loader():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "backward", "loader"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "model_r3", "backward", "loader"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "backward": gen_backward, "loader": gen_loader}[w]()
+         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "model_r3": gen_model_r3, "backward": gen_backward, "loader": gen_loader}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

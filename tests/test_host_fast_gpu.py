@@ -1,0 +1,261 @@
+"""Round-3 host-path tests on the GPU: the pre-bound launch plans behind DynamicQuantizeLinear.forward and the fused decode
+step (same bits as the checked wrappers; every change of buffers / operands sends the call back through the checks), the
+bf16 default arithmetic of the module (<= 1e-3 of the oracle), graph re-capture after the weights moved
+(ADVICE r2), and the one-position chunk of a left-padded batched prefill."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import qlinear_oracle as O  # noqa: E402
+from chatglm_q_amd import _lib  # noqa: E402
+from chatglm_q_amd import model as M  # noqa: E402
+from chatglm_q_amd.decoder import ChatGLMDecoder, DecodeSession  # noqa: E402
+from chatglm_q_amd.int4 import hip_ops as h4  # noqa: E402
+from chatglm_q_amd.int4 import qlinear as q4  # noqa: E402
+from chatglm_q_amd.int8 import qlinear as q8  # noqa: E402
+from test_parity_gpu import _rand_w4, t2n  # noqa: E402
+
+DEV = "cuda:0"
+TDT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def _layer4(K, N, dt, seed, bias=True):
+    layer = q4.DynamicQuantizeLinear(K, N, bias=bias, dtype=TDT[dt])
+    qw, sc = _rand_w4(K, N, dt, seed)
+    b = (torch.randn(N, generator=torch.Generator().manual_seed(seed + 1)) * 0.1).to(TDT[dt]) if bias else None
+    layer.apply_weights_(qw, sc, b)
+    return layer.to(DEV), qw, sc, b
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+def test_bf16_module_default_arithmetic_is_within_1e3(rows):
+    """The path DynamicQuantizeLinear.forward takes for bf16 at 1..4 rows (strict per-weight rounding unless QLINEAR_STRICT=0)
+    against the oracle's bf16 restatement of the reference (chatglm_q/int4/triton_ops.py:72-73) at the headline shape."""
+    if _lib.STRICT_MODE == "off":
+        pytest.skip("QLINEAR_STRICT=0: the exact-dequant arithmetic was asked for")
+    layer, qw, sc, b = _layer4(4096, 4096, "bf16", 300 + rows)
+    x = torch.randn(rows, 4096, generator=torch.Generator().manual_seed(rows)).bfloat16()
+    with torch.no_grad():
+        y1 = layer(x.to(DEV))                  # checked path (builds the plan)
+        y2 = layer(x.to(DEV))                  # pre-bound plan
+    ref = O.w4_matmul(t2n(x), qw.numpy(), t2n(sc), t2n(b), dtype="bf16")
+    err = O.rel_l2(t2n(y1), ref)
+    print(f"[bf16 default] rows={rows}: rel-L2 {err:.3e}")
+    assert err <= 1e-3
+    assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("dt,rows", [("f16", 1), ("f16", 2), ("f16", 7), ("f16", 300), ("bf16", 1), ("f32", 1), ("f32", 3)])
+def test_forward_plan_equals_checked_path_and_revalidates(dt, rows):
+    K, N = 1024, 768
+    layer, qw, sc, b = _layer4(K, N, dt, 17)
+    x = torch.randn(rows, K, device=DEV).to(TDT[dt])
+    with torch.no_grad():
+        y0 = layer(x)
+        assert layer._plans, "the checked path did not leave a pre-bound launch behind"
+        before = _lib.launch_count()
+        y1 = layer(x)
+        assert _lib.launch_count() > before and torch.equal(y0, y1)
+        ref = O.w4_matmul(t2n(x), qw.numpy(), t2n(sc), t2n(b), dtype=dt)
+        assert O.rel_l2(t2n(y1), ref) <= (2e-6 if dt == "f32" else 1e-3)
+        # (1) another shape with the same element count, a non-contiguous view, a misaligned view: still right
+        if rows % 2 == 0:
+            assert torch.equal(layer(x.view(2, rows // 2, K)).reshape(rows, N), y0)
+        xt = torch.randn(K, rows, device=DEV).to(TDT[dt]).t()
+        assert O.rel_l2(t2n(layer(xt)), O.w4_matmul(t2n(xt), qw.numpy(), t2n(sc), t2n(b), dtype=dt)) <= (2e-6 if dt == "f32" else 1e-3)
+        # (2) the reference loader's in-place refill: the plan must notice (version counters) and the result must follow
+        qw2, sc2 = _rand_w4(K, N, dt, 18)
+        layer.state_dict()["weight"].copy_(qw2.to(DEV))
+        layer.state_dict()["weight_scale"].copy_(sc2.to(DEV))
+        y2 = layer(x)
+        assert O.rel_l2(t2n(y2), O.w4_matmul(t2n(x), qw2.numpy(), t2n(sc2), t2n(b), dtype=dt)) <= (2e-6 if dt == "f32" else 1e-3)
+        # (3) invalidate() drops the plans; the checks fire again on the next call
+        layer.invalidate()
+        assert not layer._plans
+        with pytest.raises(AssertionError):
+            layer(x.to(torch.float32 if dt != "f32" else torch.float16))          # dtype check of the reference wrapper
+        with pytest.raises(AssertionError):
+            layer(torch.randn(rows, K // 2, device=DEV).to(TDT[dt]))              # K mismatch
+        assert torch.equal(layer(x), y2)
+        # (4) a live plan does not shadow the checks either: wrong dtype / wrong K reach the checked path
+        assert layer._plans
+        with pytest.raises(AssertionError):
+            layer(x.to(torch.float32 if dt != "f32" else torch.float16))
+        # (5) bias replaced by assignment: plans dropped, new bias used
+        if b is not None:
+            layer.bias = torch.zeros_like(layer.bias)
+            assert not layer._plans
+            assert O.rel_l2(t2n(layer(x)), O.w4_matmul(t2n(x), qw2.numpy(), t2n(sc2), None, dtype=dt)) <= (2e-6 if dt == "f32" else 1e-3)
+
+
+def test_int8_forward_plan_equals_checked_path():
+    K, N = 1024, 512
+    g = torch.Generator().manual_seed(4)
+    w = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)
+    s = (torch.rand(N, generator=g) * 0.01 + 0.001).half()
+    layer = q8.DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16)
+    layer.apply_weights_(w, s)
+    layer = layer.to(DEV)
+    for rows in (1, 2, 5, 64):
+        x = torch.randn(rows, K, device=DEV).half()
+        with torch.no_grad():
+            y0 = layer(x)
+            assert x.numel() in layer._plans
+            y1 = layer(x)
+        assert torch.equal(y0, y1)
+        ref = O.w8_matmul(t2n(x), np.ascontiguousarray(w.numpy().T), s.numpy(), None, dtype="f16")
+        assert O.rel_l2(t2n(y1), ref) <= 1e-3
+    w2 = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)
+    layer.state_dict()["weight"].copy_(w2.to(DEV))
+    with torch.no_grad():
+        y2 = layer(x)
+    assert O.rel_l2(t2n(y2), O.w8_matmul(t2n(x), np.ascontiguousarray(w2.numpy().T), s.numpy(), None, dtype="f16")) <= 1e-3
+
+
+def _tiny(dtype=torch.float16, kind="int4", seed=5):
+    cfg = M.ChatGLM2Config(hidden_size=256, inner_hidden_size=384, head_hidden_size=32, num_multi_query_groups=2,
+                           num_attention_heads=8, num_layers=2, vocab_size=320, max_sequence_length=96)
+    with torch.device(DEV):
+        model = (M.create_quant_int4_model if kind == "int4" else M.create_quant_int8_model)(cfg, dtype=dtype)
+    M.fill_synthetic_(model, seed)
+    return model.eval(), cfg
+
+
+@pytest.mark.parametrize("kind", ["int4", "int8"])
+def test_one_row_step_plans_equal_checked_wrappers(kind):
+    """Decode steps with the pre-bound launches (second step onwards) against a session whose plans are dropped before every
+    step: same logits bit for bit."""
+    model, cfg = _tiny(kind=kind)
+    ids = torch.randint(0, 320, (1, 9), device=DEV)
+
+    def run(drop):
+        sess = DecodeSession(model, 1, 32, use_graph=False)
+        logits = [sess.prefill(ids)]
+        sess.tok.copy_(logits[0].argmax(-1, keepdim=True))
+        for _ in range(4):
+            if drop:
+                for m in model.modules():
+                    if hasattr(m, "_fast"):
+                        m._fast.clear()
+                sess.cache.att_plans.clear()
+            logits.append(sess.decode_step(greedy=True).clone())
+        return torch.stack(logits)
+
+    a = run(drop=True)
+    b = run(drop=False)
+    assert any(m._fast for m in model.modules() if hasattr(m, "_fast"))
+    assert torch.equal(a, b)
+
+
+def test_graph_is_recaptured_when_the_weights_move():
+    """a decoder reuses its session and graph; apply_weights_ / load_state_dict drop the derived layouts the graph
+    baked in.  The next generation must re-capture - and produce what an eager run on the new weights produces."""
+    model, cfg = _tiny()
+    dec = ChatGLMDecoder(None, model)
+    prefix = [3, 17, 200, 5, 77]
+    kw = dict(max_generated_tokens=10, greedy=True, ignore_eos=True)
+    first = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    sess = dec._session
+    g0 = sess.graph
+    assert g0 is not None
+    again = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    assert again == first and dec._session.graph is g0                         # nothing moved: the graph is kept
+    M.fill_synthetic_(model, 99)                                               # in-place refill of every buffer (version bump)
+    want = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
+    got = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    assert got == want
+    assert dec._session.graph is not g0
+    for mod in model.modules():                                                # explicit invalidate(): same story
+        if hasattr(mod, "invalidate"):
+            mod.invalidate()
+    g1 = dec._session.graph
+    assert list(dec.generate_ids(prefix, use_graph=True, **kw)) == want
+    assert dec._session.graph is not g1
+
+
+def test_two_live_generators_do_not_share_a_session():
+    model, cfg = _tiny()
+    dec = ChatGLMDecoder(None, model)
+    kw = dict(max_generated_tokens=6, greedy=True, ignore_eos=True, use_graph=False)
+    want_a = list(dec.generate_ids([1, 2, 3], **kw))
+    want_b = list(dec.generate_ids([9, 8, 7, 6], **kw))
+    ga, gb = dec.generate_ids([1, 2, 3], **kw), dec.generate_ids([9, 8, 7, 6], **kw)
+    got_a, got_b = [], []
+    for _ in range(6):
+        got_a.append(next(ga))
+        got_b.append(next(gb))
+    assert got_a == want_a and got_b == want_b
+
+
+def test_budget_respects_the_models_sequence_limit():
+    model, cfg = _tiny()
+    dec = ChatGLMDecoder(None, model, max_sequence_length=4096)               # larger than the model's rotary table
+    out = list(dec.generate_ids(list(range(90)), max_generated_tokens=50, greedy=True, ignore_eos=True, use_graph=False))
+    assert len(out) == cfg.max_sequence_length - 90
+
+
+@pytest.mark.parametrize("S,chunk", [(9, 8), (1, 8), (17, 4)])
+def test_left_padded_batched_prefill_with_a_one_position_chunk(S, chunk, monkeypatch):
+    """S % chunk == 1 leaves a one-position chunk, which takes the one-position attention kernel with the
+    FULL-capacity mask (a sliced + compacted mask made rows b >= 1 read other sequences' columns).  Fused ops against the
+    plain-torch graph of the same model."""
+    model, cfg = _tiny()
+    B = 4
+    lens = [S, max(1, S - 3), max(1, S // 2), 1]
+    g = torch.Generator().manual_seed(S)
+    ids = torch.randint(1, 320, (B, S), generator=g)
+    attn = torch.zeros(B, S, dtype=torch.long)
+    for b, n in enumerate(lens):
+        attn[b, S - n:] = 1
+        ids[b, : S - n] = 0
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(M, "FUSED_DECODE_OPS", fused)
+        sess = DecodeSession(model, B, 32, use_graph=False)
+        # dirty cache rows beyond the prefix: a stale-row read would show
+        for k, v in zip(sess.cache.k, sess.cache.v):
+            k.normal_(0, 3)
+            v.normal_(0, 3)
+        logits = [sess.prefill(ids, chunk=chunk, attention_mask=attn)]
+        sess.tok.copy_(logits[0].argmax(-1, keepdim=True))
+        for _ in range(2):
+            logits.append(sess.decode_step(greedy=True).clone())
+        outs[fused] = torch.stack([l.float() for l in logits])
+    assert O.rel_l2(t2n(outs[True]), t2n(outs[False])) < 5e-3
+
+
+def test_decode_attention_rope_rejects_a_compacted_mask():
+    from chatglm_q_amd import fused_ops as F_
+    B, H, Gq, D, cap = 2, 8, 2, 32, 64
+    qkv = torch.randn(B, 1, (H + 2 * Gq) * D, device=DEV).half()
+    table = M.rotary_table(D, cap + 1).half().view(cap + 1, -1).to(DEV)
+    pos = torch.ones(B, 1, dtype=torch.long, device=DEV)
+    widx = torch.zeros(1, dtype=torch.long, device=DEV)
+    k = torch.zeros(B, cap, Gq, D, device=DEV).half()
+    v = torch.zeros_like(k)
+    mask = torch.zeros(B, 1, cap, device=DEV)
+    F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, Gq, D)
+    with pytest.raises(ValueError):
+        F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask[..., :40].contiguous(), H, Gq, D)
+    with pytest.raises(ValueError):
+        F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask[..., :40], H, Gq, D)
+
+
+def test_release_frees_and_rebuilds_derived_layouts():
+    layer, qw, sc, b = _layer4(1024, 768, "f16", 33)
+    x1, x8 = torch.randn(1, 1024, device=DEV).half(), torch.randn(8, 1024, device=DEV).half()
+    with torch.no_grad():
+        y1, y8 = layer(x1), layer(x8)
+    nb = layer.derived_nbytes()
+    assert nb["packed"] > 0 and nb["tiled"] > 0 and nb["canonical"] > 0
+    layer.release("tiled")
+    assert layer.derived_nbytes()["tiled"] == 0 and layer.derived_nbytes()["packed"] == nb["packed"]
+    with torch.no_grad():
+        assert torch.equal(layer(x1), y1)
+        assert layer.derived_nbytes()["tiled"] == 0           # one row never needs part 2
+        assert torch.equal(layer(x8), y8)                      # rebuilt on demand
+    assert layer.derived_nbytes()["tiled"] == nb["tiled"]
+    with pytest.raises(ValueError):
+        layer.release("nonsense")

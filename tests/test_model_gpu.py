@@ -214,6 +214,7 @@ def test_rope_attention_single_launch_equals_two(dtype, geom):
     assert O.rel_l2(t2n(got_split), t2n(want)) < {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 8e-3}[dtype]
 
 
+@pytest.mark.usefixtures("exact_dequant_policy")
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("M", [2, 3, 4])
@@ -534,6 +535,7 @@ def test_int8_model_one_row_step_matches_unfused_graph():
     assert O.rel_l2(t2n(outs[True]), t2n(outs[False])) < 5e-3
 
 
+@pytest.mark.usefixtures("exact_dequant_policy")
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
 def test_mlp_pair_one_launch_equals_two(dtype, bias):
@@ -573,6 +575,7 @@ def test_mlp_pair_one_launch_equals_two(dtype, bias):
     assert H4.w4_mlp_pair(x, ln[:256].contiguous(), 1e-5, small.gated_packed(256)[0], None, 512, s_out.prepare()._packed, None, 256, x) is None
 
 
+@pytest.mark.usefixtures("exact_dequant_policy")
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [2, 3, 4])
 @pytest.mark.parametrize("with_delta", [False, True])
