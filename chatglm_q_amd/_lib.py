@@ -112,6 +112,10 @@ EXPORTS = {
     "qlinear_w4g32_mlp_pair_workspace_bytes": (c_size_t, []),
     "qlinear_w4g32_mlp_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "qlinear_w4g32_mlp_engine_workspace_bytes": (c_size_t, [c_int64]),
+    "qlinear_w4g32_mlp_engine_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "qlinear_w4g32_mlp_engine": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed_residual": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p]),
     "qlinear_w8_fwd_residual": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_decode_attention_rope_prefetch": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p, c_int,

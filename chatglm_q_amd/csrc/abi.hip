@@ -250,6 +250,46 @@ int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, cons
                        workspace, (hipStream_t)stream);
 }
 
+size_t qlinear_w4g32_mlp_engine_workspace_bytes(int64_t N_in) { return N_in > 0 ? w4_mlp_engine_workspace_bytes(N_in) : 0; }
+
+int qlinear_w4g32_mlp_engine_supported(int64_t N_in, int64_t K, int64_t N_out) {
+    return w4_mlp_engine_supported(N_in, K, N_out, N_in / 2) ? 1 : 0;
+}
+
+static int mlp_engine_checked(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                              const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, void* Out, void* workspace, int dtype,
+                              int flags, void* trace, void* stream) {
+    if (!X || !ln_weight || !packed_in || !packed_out || !Out || !workspace) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (flags & ~QL_FLAG_STRICT_ROUNDING) return QL_ERR_UNSUPPORTED;
+    if (!fits_i32(N_in) || !fits_i32(N_out) || !fits_i32(K) || N_in <= 0 || N_out <= 0 || K <= 0 || K % 32 != 0 || N_in % 4 != 0 ||
+        (N_in / 2) % 32 != 0 || N_out != K)
+        return QL_ERR_BAD_SHAPE;
+    if (!aligned(X, 16) || !aligned(ln_weight, 16) || !aligned(packed_in, 16) || !aligned(packed_out, 16) || !aligned(Out, 8) ||
+        !aligned(workspace, 64) || (bias_out && !aligned(bias_out, 8)))
+        return QL_ERR_MISALIGNED;
+    if (X == Out) return QL_ERR_UNSUPPORTED;                  // every workgroup reads X (norm + residual) while others write Out
+    return w4_mlp_engine(dtype, (flags & QL_FLAG_STRICT_ROUNDING) != 0, X, ln_weight, eps, packed_in, bias_in, N_in, K, packed_out, bias_out,
+                         N_out, N_in / 2, Out, workspace, trace, (hipStream_t)stream);
+}
+
+int qlinear_w4g32_mlp_engine(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                             const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, void* Out, void* workspace, int dtype,
+                             int flags, void* stream) {
+    return mlp_engine_checked(X, ln_weight, eps, packed_in, bias_in, N_in, packed_out, bias_out, N_out, K, Out, workspace, dtype, flags, nullptr,
+                              stream);
+}
+
+#ifdef QL_ENGINE_TRACE
+// developer build (make trace): `trace` receives 16 s_memrealtime stamps per workgroup (tools/mlp_engine.py)
+int qlinear_w4g32_mlp_engine_trace(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                                   const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, void* Out, void* workspace,
+                                   int dtype, int flags, void* trace, void* stream) {
+    return mlp_engine_checked(X, ln_weight, eps, packed_in, bias_in, N_in, packed_out, bias_out, N_out, K, Out, workspace, dtype, flags, trace,
+                              stream);
+}
+#endif
+
 int qlinear_w4g32_fwd_packed_residual(const void* A, const void* packed, const void* bias, const void* residual, void* C,
                                       int64_t N, int64_t K, int dtype, int flags, void* stream) {
     if (!A || !packed || !C || !residual) return QL_ERR_NULL_POINTER;

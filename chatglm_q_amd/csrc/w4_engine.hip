@@ -25,13 +25,14 @@
 
 namespace ql {
 
-constexpr int kEngWaves = 8;                     // 1 loader + 7 consumers
-constexpr int kEngConsumers = kEngWaves - 1;
+constexpr int kEngWaves = 8;                     // 2 loaders + 6 consumers
+constexpr int kEngLoaders = 2;                   // a wave keeps at most 63 loads in flight (vmcnt): ONE loader's 63 KB against ~3.7 us of
+                                                 // loaded HBM latency is 17 GB/s per CU (measured: 16); two keep the ring's 13 slots in flight
+constexpr int kEngConsumers = kEngWaves - kEngLoaders;
 constexpr int kEngThreads = 64 * kEngWaves;
 constexpr int kEngSlotBytes = 9216;              // 4 columns x 128 groups x 16 B + 1 KB of scales
 constexpr int kEngSlots = 13;
-constexpr int kEngDepth = 7;                     // tasks in flight per loader: 9 loads each, 63 = the vmcnt ceiling
-constexpr int kEngLoadsPerTask = 9;
+constexpr int kEngDepth = 7;                     // tasks in flight per loader wave: 9 loads each, 63 = the vmcnt ceiling
 constexpr int kEngMaxGroupsPerTask = 128;
 constexpr int kEngMaxQuadsB = 16;                // second-projection column quads per workgroup (K-slice combine slots)
 constexpr unsigned kEngSpinLds = 1u << 22;       // bounds of the spins (each iteration sleeps): ~tens of ms
@@ -59,70 +60,39 @@ struct EngineArgs {
     unsigned long long* trace;  // developer builds only
 };
 
-struct EngTask {
-    int phase;                  // 0: first projection, 1: second
-    int quad, ks;               // column quad, K slice
-    int g0, ng;                 // first group of the slice, groups in it (<= 128)
-    int qlocal;                 // index of the quad among this workgroup's quads of the phase
-};
-
-struct EngPlan {                // this workgroup's share: contiguous quad ranges of both projections
-    int qa0, qa1, qb0, qb1;     // [qa0, qa1) quads of the first projection, [qb0, qb1) of the second
-    int nA, nB;                 // tasks per phase
-    int Ga, Gb, gsa, gsb;       // groups per row / per K slice
-};
-
-template <typename T>
-__device__ __forceinline__ EngPlan eng_plan(const EngineArgs<T>& p) {
-    EngPlan pl;
-    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
-    const int qa = (p.Na + 3) >> 2, qb = (p.Nb + 3) >> 2;
-    pl.qa0 = (int)((long long)qa * b / nb);
-    pl.qa1 = (int)((long long)qa * (b + 1) / nb);
-    pl.qb0 = (int)((long long)qb * b / nb);
-    pl.qb1 = (int)((long long)qb * (b + 1) / nb);
-    pl.nA = (pl.qa1 - pl.qa0) * p.KSa;
-    pl.nB = (pl.qb1 - pl.qb0) * p.KSb;
-    pl.Ga = p.Ka >> 5;
-    pl.Gb = p.Kb >> 5;
-    pl.gsa = (pl.Ga + p.KSa - 1) / p.KSa;
-    pl.gsb = (pl.Gb + p.KSb - 1) / p.KSb;
-    return pl;
-}
-
-// task i of the workgroup's stream: phase A quad-major (quad, slice), then phase B slice-minor as well
-template <typename T>
-__device__ __forceinline__ EngTask eng_task(const EngineArgs<T>& p, const EngPlan& pl, int i) {
-    EngTask t;
-    if (i < pl.nA) {
-        t.phase = 0;
-        t.qlocal = i / p.KSa;
-        t.ks = i - t.qlocal * p.KSa;
-        t.quad = pl.qa0 + t.qlocal;
-        t.g0 = t.ks * pl.gsa;
-        t.ng = min(pl.Ga, t.g0 + pl.gsa) - t.g0;
-    } else {
-        const int j = i - pl.nA;
-        t.phase = 1;
-        t.qlocal = j / p.KSb;
-        t.ks = j - t.qlocal * p.KSb;
-        t.quad = pl.qb0 + t.qlocal;
-        t.g0 = t.ks * pl.gsb;
-        t.ng = min(pl.Gb, t.g0 + pl.gsb) - t.g0;
-    }
-    if (t.ng < 0) t.ng = 0;
-    return t;
-}
-
-// ---- LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to 1 KB of LDS at `lds_dst` (wave-uniform) -----------------
-// M0 holds the LDS base of the transfer and is compiler-reserved: written and restored inside the statement
-// (cdna_hip_programming.md 5.7).  The load is invisible to hipcc's vmcnt bookkeeping: the loader counts its own.
-__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
+// ---- LDS-DMA ------------------------------------------------------------------------------------------------------------------------
+// M0 holds the LDS base of a transfer and is compiler-reserved: written and restored inside the statement
+// (cdna_hip_programming.md 5.7).  The loads are invisible to hipcc's vmcnt bookkeeping: the loader counts its own.
+// One TASK in one statement: 9 transfers of 1 KB to consecutive KBs of the slot at `lds_dst`.  Sources: four column segments
+// (wave-uniform 64-bit bases b0..b3 + per-lane byte offsets v0 / v1 for the lanes' first / second 64 groups) and the scale
+// segment (bs + vs).  saddr form: the address arithmetic stays on the scalar unit; M0 saved once, advanced by 1 KB per
+// transfer (s_add_u32 writes SCC: clobbered), restored once - ~30 instructions per task instead of ~300 with one
+// statement and 64-bit VALU address arithmetic per transfer (the first version's loader was instruction-bound at ~1 us per task).
+__device__ __forceinline__ void glds_task(unsigned lds_dst, unsigned v0, unsigned v1, unsigned vs, unsigned long long b0,
+                                          unsigned long long b1, unsigned long long b2, unsigned long long b3, unsigned long long bs) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8 nt\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9 nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(v0), "v"(v1), "v"(vs), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(bs)
+        : "memory", "scc");
+}
+
+// a wave-uniform 64-bit value the compiler may not recognise as such -> an SGPR pair
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int N>
@@ -146,8 +116,18 @@ __device__ __forceinline__ void lds_fence() {       // the wave's LDS operations
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Flag words live in LDS and are polled: the pointer type carries the LDS address space explicitly.  (A `volatile unsigned*`
+// derived from the dynamic-LDS array stays a GENERIC pointer - LLVM's address-space inference does not rewrite volatile
+// accesses - and every poll became a flat_load + s_waitcnt vmcnt(0): in the loader that drained the whole LDS-DMA queue
+// per poll, 54 us per MLP.)
+typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ unsigned lds_add(lds_vu32* p, unsigned v) {
+    return __hip_atomic_fetch_add((lds_u32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // spin until *flag == want (LDS word written by another wave of the workgroup); false after kEngSpinLds polls
-__device__ __forceinline__ bool lds_wait_eq(volatile unsigned* flag, unsigned want) {
+__device__ __forceinline__ bool lds_wait_eq(lds_vu32* flag, unsigned want) {
     bool hit = false;
     for (unsigned spins = 0; spins < kEngSpinLds; ++spins) {
         if (*flag == want) {
@@ -158,13 +138,6 @@ __device__ __forceinline__ bool lds_wait_eq(volatile unsigned* flag, unsigned wa
     }
     asm volatile("" ::: "memory");                  // nothing that follows is read before the flag was seen
     return hit;
-}
-__device__ __forceinline__ bool lds_wait_ge(volatile unsigned* flag, unsigned want) {
-    for (unsigned spins = 0; spins < kEngSpinLds; ++spins) {
-        if (*flag >= want) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
 }
 
 // ---- the tile math of w4_packed_gemv_16_body (MB = 1), operands from LDS ------------------------------------------------------
@@ -263,7 +236,7 @@ __host__ __device__ inline EngLds eng_lds(int Ka, int Kb) {
     return L;
 }
 // flag words (unsigned) inside the flags block
-enum { F_READY = 0, F_FREED = 16, F_NORM = 32, F_NORMCNT = 36, F_XDONE = 37, F_GATHER = 38, F_ENDCNT = 39, F_QCNT = 48 /* 2 x kEngMaxQuadsB */,
+enum { F_READY = 0, F_FREED = 16, F_NORM = 32, F_NORMCNT = 36, F_XDONE = 37, F_GATHER = 38, F_ENDCNT = 39 /* + 40: trace */, F_NEXT = 41 /* + 42 */, F_QCNT = 48 /* 2 x kEngMaxQuadsB */,
        F_WORDS = 48 + 2 * kEngMaxQuadsB };
 static_assert(F_WORDS * 4 <= 512, "flag block");
 
@@ -272,108 +245,161 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const EngPlan pl = eng_plan(p);
+    // This workgroup's share, as plain scalars (a struct selected by phase made hipcc build a lookup table in SCRATCH: a
+    // scratch_load + s_waitcnt vmcnt(0) per task in the loader drained its whole LDS-DMA queue - 54 us per MLP).
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int qa_all = (p.Na + 3) >> 2, qb_all = (p.Nb + 3) >> 2;
+    const int qa0 = (int)((long long)qa_all * b / nb), nqa = (int)((long long)qa_all * (b + 1) / nb) - qa0;
+    const int qb0 = (int)((long long)qb_all * b / nb), nqb = (int)((long long)qb_all * (b + 1) / nb) - qb0;
+    const int KSa = p.KSa, KSb = p.KSb;
+    const int Ga = p.Ka >> 5, Gb = p.Kb >> 5;
+    const int gsa = (Ga + KSa - 1) / KSa, gsb = (Gb + KSb - 1) / KSb;
+    const int nA = nqa * KSa, nB = nqb * KSb, ntasks = nA + nB;
     const EngLds L = eng_lds(p.Ka, p.Kb);
-    const int ntasks = pl.nA + pl.nB;
-    volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(smem + L.flags);
+    lds_vu32* flags = (lds_vu32*)(smem + L.flags);
     const unsigned lds_base = (unsigned)(uintptr_t)smem;        // LDS byte address of the dynamic region (low 32 bits of the flat pointer)
 
-    // ---- loader: issue the first tasks before anything else happens in the workgroup ----------------------------------------
-    auto issue_task = [&](int i) {
-        const EngTask t = eng_task(p, pl, i);
-        const int slot = i % kEngSlots;
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + L.ring + (unsigned)slot * kEngSlotBytes));
-        const int G = t.phase ? pl.Gb : pl.Ga;
-        const u32x4* W = t.phase ? p.Wb : p.Wa;
-        const char* S = reinterpret_cast<const char*>(t.phase ? p.Sb : p.Sa);
-        const int last = t.ng > 0 ? t.ng - 1 : 0;
-        const int l0 = min(lane, last), l1 = min(lane + 64, last);
-        const u32x4* wq = W + ((int64_t)t.quad * 4) * G + t.g0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            glds16_nt(wq + (int64_t)c * G + l0, dst + c * 2048);
-            glds16_nt(wq + (int64_t)c * G + l1, dst + c * 2048 + 1024);
-        }
-        // scales: ng x 8 bytes from byte offset 8 * (quad * G + g0), fetched as 16-byte units from the aligned floor
-        const int64_t sbyte = ((int64_t)t.quad * G + t.g0) * 8;
-        const int64_t sfloor = sbyte & ~(int64_t)15;
-        const int units = (int)((sbyte - sfloor + (int64_t)t.ng * 8 + 15) >> 4);
-        glds16_nt(S + sfloor + 16 * (int64_t)min(lane, units > 0 ? units - 1 : 0), dst + 8192);
-    };
-
-    if (wave == 0) {
-        const int first = min(ntasks, kEngDepth);
-        for (int i = 0; i < first; ++i) issue_task(i);
-    }
-    // flags start at zero (LDS keeps whatever the previous workgroup left): ONE workgroup barrier, before any poll
+    // flags start at zero (LDS keeps whatever the previous workgroup left): written now, ONE workgroup barrier before any poll.
+    // The loader reaches its barrier only after it has issued its first tasks.
     if (tid < F_WORDS) flags[tid] = 0u;
     lds_fence();
-    __builtin_amdgcn_s_barrier();
-    ENG_STAMP(0);
 
-    if (wave == 0) {
-        // ================================================= LOADER ================================================================
-        bool ok = true;
-        int marked = 0;                                      // tasks whose ready flag has been set
-        auto mark_oldest = [&](int issued) {                 // blocks until task `marked` has landed, then publishes it
+    if (wave < kEngLoaders) {
+        // ================================================= LOADERS ===============================================================
+        // loader w streams tasks w, w + 2, ... of the workgroup's list; issued / marked count ITS tasks, `gtask` all of them
+        bool ok = true, synced = false;
+        int issued = 0, marked = 0, slot = 0, gtask = 0;
+        const int mine = (ntasks + kEngLoaders - 1 - wave) / kEngLoaders;
+#ifdef QL_ENGINE_TRACE
+        unsigned long long blocked = 0;
+#endif
+        const int first = min(mine, (kEngSlots - 1) / kEngLoaders);   // issued before the barrier: no slot is reused yet
+        auto mark_oldest = [&]() {                           // blocks until this loader's oldest task has landed, then publishes it
             wait_tasks_in_flight(issued - marked - 1);
-            if (lane == 0) flags[F_READY + marked % kEngSlots] = (unsigned)(marked + 1);
+            const int g = marked * kEngLoaders + wave;       // its index in the workgroup's list
+            if (lane == 0) flags[F_READY + g % kEngSlots] = (unsigned)(g + 1);
             ++marked;
         };
-        for (int i = min(ntasks, kEngDepth); i < ntasks; ++i) {
-            // the oldest task in flight has landed once at most kEngDepth - 1 tasks' loads are outstanding
-            mark_oldest(i);
-            if (i >= kEngSlots) {
-                // ring full: while the consumers are busy (or away gathering), publish what lands instead of just sleeping
-                const unsigned need = (unsigned)(i - kEngSlots + 1);
-                unsigned spins = 0;
-                while (flags[F_FREED + i % kEngSlots] != need) {
-                    if (marked < i) mark_oldest(i);
-                    else __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kEngSpinLds) {
-                        ok = false;
-                        break;
-                    }
-                }
-                asm volatile("" ::: "memory");
+        auto step = [&](int quad, int ks, int G, int gs, unsigned long long W, unsigned long long S) {
+            if (gtask % kEngLoaders != wave) {               // the other loader's task
+                ++gtask;
+                if (++slot == kEngSlots) slot = 0;
+                return;
             }
-            issue_task(i);
-        }
-        for (; marked < ntasks; ++marked) {                  // drain: ntasks - marked tasks still in flight
-            wait_tasks_in_flight(ntasks - marked - 1);
-            if (lane == 0) flags[F_READY + marked % kEngSlots] = (unsigned)(marked + 1);
-        }
+            if (issued == first && !synced) {                // the first tasks are in flight: now join the workgroup's barrier
+                __builtin_amdgcn_s_barrier();
+                synced = true;
+            }
+            if (issued >= kEngDepth) {
+                mark_oldest();                               // at most kEngDepth - 1 tasks stay in flight
+            }
+            {
+                if (gtask >= kEngSlots) {
+                    // ring full: while the consumers are busy (or away gathering), publish what lands instead of just sleeping
+                    const unsigned need = (unsigned)(gtask - kEngSlots + 1);
+                    unsigned spins = 0;
+#ifdef QL_ENGINE_TRACE
+                    const unsigned long long tb0 = __builtin_amdgcn_s_memrealtime();
+#endif
+                    while (flags[F_FREED + slot] != need) {
+                        if (marked < issued) mark_oldest();
+                        else __builtin_amdgcn_s_sleep(1);
+                        if (++spins > kEngSpinLds) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+#ifdef QL_ENGINE_TRACE
+                    blocked += __builtin_amdgcn_s_memrealtime() - tb0;
+#endif
+                }
+            }
+            const int g0 = ks * gs;
+            const int ng = max(min(G, g0 + gs) - g0, 1);
+            const unsigned long long b0 = W + ((unsigned long long)quad * 4ull * (unsigned)G + (unsigned)g0) * 16ull;
+            // scales: ng x 8 bytes from byte offset 8 * (quad * G + g0), fetched as 16-byte units from the aligned floor
+            const unsigned long long sbyte = ((unsigned long long)quad * (unsigned)G + (unsigned)g0) * 8ull;
+            const unsigned long long sfloor = sbyte & ~15ull;
+            const int units = (int)((sbyte - sfloor + (unsigned long long)ng * 8ull + 15ull) >> 4);
+            const unsigned v0 = (unsigned)min(lane, ng - 1) * 16u, v1 = (unsigned)min(lane + 64, ng - 1) * 16u;
+            const unsigned vs = (unsigned)min(lane, units - 1) * 16u;
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + L.ring + (unsigned)slot * kEngSlotBytes));
+            const unsigned long long ub0 = uniform64(b0), ucol = uniform64((unsigned long long)G * 16ull);
+            glds_task(dst, v0, v1, vs, ub0, ub0 + ucol, ub0 + 2ull * ucol, ub0 + 3ull * ucol, uniform64(S + sfloor));
+            ++issued;
+            ++gtask;
+            if (++slot == kEngSlots) slot = 0;
+        };
+        for (int ql = 0; ql < nqa; ++ql)
+            for (int ks = 0; ks < KSa; ++ks) step(qa0 + ql, ks, Ga, gsa, (unsigned long long)(uintptr_t)p.Wa, (unsigned long long)(uintptr_t)p.Sa);
+        for (int ql = 0; ql < nqb; ++ql)
+            for (int ks = 0; ks < KSb; ++ks) step(qb0 + ql, ks, Gb, gsb, (unsigned long long)(uintptr_t)p.Wb, (unsigned long long)(uintptr_t)p.Sb);
+        if (!synced) __builtin_amdgcn_s_barrier();
+        if (wave == 0) ENG_STAMP(0);
+        while (marked < issued) mark_oldest();               // drain
         if (!ok && lane == 0) __hip_atomic_store(p.ws + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ENG_STAMP(1);
+#ifdef QL_ENGINE_TRACE
+        if (wave == 0) {
+            ENG_STAMP(1);
+            if (lane == 0 && p.trace) p.trace[(int)blockIdx.x * kEngTraceWords + 15] = blocked;
+        }
+#endif
         return;
     }
 
     // =================================================== CONSUMERS =================================================================
     typedef Splice<T> SP;
-    const int cw = wave - 1;                                 // consumer index 0..6
+    const int cw = wave - kEngLoaders;                       // consumer index
+    // consumers 0..3 play the 256 threads of the two-launch kernel's RMSNorm prologue: their chunks of the input row and of the
+    // norm weight are requested now, in front of the barrier (the row was written by the previous launch: an L2 / MALL hit)
+    constexpr int kMaxAch = 8;                               // K <= 16384
+    const int cpr = p.Ka >> 3;                               // 16-byte chunks of the row
+    const int ach = (cpr + 255) >> 8;                        // chunks per virtual thread
+    u32x4 xin[kMaxAch], lnw[kMaxAch];
+    if (cw < 4) {
+        const int vt = cw * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < kMaxAch; ++i) {
+            const int c = vt + i * 256;
+            if (i < ach && c < cpr) {
+                xin[i] = *reinterpret_cast<const u32x4*>(p.x + c * 8);
+                lnw[i] = *reinterpret_cast<const u32x4*>(p.ln_weight + c * 8);
+            }
+        }
+    }
+    // launch epoch (tag of this launch's granules): requested now, needed at the first publish
+    const unsigned tag = __hip_atomic_load(p.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // epilogue operands of this workgroup's second-projection quads (residual = the input row, bias): lane q holds quad q's,
+    // requested now so that no global round trip sits in the tail of the launch
+    u32x2 resid_q = {0u, 0u}, bias_q = {0u, 0u};
+    if (nqb > 0) {
+        const int q = qb0 + min(lane, nqb - 1);
+        resid_q = *reinterpret_cast<const u32x2*>(p.x + q * 4);
+        if (p.bias_b) bias_q = *reinterpret_cast<const u32x2*>(p.bias_b + q * 4);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (cw == 0) ENG_STAMP(10);
+
     u32 k_mask, k_mask_odd, k_magic;
     asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask) : "i"(SP::kMask));
     asm volatile("s_mov_b32 %0, %1" : "=s"(k_mask_odd) : "i"(SP::kMaskOdd));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(SP::kMagic));
     bool ok = true;
 
-    // launch epoch (tag of this launch's granules): requested now, needed at the first publish
-    const unsigned tag = __hip_atomic_load(p.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-
     // ---- RMSNorm of the input row into LDS: the arithmetic of the PRO_NORM prologue of w4_packed_gemv_16_body, whose 256
     //      threads are played by consumer waves 0..3 (virtual thread v = 64 cw + lane)
     {
-        const int cpr = p.Ka >> 3;                           // 16-byte chunks of the row
-        const int ach = (cpr + 255) >> 8;                    // chunks per virtual thread (2, 4, 8 there; any count here)
         float* nred = reinterpret_cast<float*>(smem + L.flags) + F_NORM;
         if (cw < 4) {
             const int vt = cw * 64 + lane;
             float ss = 0.f;
-            for (int i = 0; i < ach; ++i) {
+#pragma unroll
+            for (int i = 0; i < kMaxAch; ++i) {
                 const int c = vt + i * 256;
-                if (c < cpr) {
+                if (i < ach && c < cpr) {
                     float hv[8];
-                    unpack8<T>(*reinterpret_cast<const u32x4*>(p.x + c * 8), hv);
+                    unpack8<T>(xin[i], hv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(hv[e], hv[e], ss);
                 }
@@ -382,95 +408,110 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
             if (lane == 0) {
                 nred[cw] = ss;
                 lds_fence();
-                __hip_atomic_fetch_add(const_cast<unsigned*>(flags + F_NORMCNT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_add(flags + F_NORMCNT, 1u);
             }
             ok &= lds_wait_eq(flags + F_NORMCNT, 4u);
             const float r = rsqrtf(((nred[0] + nred[1]) + (nred[2] + nred[3])) / (float)p.Ka + p.eps);
-            for (int i = 0; i < ach; ++i) {
+#pragma unroll
+            for (int i = 0; i < kMaxAch; ++i) {
                 const int c = vt + i * 256;
-                if (c < cpr) {
+                if (i < ach && c < cpr) {
                     float hv[8], wv[8];
-                    unpack8<T>(*reinterpret_cast<const u32x4*>(p.x + c * 8), hv);
-                    unpack8<T>(*reinterpret_cast<const u32x4*>(p.ln_weight + c * 8), wv);
+                    unpack8<T>(xin[i], hv);
+                    unpack8<T>(lnw[i], wv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) hv[e] = Act<T>::round(hv[e] * r) * wv[e];
                     *reinterpret_cast<u32x4*>(smem + L.xrow + (size_t)a_chunk_pos(c >> 2, c & 3) * 16) = pack8<T>(hv);
                 }
             }
             lds_fence();
-            if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(flags + F_XDONE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) lds_add(flags + F_XDONE, 1u);
         }
         ok &= lds_wait_eq(flags + F_XDONE, 4u);
     }
     if (cw == 0) ENG_STAMP(2);
 
-    // epilogue operands of this workgroup's second-projection quads (residual = the input row, bias): lane q holds quad q's,
-    // requested now so that no global round trip sits in the tail of the launch
-    u32x2 resid_q = {0u, 0u}, bias_q = {0u, 0u};
-    {
-        const int nqb = pl.qb1 - pl.qb0;
-        const int q = pl.qb0 + min(lane, nqb > 0 ? nqb - 1 : 0);
-        if (nqb > 0) {
-            resid_q = *reinterpret_cast<const u32x2*>(p.x + q * 4);
-            if (p.bias_b) bias_q = *reinterpret_cast<const u32x2*>(p.bias_b + q * 4);
-        }
-    }
     unsigned long long* granules = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.ws) + kEngWsHeaderBytes);
     float* parts = reinterpret_cast<float*>(smem + L.parts);
 
-    // one task: the sums of (quad, K slice) over its groups, then the epilogue or the K-slice combine
-    auto run_task = [&](int i) {
-        const EngTask t = eng_task(p, pl, i);
+#ifdef QL_ENGINE_TRACE
+    unsigned long long waited[2] = {0, 0}, ntask[2] = {0, 0};   // consumer 0: time spent waiting for a landed slot, tasks run
+#endif
+    // one task (stream index i): the sums of (quad, K slice) over its groups, then the epilogue or the K-slice combine.
+    // Every per-phase quantity arrives as a scalar argument (see the note on scratch above).
+    auto run_task = [&](int i, const int phase, int quad, int qlocal, int ks, int G, int gs, int KS, unsigned arow_off) {
         const int slot = i % kEngSlots;
+        const int g0 = ks * gs;
+        const int ng = max(min(G, g0 + gs) - g0, 1);
+#ifdef QL_ENGINE_TRACE
+        const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
         ok &= lds_wait_eq(flags + F_READY + slot, (unsigned)(i + 1));
+#ifdef QL_ENGINE_TRACE
+        waited[phase] += __builtin_amdgcn_s_memrealtime() - tw0;
+        ++ntask[phase];
+#endif
         const char* sl = smem + L.ring + (size_t)slot * kEngSlotBytes;
-        const int G = t.phase ? pl.Gb : pl.Ga;
-        const char* arow = smem + (t.phase ? L.mid : L.xrow);
-        const int soff = (int)((((int64_t)t.quad * G + t.g0) * 8) & 8);          // the scale fetch started at the 16-byte floor
+        const char* arow = smem + arow_off;
+        const int soff = (int)((((int64_t)quad * G + g0) * 8) & 8);               // the scale fetch started at the 16-byte floor
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const int iters = (t.ng + 63) >> 6;
-        for (int it = 0; it < iters; ++it) {
+        const int iters = (ng + 63) >> 6;
+        // The slot's bytes go to registers first (2 tiles x (4 x 16 B + 8 B) per lane) and the slot is handed back to the loader
+        // BEFORE the math: a slot held for the ~2.5 us of a task's v_dot2c work left the loader 6 free slots of 13 and stalled
+        // the stream (timeline in profiles/r03_mlp_engine.txt).
+        u32x4 w[2][4];
+        u32x2 sv[2];
+        int gq[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
             const int gi = it * 64 + lane;
-            const bool valid = gi < t.ng;
-            const int gic = valid ? gi : t.ng - 1;                                 // in-range LDS addresses for the idle lanes
-            const int g = valid ? t.g0 + gi : G - 1;                               // the clamp of the two-launch kernel (gc)
-            u32x4 w[4];
+            const bool valid = gi < ng;
+            const int gic = valid ? gi : ng - 1;                                   // in-range LDS addresses for the idle lanes
+            gq[it] = valid ? g0 + gi : G - 1;                                      // the clamp of the two-launch kernel (gc)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const u32x4*>(sl + c * 2048 + gic * 16);
-            u32x2 sv = *reinterpret_cast<const u32x2*>(sl + 8192 + soff + gic * 8);
-            if (!valid) sv = u32x2{0u, 0u};
-            u32 av[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32x4 x = *reinterpret_cast<const u32x4*>(arow + (size_t)a_chunk_pos(g, j) * 16);
-                av[4 * j + 0] = x[0];
-                av[4 * j + 1] = x[1];
-                av[4 * j + 2] = x[2];
-                av[4 * j + 3] = x[3];
-            }
-            eng_tile_math<T, STRICT>(w, sv, av, acc, k_mask, k_mask_odd, k_magic);
+            for (int c = 0; c < 4; ++c) w[it][c] = *reinterpret_cast<const u32x4*>(sl + c * 2048 + gic * 16);
+            sv[it] = *reinterpret_cast<const u32x2*>(sl + 8192 + soff + gic * 8);
+            if (!valid) sv[it] = u32x2{0u, 0u};
         }
         lds_fence();                                                               // every read of the slot has returned
         if (lane == 0) flags[F_FREED + slot] = (unsigned)(i + 1);
 #pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (it < iters) {
+                u32 av[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 x = *reinterpret_cast<const u32x4*>(arow + (size_t)a_chunk_pos(gq[it], j) * 16);
+                    av[4 * j + 0] = x[0];
+                    av[4 * j + 1] = x[1];
+                    av[4 * j + 2] = x[2];
+                    av[4 * j + 3] = x[3];
+                }
+#ifdef QL_ENGINE_NOMATH        // timing ablation (results wrong): the consumers touch the operands and skip the dequant + dot work
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] += u32_as_f32((w[it][c][0] ^ w[it][c][1] ^ w[it][c][2] ^ w[it][c][3] ^ sv[it][0] ^ sv[it][1] ^ av[c]) & 0x3fffffffu);
+#else
+                eng_tile_math<T, STRICT>(w[it], sv[it], av, acc, k_mask, k_mask_odd, k_magic);
+#endif
+            }
+        }
+#pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
 
-        const int KS = t.phase ? p.KSb : p.KSa;
         if (KS > 1) {
             // K slices of a quad meet in LDS; whoever arrives last adds them in slice order (the order of the two-launch kernel)
-            float* pq = parts + ((t.phase * kEngMaxQuadsB + t.qlocal) * 4 + t.ks) * 4;
+            float* q0 = parts + ((phase * kEngMaxQuadsB + qlocal) * 4) * 4;
             bool last = false;
             if (lane == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) pq[c] = acc[c];
+                for (int c = 0; c < 4; ++c) q0[ks * 4 + c] = acc[c];
                 lds_fence();
-                const unsigned before = __hip_atomic_fetch_add(const_cast<unsigned*>(flags + F_QCNT + t.phase * kEngMaxQuadsB + t.qlocal), 1u,
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned before = lds_add(flags + F_QCNT + phase * kEngMaxQuadsB + qlocal, 1u);
                 last = before == (unsigned)KS - 1u;
             }
             if (!__builtin_amdgcn_readfirstlane((int)last)) return;
             if (lane == 0) {
-                const float* q0 = parts + ((t.phase * kEngMaxQuadsB + t.qlocal) * 4) * 4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = q0[c];
@@ -479,12 +520,9 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
                 }
             }
         }
-        const int ql = __builtin_amdgcn_readfirstlane(t.qlocal) & 63;
-        const u32 rq0 = (u32)__builtin_amdgcn_readlane((int)resid_q[0], ql), rq1 = (u32)__builtin_amdgcn_readlane((int)resid_q[1], ql);
-        const u32 bq0 = (u32)__builtin_amdgcn_readlane((int)bias_q[0], ql), bq1 = (u32)__builtin_amdgcn_readlane((int)bias_q[1], ql);
-        if (lane != 0) return;
-        const int n0 = t.quad * 4;
-        if (t.phase == 0) {
+        const int n0 = quad * 4;
+        if (phase == 0) {
+            if (lane != 0) return;
             // SiLU(h) * gate on the quad's (h0, h1, gate0, gate1) sums -> ONE granule {pair of outputs, tag}
             float y[4];
 #pragma unroll
@@ -494,9 +532,13 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
             }
             const float o0 = Act<T>::round(Act<T>::round(y[0] / (1.0f + __expf(-y[0]))) * y[2]);
             const float o1 = Act<T>::round(Act<T>::round(y[1] / (1.0f + __expf(-y[1]))) * y[3]);
-            __hip_atomic_store(granules + t.quad, ((unsigned long long)tag << 32) | pack2<T>(o0, o1), __ATOMIC_RELAXED,
+            __hip_atomic_store(granules + quad, ((unsigned long long)tag << 32) | pack2<T>(o0, o1), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         } else {
+            const int ql = __builtin_amdgcn_readfirstlane(qlocal) & 63;
+            const u32 rq0 = (u32)__builtin_amdgcn_readlane((int)resid_q[0], ql), rq1 = (u32)__builtin_amdgcn_readlane((int)resid_q[1], ql);
+            const u32 bq0 = (u32)__builtin_amdgcn_readlane((int)bias_q[0], ql), bq1 = (u32)__builtin_amdgcn_readlane((int)bias_q[1], ql);
+            if (lane != 0) return;
             // out = round(y + x), y = rounded sum (+ bias, rounded): the quad as one 8-byte store (Nb % 4 == 0)
             float rq[4], bq[4], y[4];
             unpack2<T>(rq0, rq[0], rq[1]);
@@ -514,8 +556,24 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
     };
 
     // ---- phase A ----------------------------------------------------------------------------------------------------------------
-    for (int i = cw; i < pl.nA; i += kEngConsumers) run_task(i);
+    // tasks are CLAIMED (one LDS atomic each), not dealt: the consumer that shares its SIMD with the loader runs faster than
+    // the pairs that share one, and a static deal made the slow pairs finish microseconds after the others
+    auto claim = [&](int word) {
+        unsigned i = 0;
+        if (lane == 0) i = lds_add(flags + word, 1u);
+        return __builtin_amdgcn_readfirstlane((int)i);
+    };
+    for (int i = claim(F_NEXT); i < nA; i = claim(F_NEXT)) {
+        const int ql = i / KSa;
+        run_task(i, 0, qa0 + ql, ql, i - ql * KSa, Ga, gsa, KSa, L.xrow);
+    }
     if (cw == 0) ENG_STAMP(3);
+#ifdef QL_ENGINE_TRACE
+    if (lane == 0 && lds_add(flags + F_ENDCNT + 1, 1u) ==
+                         (unsigned)kEngConsumers - 1u)
+        ENG_STAMP(7);                                        // the LAST consumer of the workgroup finished phase A
+    unsigned sweeps = 0;
+#endif
 
     // ---- gather the (1, Kb) row: granule g carries elements 2g, 2g + 1.  Consumer cw sweeps passes cw, cw + 7, ... of 1024
     //      granules (16 relaxed agent-scope 8-byte loads per lane in flight), until every tag of the pass is this launch's
@@ -534,6 +592,9 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) good &= (unsigned)(v[k] >> 32) == tag;
+#ifdef QL_ENGINE_TRACE
+                ++sweeps;
+#endif
                 if (__all(good)) break;
                 if (++spins > kEngSpinGlobal) {
                     ok = false;
@@ -550,20 +611,29 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
                 }
             }
         }
+#ifdef QL_ENGINE_TRACE
+        if (cw == 0) {
+            ENG_STAMP(8);                                    // consumer 0's own sweep complete
+            if (lane == 0 && p.trace) p.trace[(int)blockIdx.x * kEngTraceWords + 9] = sweeps;
+        }
+#endif
         lds_fence();
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(flags + F_GATHER), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) lds_add(flags + F_GATHER, 1u);
         ok &= lds_wait_eq(flags + F_GATHER, (unsigned)kEngConsumers);
     }
     if (cw == 0) ENG_STAMP(4);
 
     // ---- phase B ----------------------------------------------------------------------------------------------------------------
-    for (int j = cw; j < pl.nB; j += kEngConsumers) run_task(pl.nA + j);
+    for (int j = claim(F_NEXT + 1); j < nB; j = claim(F_NEXT + 1)) {
+        const int ql = j / KSb;
+        run_task(nA + j, 1, qb0 + ql, ql, j - ql * KSb, Gb, gsb, KSb, L.mid);
+    }
     if (cw == 0) ENG_STAMP(5);
 
     // ---- end of launch: the last consumer of the last workgroup bumps the epoch (device memory, so graph replays see it)
     if (!ok && lane == 0) __hip_atomic_store(p.ws + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
-        const unsigned before = __hip_atomic_fetch_add(const_cast<unsigned*>(flags + F_ENDCNT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned before = lds_add(flags + F_ENDCNT, 1u);
         if (before == (unsigned)kEngConsumers - 1u) {
             const unsigned done = __hip_atomic_fetch_add(p.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done == gridDim.x - 1u) {
@@ -573,6 +643,12 @@ __global__ __launch_bounds__(kEngThreads, 2) void w4_mlp_engine_kernel(const Eng
         }
     }
     if (cw == 0) ENG_STAMP(6);
+#ifdef QL_ENGINE_TRACE
+    if (cw == 0 && lane == 0 && p.trace) {
+        unsigned long long* tr = p.trace + (int)blockIdx.x * kEngTraceWords;
+        tr[11] = waited[0]; tr[12] = waited[1]; tr[13] = ntask[0]; tr[14] = ntask[1];
+    }
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
@@ -591,7 +667,7 @@ size_t w4_mlp_engine_workspace_bytes(int64_t N_in) { return (size_t)kEngWsHeader
 bool w4_mlp_engine_supported(int64_t Na, int64_t Ka, int64_t Nb, int64_t Kb) {
     if (Na <= 0 || Ka <= 0 || Nb <= 0 || Kb <= 0 || Ka % 32 || Kb % 32 || Na % 4 || Nb % 4 || Kb * 2 != Na || Nb != Ka) return false;
     const int cus = eng_cu_count();
-    if (cus <= 0) return false;
+    if (cus <= 0 || Ka > 16384) return false;
     const int ksa = w4_gemv_ksplit((Na + 3) / 4, Ka / 32), ksb = w4_gemv_ksplit((Nb + 3) / 4, Kb / 32);
     const int64_t gsa = (Ka / 32 + ksa - 1) / ksa, gsb = (Kb / 32 + ksb - 1) / ksb;
     if (gsa > kEngMaxGroupsPerTask || gsb > kEngMaxGroupsPerTask || ksa > 4 || ksb > 4) return false;

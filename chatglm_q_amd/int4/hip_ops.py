@@ -463,6 +463,62 @@ def w4_forward_rows_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias
     return c.reshape(*a.shape[:-1], cols), (hout.reshape(a.shape) if hout is not None else None)
 
 
+def mlp_engine_supported(n_in: int, K: int, n_out: int) -> bool:
+    """True when ``qlinear_w4g32_mlp_engine`` serves a (K -> n_in -> n_out) gated MLP (one persistent launch)."""
+    return bool(_lib.get_lib().qlinear_w4g32_mlp_engine_supported(n_in, K, n_out))
+
+
+def mlp_engine_workspace(n_in: int, device) -> Tensor:
+    """Zeroed workspace of the persistent MLP launch (launch epoch, error word, hand-off granules): one per decode session /
+    stream, reused by every layer's launch of that session (the launches of a stream are ordered)."""
+    nbytes = int(_lib.get_lib().qlinear_w4g32_mlp_engine_workspace_bytes(n_in))
+    ws = torch.zeros(nbytes + 64, dtype=torch.uint8, device=device)
+    off = (-ws.data_ptr()) % 64
+    return ws[off: off + nbytes]
+
+
+def mlp_engine_error(ws: Tensor) -> int:
+    """Host-synchronous read of the workspace's error word: non-zero when a bounded wait of an earlier launch gave up."""
+    return int(ws[8:12].view(torch.int32).item())
+
+
+def w4_mlp_engine(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, bias_in: Tensor | None, n_in: int,
+                  packed_out: Tensor, bias_out: Tensor | None, n_out: int, ws: Tensor, strict: bool | None = None,
+                  plan_out: list | None = None, guards=()) -> Tensor | None:
+    """The MLP of a one-row decode step in ONE persistent launch (``qlinear_w4g32_mlp_engine``): ``round(w_out(silu(h) * gate)
+    + x)`` with ``(h | gate) = w_in(rmsnorm(x) * ln_weight)``; bit-equal to ``w4_forward_fused(PRO_ADDNORM | EPI_SILU_GATE)``
+    followed by ``w4_forward_residual(residual=x)``.  None when the library does not serve the shape that way."""
+    lib = _lib.get_lib()
+    K = x.shape[-1]
+    if x.numel() != K:
+        raise ValueError("the MLP engine serves exactly one row")
+    _check_row_operands("w4_mlp_engine", x, K, ln_weight=ln_weight, bias_in=bias_in, bias_out=bias_out)
+    if n_out != K or not mlp_engine_supported(n_in, K, n_out):
+        return None
+    if gated_packed.numel() < gemv_nbytes(n_in, K, x.dtype) or packed_out.numel() < gemv_nbytes(n_out, n_in // 2, x.dtype):
+        raise AssertionError("w4_mlp_engine: derived buffers too small for the two projections")
+    if ws.device != x.device or ws.data_ptr() % 64 or ws.numel() < int(lib.qlinear_w4g32_mlp_engine_workspace_bytes(n_in)):
+        raise AssertionError("w4_mlp_engine: workspace on another device, misaligned or too small")
+    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.strict_for(x.dtype) if strict is None else strict) else 0
+    x = x.contiguous()
+    out = torch.empty((*x.shape[:-1], n_out), device=x.device, dtype=x.dtype)
+    code = _lib.dtype_code(x.dtype)
+    with torch.cuda.device(x.device):
+        st = lib.qlinear_w4g32_mlp_engine(x.data_ptr(), ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
+                                          packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, out.data_ptr(), ws.data_ptr(), code, flags,
+                                          _lib.stream_ptr(x.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w4g32_mlp_engine")
+    if plan_out is not None:
+        plan_out.append(_lib.make_plan(
+            "qlinear_w4g32_mlp_engine", (None, ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
+                                         packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, None, ws.data_ptr(), code, flags, None),
+            0, 10, 14, 1, K, n_out, x.dtype, x.device, (*guards, ln_weight, bias_in, bias_out),
+            keep=(gated_packed, packed_out, bias_in, bias_out, ln_weight, ws)))
+    return out
+
+
 _PAIR_WS: dict = {}
 
 

@@ -28,6 +28,9 @@ FUSED_DECODE_OPS = os.environ.get("QLINEAR_FUSED_DECODE", "1") not in ("0", "fal
 ROWS_FUSED_MAX = int(os.environ.get("QLINEAR_ROWS_FUSED_MAX", "2"))      # largest batch that takes it (0 / 1: off)
 # experiment: the two MLP projections of a one-row int4 decode step in ONE launch (qlinear_w4g32_mlp_pair)
 MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False")
+# the MLP of a one-row int4 decode step as ONE persistent launch (qlinear_w4g32_mlp_engine: LDS-DMA loader wave + consumer waves
+# per CU)
+MLP_ENGINE = os.environ.get("QLINEAR_MLP_ENGINE", "0") not in ("0", "false", "False")
 
 
 @dataclass
@@ -101,6 +104,7 @@ class KVCache:
         self.capacity = capacity
         self.length = 0            # host-side count of valid positions (not used inside captured graphs)
         self.att_plans: dict = {}  # layer -> (layout epoch, operand addresses, pre-bound attention launch); model._step_one_row
+        self.engine_ws = None      # workspace of the persistent MLP launch (hand-off granules, launch epoch): one per session
 
     def as_tuples(self):
         """Reference-shaped view: tuple of (k, v) each (batch, length, groups, 1, d_head)."""
@@ -417,6 +421,26 @@ class ChatGLM2Model(nn.Module):
                 mod._fast["resid"] = plan_out[0]
             return out
 
+        def mlp_engine(ff, ln, x):
+            w_in, w_out = ff.w_in, ff.w_out
+            plan = w_in._fast.get("engine")
+            if plan is not None and plan[0] is cache:
+                out = plan[1](x)
+                if out is not None:
+                    return out
+            if cache.engine_ws is None:
+                if not H4.mlp_engine_supported(w_in.out_features, w_in.in_features, w_out.out_features):
+                    return None
+                cache.engine_ws = H4.mlp_engine_workspace(w_in.out_features, x.device)
+            gp, gb = w_in.gated_packed(ff.hidden_dim)
+            plan_out = []
+            out = H4.w4_mlp_engine(x, ln.weight, ln.eps, gp, gb, w_in.out_features, w_out.prepare()._packed, w_out.bias,
+                                   w_out.out_features, cache.engine_ws, plan_out=plan_out,
+                                   guards=(w_in.weight, w_in.weight_scale, w_out.weight, w_out.weight_scale))
+            if out is not None and plan_out and plan_out[0] is not None:
+                w_in._fast["engine"] = (cache, plan_out[0])     # the plan bakes this session's workspace in
+            return out
+
         epoch = _lib.layout_epoch()
         att_key = (position_ids.data_ptr(), write_index.data_ptr(), mask.data_ptr(), cache.capacity)
         for i, layer in enumerate(self._layer_sites()):
@@ -439,6 +463,8 @@ class ChatGLM2Model(nn.Module):
                 epoch = _lib.layout_epoch()                 # prepare() above may have built a layout
             h = residual_linear(at.o_proj, att, h)
             hn = None
+            if kind == "int4" and MLP_ENGINE:                  # both MLP projections in one persistent launch
+                hn = mlp_engine(ff, ffn_ln, h)
             if kind == "int4" and MLP_PAIR and not _lib.strict_for(h.dtype):   # round-2 experiment (chained grids), exact-dequant only
                 gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
                 hn = H4.w4_mlp_pair(h, ffn_ln.weight, ffn_ln.eps, gp, gb, ff.w_in.out_features,

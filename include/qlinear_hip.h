@@ -229,6 +229,24 @@ int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, cons
                            const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, const void* residual, void* mid,
                            void* Out, void* workspace, int dtype, void* stream);
 
+/* The MLP of a one-row decode step as ONE PERSISTENT launch (w4_engine.hip):
+ *   Out = round(w_out(round(silu(h) * gate)) + X),  (h | gate) = w_in(rmsnorm(X) * ln_weight)       chatglm_q/model.py:199-201,244-245
+ * bit for bit what qlinear_w4g32_fwd_packed_fused(QL_PRO_ADDNORM | QL_EPI_SILU_GATE) followed by
+ * qlinear_w4g32_fwd_packed_residual(residual = X) compute (flags: 0 or QL_FLAG_STRICT_ROUNDING, as there).  One workgroup per CU:
+ * a loader wave streams both projections' packed weights through an LDS ring with LDS-DMA and never waits for an activation,
+ * seven consumer waves compute the two-launch kernels' per-wave sums out of LDS, the (1, N_in / 2) row between the projections
+ * travels as 8-byte {data, tag} granules in `workspace`.
+ * workspace: qlinear_w4g32_mlp_engine_workspace_bytes(N_in) bytes, 64-byte aligned, zeroed ONCE by the caller and then owned by
+ *   launches of ONE stream (the launch epoch lives in it; word 2 is an error code: non-zero = a bounded wait gave up and the
+ *   results of that launch are garbage).  X and Out must not alias.  fp16 / bf16, group 32.
+ * packed_in: gate-interleaved part 1 of the (K, N_in) projection; packed_out: part 1 of the (N_in / 2, N_out) one; N_out == K.
+ * QL_ERR_UNSUPPORTED when qlinear_w4g32_mlp_engine_supported is 0 (K slice of a task longer than 128 groups, LDS): two launches. */
+size_t qlinear_w4g32_mlp_engine_workspace_bytes(int64_t N_in);
+int qlinear_w4g32_mlp_engine_supported(int64_t N_in, int64_t K, int64_t N_out);
+int qlinear_w4g32_mlp_engine(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
+                             const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, void* Out, void* workspace, int dtype,
+                             int flags, void* stream);
+
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
  * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then
