@@ -140,7 +140,19 @@ def w8a8_config3(torch, device):
     us_g = _graph_time(torch, device, lambda: [hip_ops.w8a8_gemm_tiled(a_q, a_s, t, N, sc) for t in tiled]) / n * 1e3
     us_r1 = _graph_time(torch, device, lambda: [hip_ops.w8a8_forward(a, w, sc) for w in ws]) / n * 1e3
     ops = 2.0 * M * N * K
+    # yardstick, never the target: the vendor library's plain i8 x i8 -> i32 GEMM (torch._int_mm -> hipBLASLt) on the same box,
+    # no scales, no output conversion
+    yard = {}
+    for Mv in (512, 8192):
+        try:
+            av = torch.randint(-127, 128, (Mv, K), dtype=torch.int8, device=device, generator=gen)
+            wts = [w.t() for w in ws[:8]]
+            usv = _graph_time(torch, device, lambda: [torch._int_mm(av, wt) for wt in wts]) / len(wts) * 1e3
+            yard[f"M{Mv}"] = {"us": round(usv, 2), "TOPs": round(2.0 * Mv * N * K / usv / 1e6, 1)}
+        except Exception as e:      # not every build ships the op
+            yard[f"M{Mv}"] = {"error": repr(e)[:200]}
     return {"workload": "act-quant + i8xi8 MFMA GEMM 512x4096->4096 (fused op time, both kernels), tile-major weights",
+            "vendor_i8_gemm_yardstick_torch_int_mm": yard,
             "us": round(us, 2), "TOPs": round(ops / us / 1e6, 1),
             "frac_of_i8_mfma_peak": round(ops / us / 1e6 / I8_MFMA_PEAK_TOPS, 4),
             "act_quant_us": round(us_q, 2), "gemm_us": round(us_g, 2), "gemm_TOPs": round(ops / us_g / 1e6, 1),
@@ -208,6 +220,44 @@ def drop_in_generate(torch, model, prompt, n_tokens=24):
         M.FUSED_DECODE_OPS = prev
 
 
+def _fused_vs_plain(torch, model, prompt):
+    """rel-L2 between the last-position logits of the fused path (prefill + 4 graph-replayed steps) and of the reference-shaped
+    forward() with the fused decode ops switched off, same model, same tokens."""
+    from chatglm_q_amd import model as M
+    from chatglm_q_amd.decoder import DecodeSession
+    dev = model.final_ln.weight.device
+    ids = torch.tensor([prompt], device=dev)
+    sess = DecodeSession(model, 1, 64, use_graph=True)
+    lg = sess.prefill(ids)
+    toks = []
+    sess.tok.copy_(lg.argmax(-1, keepdim=True))
+    sess.capture(greedy=True)
+    for _ in range(4):
+        toks.append(int(sess.tok.item()))
+        lg = sess.decode_step(greedy=True)
+    fused = lg.float()
+    prev = M.FUSED_DECODE_OPS
+    M.FUSED_DECODE_OPS = False
+    try:
+        with torch.no_grad():
+            _, logits, _ = model(input_ids=torch.tensor([prompt + toks], device=dev))
+    finally:
+        M.FUSED_DECODE_OPS = prev
+    plain = logits[:, -1].float()
+    return round(float((fused - plain).norm() / plain.norm()), 6)
+
+
+def _resident_bytes(model):
+    """Bytes a decode + prefill deployment of the model holds: canonical buffers and every derived layout built so far."""
+    tot = {}
+    for m in model.modules():
+        if hasattr(m, "derived_nbytes"):
+            for k, v in m.derived_nbytes().items():
+                tot[k] = tot.get(k, 0) + v
+    tot["total_GB"] = round(sum(v for k, v in tot.items()) / 1e9, 2)
+    return tot
+
+
 def e2e_generate(torch, device):
     """BASELINE config 4: ChatGLM2-6B int4g32 (synthetic weights), batch 1, prompt 32 ids, 128 generated tokens,
     greedy, EOS ignored.  Timing definitions of the reference (chatglm_q/decoder.py:99-106)."""
@@ -219,16 +269,27 @@ def e2e_generate(torch, device):
     prompt = [(37 * i + 11) % cfg.vocab_size for i in range(32)]
     dec = ChatGLMDecoder(None, model)
     out = {}
+    # untimed warm-up of every mode (lazy layouts, graph capture, allocator): round 2 timed them inside the first leg
+    for kw in (dict(use_graph=True, sync_every_token=True), dict(use_graph=False)):
+        list(dec.generate_ids(prompt, max_generated_tokens=8, greedy=True, ignore_eos=True, **kw))
+    streams = {}
     for label, kw in [("graph_sync_every_token", dict(use_graph=True, sync_every_token=True)),
                       ("graph_device_loop", dict(use_graph=True, sync_every_token=False)),
                       ("eager", dict(use_graph=False))]:
         n = 128 if label != "eager" else 32
         toks = list(dec.generate_ids(prompt, max_generated_tokens=n, greedy=True, ignore_eos=True, **kw))
+        streams[label] = toks
         s = dec.last_stats
         out[label] = {"generated": len(toks), "prefill_s": round(s["init_s"], 4),
                       "gen_tok_per_s": round(s["gen_tok_per_s"], 1), "avg_tok_per_s": round(s["avg_tok_per_s"], 1),
                       "linear_GBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 1e9, 1),
                       "linear_frac_of_8TBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 8e12, 4)}
+    # correctness of what was just timed: the three modes emit one token stream, and the logits of a fused
+    # graph-replayed step agree with the same model run through plain torch ops around eager QLinear launches
+    out["check"] = {"graph_equals_device_loop": streams["graph_sync_every_token"] == streams["graph_device_loop"],
+                    "graph_equals_eager_first_32": streams["graph_sync_every_token"][:32] == streams["eager"][:32],
+                    "fused_graph_step_vs_plain_torch_graph_rel_l2": _fused_vs_plain(torch, model, prompt)}
+    out["resident_bytes"] = _resident_bytes(model)
     out["drop_in_reference_graph"] = drop_in_generate(torch, model, prompt)
     out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, greedy, fp16, synthetic weights"
     # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 512 positions (M = 2048 rows per forward)

@@ -316,3 +316,31 @@ def test_decode_with_the_mlp_engine_equals_the_five_launch_step(monkeypatch):
     before = _lib.launch_count()
     list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
     assert n_eager < _lib.launch_count() - before               # one launch less per layer and step
+
+
+def test_decode_only_session_frees_prefill_layouts_and_decodes_the_same():
+    model, cfg = _tiny()
+    ids = torch.randint(0, 320, (1, 40), device=DEV)
+
+    def run(decode_only):
+        for m in model.modules():
+            if hasattr(m, "invalidate"):
+                m.invalidate()
+        sess = DecodeSession(model, 1, 64, use_graph=True, decode_only=decode_only)
+        lg = sess.prefill(ids)                                   # 40 rows: builds part 2 of every layer
+        sess.tok.copy_(lg.argmax(-1, keepdim=True))
+        sess.capture(greedy=True)
+        out = [int(sess.tok.item())]
+        for _ in range(6):
+            sess.decode_step(greedy=True)
+            out.append(int(sess.tok.item()))
+        resident = sum(sum(v for k, v in m.derived_nbytes().items() if k != "canonical") for m in model.modules()
+                       if hasattr(m, "derived_nbytes"))
+        return out, resident
+
+    want, full = run(False)
+    got, lean = run(True)
+    assert got == want
+    assert lean < full
+    w_in = model.layers[0].ffn.w_in
+    assert w_in.derived_nbytes()["tiled"] == 0 and w_in.derived_nbytes()["packed"] == 0 and w_in.derived_nbytes()["gated"] > 0
