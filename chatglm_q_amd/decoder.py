@@ -203,6 +203,10 @@ class DecodeSession:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             self._step_body(greedy)                             # warm-up: allocations, lazy repacks
+            # the warm-up built what the step reads (e.g. the gate-interleaved copy of w_in): what it made redundant goes now,
+            # and the step runs once more so that every pre-bound launch exists before the capture
+            if self.decode_only and self.release_prefill_layouts():
+                self._step_body(greedy)
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
