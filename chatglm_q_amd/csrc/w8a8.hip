@@ -21,6 +21,7 @@
 //     their step fill each other's barrier / LDS-latency gaps - the same total MFMA work, twice the latency hiding;
 //   * the A tile is staged global -> VGPR -> LDS one step ahead, XOR-swizzled so that fragment reads are conflict-free.
 #include <type_traits>
+#include <utility>
 
 // developer ablation switches for tools/w8a8_ablate.sh (always 0 in the shipped library): 1 no MFMA, 2 no steady-state W
 // loads, 4 no steady-state A loads, 8 no LDS fragment reads, 16 no block barriers in the K loop, 32 no LDS stores
@@ -235,7 +236,75 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 // first-tile latency and epilogue around every 19 us loop, profiles/r02_w8a8_timeline.txt).
 // COLG (with NG = 2): the two groups are COLUMN groups instead - the block covers 256 columns, both groups walk the same K
 // chunks and share ONE A tile in LDS (half the A bytes per flop from L2 / the fabric, no exchange at the end).
-template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false>
+// ---- NITER + ADMA form: the wave's vector-memory queue counted by hand --------------------------------------------------------
+// Every load of the K pipeline is an inline-asm statement (hipcc sees none of them and inserts no vmcnt waits of its own):
+// W fragments global -> VGPR, A pieces global -> LDS by LDS-DMA (no VGPR round trip, no ds_write pass: the ablation builds put
+// the ds_write pass at 2.7 of the loop's 8.4 us).  Loads complete in issue order, so "operand X has landed" = "at most N
+// younger loads are still outstanding"; the issue order is fixed at compile time, these functions restate it.
+//   prologue:            A(0) W(0) [PF PF] A(1) W(1) A(2)                      (A(k): 4 pieces, W(k): 8 fragments of chunk-iteration k)
+//   iteration j, behind the MFMAs of sub-step s:   W(j + 2, s)   then   A(j + 3, s) if s < 4
+#ifndef QL_W8A8_PF
+#define QL_W8A8_PF 0                                // L2-prefetch instructions per wave behind W(0) (0: none; 2 measured 18.5 vs 17.1 us cold, 16.7 vs 14.0 us cache-hot: a 64-line gather costs the load path more than it saves)
+#endif
+constexpr int kAdmaPieces = 4, kAdmaSubs = 8, kAdmaPf = QL_W8A8_PF, kAdmaPrologue = 3 * kAdmaPieces + 2 * kAdmaSubs + kAdmaPf;
+constexpr int adma_min(int a, int b) { return a < b ? a : b; }
+constexpr int adma_issued_before(int niter, int j, int s) {      // loads issued before sub-step s of iteration j begins (closed
+    // form, no loops: inner loops with a trip count that depends on the unrolled index kept hipcc from unrolling the K loop)
+    return kAdmaPrologue + kAdmaSubs * adma_min(j, niter > 2 ? niter - 2 : 0) + kAdmaPieces * adma_min(j, niter > 3 ? niter - 3 : 0) +
+           (j + 2 < niter ? s : 0) + (j + 3 < niter ? adma_min(s, kAdmaPieces) : 0);
+}
+constexpr int adma_idx_w(int niter, int k, int s) {              // position of W(k, s) in the issue order
+    return k == 0 ? kAdmaPieces + s : k == 1 ? 2 * kAdmaPieces + kAdmaSubs + kAdmaPf + s : adma_issued_before(niter, k - 2, s);
+}
+constexpr int adma_idx_a_last(int niter, int k) {                // position of the last piece of A(k)
+    return k == 0 ? kAdmaPieces - 1 : k == 1 ? 2 * kAdmaPieces + kAdmaSubs + kAdmaPf - 1 : k == 2 ? kAdmaPrologue - 1
+                  : adma_issued_before(niter, k - 3, kAdmaPieces - 1) + 1;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_imm(i32x4& w) {          // ... tied to the fragment it releases: its MFMA cannot move above
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w) : "n"(N) : "memory");
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) - the wait counts are
+// template arguments (a run-time switch over 41 immediates per wait made the loop body too large for hipcc to unroll)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+// 64 lanes x 16 bytes: global (wave-uniform 64-bit base + per-lane byte offset) -> 1 KB of LDS at `lds_dst` + 16 lane.  M0 holds
+// the LDS address and is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(unsigned lds_dst, unsigned voff, unsigned long long base) {
+    unsigned keep;
+    // s_nop 4: when hipcc materialises the base with v_readfirstlane (it does whenever it cannot prove the chunk index uniform), a
+    // VALU write of an SGPR needs 5 wait states before a VMEM instruction reads it, and the hazard pass does not look inside asm
+    // (the stamped build faulted on addresses with a stale high half until these were added)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gload16(i32x4& dst, unsigned voff, unsigned long long base) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ unsigned long long sgpr64(unsigned long long v) {   // wave-uniform value -> an SGPR pair
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// NITER > 0: the K loop fully unrolled for exactly NITER iterations per K-parity group (K = NITER * KP * BK, no K tail): every
+// prefetch condition is a compile-time constant, so hipcc's vmcnt waits are exact counts.  Round 3, read in the ISA: with
+// K = 4096 (8 iterations) the generic form below never enters its steady-state loop (it needs U + DEPTH + 2 = 10 iterations)
+// and runs ALL of config 3 in the peeled tail, whose conditional loads make the compiler drain the queue (vmcnt(0)) at the
+// head of every iteration - load latency, LDS staging and MFMAs in series, 1.2 us per iteration where each alone is 0.3 - 0.5.
+// The unrolled form also spreads the next loads / LDS stores over the sub-steps (one W load behind each MFMA pair) instead
+// of issuing 10 KB per wave in one burst at the end of the iteration, where all 8 waves queue at the CU's 64 B/clk load path.
+template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false, int NITER = 0, bool ADMA = false>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
                                                          int N, int K, int nbx, int rotate, int super_rows, const float* __restrict__ a_scale,
                                                          const T* __restrict__ S_, const T* __restrict__ bias,
@@ -254,7 +323,8 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     constexpr int BUF = BM * BK;                       // one A-tile buffer
     constexpr int NS = 4 * S;                          // MFMA sub-steps per chunk
     const T* __restrict__ Sc = S_;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][3 buffers][BUF]; reused by the epilogue
+    constexpr int NB = ADMA ? 4 : 3;                   // A-tile buffers per K-parity group
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 groups][NB buffers][BUF]; reused by the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, tg = COLG ? tid : tid & 255;
     QL_STAMP(0);
@@ -270,7 +340,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * (BN / 32) + (COLG ? grp * 4 : 0) + wv;
     const int8_t* wbase = Wm + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 2048 + lane * 16;
-    char* lds_a = smem + kgrp * (3 * BUF);
+    char* lds_a = smem + kgrp * (NB * BUF);
 
     // swizzle: chunk c of row r sits at chunk position CPR r + (c ^ x(r)); 128-byte rows: x = (r >> 1) & 7, 256-byte
     // rows (one row = all 64 banks): x = r & 15 - fragment reads (16 lanes = 16 rows, one chunk index) conflict-free
@@ -316,7 +386,11 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     // K ROTATION (see the header): block (x, y) starts at phase (2 y + x mod 4) of its K walk.  Measured neutral at
     // 512 x 4096 x 4096 (19.2 vs 19.4 us) - kept behind QLINEAR_W8A8_ROTATE=1 for experiments, default off.
     const int phases = niter < 16 ? niter : 16;
-    const int rot = rotate ? ((2 * tile.y + (tile.x & 3)) % phases) * (niter / phases) : 0;
+    // NITER form: the blocks that share a weight panel (the row tiles of one column tile, all on one XCD) start at different K
+    // chunks, so that between them their first iteration requests the WHOLE panel from HBM at once; walking K in lockstep they
+    // all wait for the same few lines and the compulsory misses of the launch go out 1/NITER at a time (tools/microbench/
+    // l2_share_probe.hip, this pattern with weights from HBM: 15.3 us per launch in lockstep, 11.7 us rotated, 8.8 us L2-hot)
+    const int rot = NITER > 0 ? ((rotate > 0 && NITER % rotate == 0) ? (tile.y % rotate) * (NITER / rotate) : 0) : rotate > 0 ? ((2 * tile.y + (tile.x & 3)) % phases) * (niter / phases) : 0;
     auto chunk_of = [&](int i) {                       // K chunk of loop iteration i (i may run past niter: clamped by users)
         int r = i + rot;
         r = r >= niter ? r - niter : r;
@@ -399,10 +473,85 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
         else mma_chunk_partial(buf, nbuf, w, units);
     };
 
+    if constexpr (NITER > 0 && ADMA) {
+        static_assert(DEPTH == 2 && S == 2 && ACH == kAdmaPieces && NS == kAdmaSubs && kAllStage, "the issue order restated by adma_*()");
+        // per-lane source offsets of the A pieces: LDS-DMA writes lane-linear, so the swizzle goes into the SOURCE address -
+        // the thread at chunk position q of the tile (row q / CPR, position cp = q % CPR) fetches source chunk cp ^ swz(row)
+        unsigned a_off[ACH];
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) {
+            const int q = tg + u * STG, r = q / CPR, cp = q % CPR;
+            a_off[u] = (unsigned)((m0 + r < M) ? (m0 + r) : (M - 1)) * (unsigned)K + (unsigned)((cp ^ swz(r)) * 16);
+        }
+        const unsigned lds_grp = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)smem + (unsigned)(kgrp * (NB * BUF)) + (unsigned)((tg >> 6) * 1024)));
+        const unsigned w_off = (unsigned)lane * 16u;
+        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
+        const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)Aq);
+        const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wm + (unsigned long long)ct * (unsigned long long)ksteps64 * 2048ull);
+        auto issue_a = [&](int k, int u) {             // piece u of A(k) -> buffer k % NB
+            const int t = chunk_of(k);
+            glds16(lds_grp + (unsigned)((k % NB) * BUF + u * STG * 16), a_off[u], sgpr64(a_base + (unsigned long long)(t * BK)));
+        };
+        i32x4 wr[DEPTH][NS];
+        auto issue_w = [&](int k, int sub) {           // fragment `sub` of W(k) -> register slot k % DEPTH
+            const int t = chunk_of(k);
+            gload16(wr[k % DEPTH][sub], w_off, sgpr64(w_base + (unsigned long long)((2 * S * t + (sub >> 1)) * 2048 + (sub & 1) * 1024)));
+        };
+        QL_STAMP(7);
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) issue_a(0, u);
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) issue_w(0, sub);
+        // L2 prefetch (cold weights): one dword per 128-byte line, 64 lines = 8 KB per instruction.  The row tiles that share this
+        // column tile each touch ANOTHER K chunk of the wave's weight stream (between them: all of it), and the XCD's 256 waves
+        // touch 8 KB each of the activation tile rows - every compulsory miss of the launch is in flight behind the first tile's
+        // loads instead of going out one pipeline stage at a time (tools/microbench/l2_share_probe.hip: 15.2 -> 12.2 us)
+        int pf0 = 0, pf1 = 0;
+        if constexpr (kAdmaPf == 2) {
+            const int tp = KP * (tile.y % NITER) + kgrp;
+            const int pw = (int)(blockIdx.x >> 3) * (NG * 4) + wave;               // wave index within the XCD (speed only)
+            const int64_t a_bytes = (int64_t)M * K;
+            int64_t a_pf = (int64_t)pw * 8192 + lane * 128;
+            a_pf = a_pf < a_bytes ? a_pf : a_bytes - 4;
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(pf0) : "v"((unsigned)lane * 128u), "s"(sgpr64(w_base + (unsigned long long)(2 * S * tp) * 2048ull)) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(Aq + a_pf) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) issue_a(1, u);
+#pragma unroll
+        for (int sub = 0; sub < NS; ++sub) issue_w(1, sub);
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) issue_a(2, u);
+        QL_STAMP(1);
+        vm_wait_imm<kAdmaPrologue - adma_idx_a_last(NITER, 1) - 1>();     // A(0), A(1) have landed (this wave's pieces)
+        __syncthreads();
+        QL_STAMP(2);
+        read_a(0, 0, fa[0]);
+        static_for<NITER>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int buf = i % NB, nbuf = (i + 1) % NB;
+            static_for<NS>([&](auto sc) {
+                constexpr int sub = decltype(sc)::value;
+                if constexpr (sub + 1 < NS) read_a(buf, sub + 1, fa[(sub + 1) & 1]);
+                else if constexpr (i + 1 < NITER) read_a(nbuf, 0, fa[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                vm_wait_imm<adma_issued_before(NITER, i, sub) - adma_idx_w(NITER, i, sub) - 1>(wr[i % DEPTH][sub]);
+                if constexpr (i == 1 && sub == 0 && kAdmaPf == 2) asm volatile("" : "+v"(pf0), "+v"(pf1));   // older than W(1): landed; registers free from here
+                mma(fa[sub & 1], wr[i % DEPTH][sub]);
+                if constexpr (i + 2 < NITER) issue_w(i + 2, sub);
+                if constexpr (sub < ACH && i + 3 < NITER) issue_a(i + 3, sub);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (i + 2 < NITER) vm_wait_imm<adma_issued_before(NITER, i + 1, 0) - adma_idx_a_last(NITER, i + 2) - 1>();   // A(i + 2) landed
+            if constexpr (i + 1 < NITER) __syncthreads();
+        });
+        QL_STAMP(3);
+    } else {
     // prologue: A tiles of iterations 0 and 1 into LDS, ring slot d <- W of iteration d and A of iteration d + 2.
     // Request order = need order: the first MFMA needs A(0) and W(0) only.
     {
         i32x4 a0[ACH], a1[ACH];
+        QL_STAMP(7);                                   // address setup done: the first load goes now
         load_a(0, a0);
         load_w(0, st[0]);
         load_a(1, a1);
@@ -424,7 +573,32 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     // count rounded up to the unroll (an extra iteration does no MFMAs).  The peeled form (main loop + tail with
     // conditional loads) drains the ring in every tail iteration (hipcc's vmcnt bookkeeping turns conservative: vmcnt(0)
     // in the ISA), and with K = 4096 the tail is most of the loop.
-    if constexpr (DEPTH % 3 == 0) {
+    if constexpr (NITER > 0) {
+        static_assert(DEPTH == 2 && ACH <= NS / 2, "schedule below: ACH stores, then ACH loads, over the NS sub-steps");
+#pragma unroll
+        for (int i = 0; i < NITER; ++i) {
+            const int d = i % DEPTH, buf = i % 3, nbuf = (i + 1) % 3, wbuf = (i + 2) % 3;
+            const int tw = chunk_of(i + DEPTH), ta = chunk_of(i + DEPTH + 2);              // chunks fetched this iteration
+#pragma unroll
+            for (int sub = 0; sub < NS; ++sub) {
+                if (sub + 1 < NS) read_a(buf, sub + 1, fa[(sub + 1) & 1]);
+                else if (i + 1 < NITER) read_a(nbuf, 0, fa[0]);
+                __builtin_amdgcn_sched_barrier(0);                                 // the next fragments are requested BEFORE these MFMAs
+                mma(fa[sub & 1], st[d].w[sub]);
+                if (i + DEPTH < NITER && !(QL_W8A8_ABLATE & 2))                    // the fragment just consumed is re-requested
+                    st[d].w[sub] = *reinterpret_cast<const i32x4*>(wbase + (int64_t)(2 * S * tw + (sub >> 1)) * 2048 + (sub & 1) * 1024);
+                if (sub < ACH && i + 2 < NITER && !(QL_W8A8_ABLATE & 32) && (kAllStage || tg + sub * STG < NCH))
+                    *reinterpret_cast<i32x4*>(lds_a + wbuf * BUF + a_dst[sub]) = st[d].a[sub];
+                if (sub >= NS - ACH && i + DEPTH + 2 < NITER && !(QL_W8A8_ABLATE & 4))
+                    st[d].a[sub - (NS - ACH)] = *reinterpret_cast<const i32x4*>(a_src[sub - (NS - ACH)] + ta * BK);
+                // (pinned with sched_barrier: given sched_group_barrier hints hipcc moved the fragment reads BEHIND the MFMAs of the
+                // sub-step before and waited lgkmcnt(0) in front of every MFMA - no lookahead left, seen in the ISA)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(QL_W8A8_ABLATE & 16)) __syncthreads();
+        }
+        QL_STAMP(3);
+    } else if constexpr (DEPTH % 3 == 0) {
         for (int it = 0; it < niter; it += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
@@ -476,6 +650,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     }
 
     }
+    }   // register-staged forms
     QL_STAMP(4);                                       // K loop done
     // epilogue operands requested NOW: their global round trip overlaps the exchange below instead of sitting in the
     // wave's tail (measured on the ablation builds: the epilogue was 2.1 us of a 19 us kernel)
@@ -566,24 +741,24 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     QL_STAMP(6);                                       // output tiles stored (this wave)
 }
 
-template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false>
+template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false, int NITER = 0, bool ADMA = false>
 static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* Sc, const void* bias, void* C,
                                 int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     constexpr int BM = 32 * MT;
     constexpr int BN = COLG ? 128 * NG : 128;
     const int nbx = (int)((N + BN - 1) / BN), nby = (int)((M + BM - 1) / BM);
-    constexpr int kTiles = (COLG ? 1 : NG) * 3 * BM * 128 * S;                  // K-parity groups x three A buffers
+    constexpr int kTiles = (COLG ? 1 : NG) * (ADMA ? 4 : 3) * BM * 128 * S;     // K-parity groups x three (LDS-DMA form: four) A buffers
     constexpr int kLds = kTiles < NG * 8192 ? NG * 8192 : kTiles;              // epilogue: 2 KB per wave
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG, NITER, ADMA>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
-    static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch
+    static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch (1: rotation on; measured 17.5 vs 17.2 us in the unrolled form)
     static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
     const int sy = NG == 1 ? 8 : 4;                    // blocks in flight per XCD: 64 (two per CU) or 32
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
-    w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
+    w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG, NITER, ADMA><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, super ? sy : 0,
         a_scale, (const T*)Sc,
         (const T*)bias, (T*)C, ldc);
@@ -609,6 +784,12 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
     if (mt == 4 && colg == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 4 && ng == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 1>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    static const int no_unroll = [] { const char* e = getenv("QLINEAR_W8A8_UNROLL"); return e && atoi(e) == 0; }();   // A/B switch
+    static const int no_adma = [] { const char* e = getenv("QLINEAR_W8A8_ADMA"); return e && atoi(e) == 0; }();       // A/B switch
+    if (mt == 2 && K == 4096 && !no_unroll && !no_adma && M * K < (int64_t)1 << 31)   // ... with A by LDS-DMA, hand-counted VM queue
+        return launch_w8a8_tiled_mt<T, 2, 2, 2, 2, false, 8, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    if (mt == 2 && K == 4096 && !no_unroll)            // 8 iterations of 256 bytes per K-parity group, fully unrolled (config 3)
+        return launch_w8a8_tiled_mt<T, 2, 2, 2, 2, false, 8>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 2) return launch_w8a8_tiled_mt<T, 2, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     return launch_w8a8_tiled_mt<T, 1, 2, 3, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 }

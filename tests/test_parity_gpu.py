@@ -451,7 +451,9 @@ def test_act_quant_bit_exact_vs_oracle(M, K, dt, per_tensor):
 W8A8_TILED_SHAPES = [(512, 4096, 4096, "f16"), (70, 1024, 200, "f16"), (33, 512, 96, "bf16"), (64, 256, 64, "f32"),
                      (1, 4096, 256, "f16"), (130, 13696, 136, "f16"), (300, 208, 130, "f32"), (2048, 1024, 512, "bf16"),
                      (513, 4160, 264, "f16"), (8192, 4096, 512, "f16"), (40, 64, 40, "f16"), (96, 16, 32, "f16"),
-                     (1000, 1088, 1000, "bf16")]
+                     (1000, 1088, 1000, "bf16"),
+                     # K = 4096 at 64-row tiles: the fully unrolled K loop (round 3), ragged M / N, every output dtype
+                     (100, 4096, 200, "bf16"), (64, 4096, 136, "f32"), (257, 4096, 1000, "f16")]
 
 
 @pytest.mark.parametrize("M,K,N,dt", W8A8_TILED_SHAPES)

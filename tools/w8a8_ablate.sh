@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   make -C $CS >/dev/null
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc $FLAGS -DQL_W8A8_ABLATE=$v -c $CS/w8a8.hip -o /tmp/w8a8_abl$v.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/libql_abl$v.so $(ls $CS/*.o | grep -v w8a8.o) /tmp/w8a8_abl$v.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/libql_abl$v.so $(ls $CS/*.o | grep -v "w8a8.o\|_span.o\|_trace.o\|_nomath.o") /tmp/w8a8_abl$v.o
   done
 else
   echo "variant 0 (product)"; python tools/w8a8_config3.py --gemm-only

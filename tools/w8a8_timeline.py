@@ -13,7 +13,7 @@ from chatglm_q_amd import _lib  # noqa: E402
 from chatglm_q_amd.int8 import hip_ops as h8  # noqa: E402
 
 NAMES = ["wave start", "setup done, prologue loads issued", "first A tiles in LDS (barrier)", "main loop done", "K loop done",
-         "K-parity groups combined", "output stored"]
+         "K-parity groups combined", "output stored", "address setup done (first load issues)"]
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
         torch.cuda.synchronize()
         buf = np.zeros((blocks, 8), dtype=np.uint64)
         assert lib.qlinear_w8a8_stamps_read(buf.ctypes.data, blocks) == 0
-        t = buf[:, :7].astype(np.int64)
+        t = buf[:, :8].astype(np.int64)
         t0 = t[:, 0].min()
         rows.append((t - t0) * 0.01)
     r = np.median(np.stack(rows), axis=0)                   # median over repetitions, per block and point
