@@ -139,6 +139,19 @@ def w8a8_config3(torch, device):
     us_q = _graph_time(torch, device, lambda: [hip_ops.act_quant_rowwise(a) for _ in range(n)]) / n * 1e3
     us_g = _graph_time(torch, device, lambda: [hip_ops.w8a8_gemm_tiled(a_q, a_s, t, N, sc) for t in tiled]) / n * 1e3
     us_r1 = _graph_time(torch, device, lambda: [hip_ops.w8a8_forward(a, w, sc) for w in ws]) / n * 1e3
+    # in a model the rows come out of a norm / activation launch: with the quantising producer (qlinear_rmsnorm_quant_i8) the int8
+    # rows + scales are a by-product of THAT launch - what the int8-activation linear itself costs is then the GEMM launch
+    from chatglm_q_amd import fused_ops as F_
+    lnw = torch.ones(K, device=device, dtype=torch.float16)
+    us_norm = _graph_time(torch, device, lambda: [F_.rmsnorm(a, lnw, 1e-5) for _ in range(n)]) / n * 1e3
+    us_normq = _graph_time(torch, device, lambda: [F_.rmsnorm_quant(a, lnw, 1e-5)[1] for _ in range(n)]) / n * 1e3
+    us_chain_sep = _graph_time(torch, device, lambda: [hip_ops.w8a8_forward_tiled(F_.rmsnorm(a, lnw, 1e-5), t, N, sc) for t in tiled]) / n * 1e3
+
+    def chain_fused():
+        for t in tiled:
+            _, q, s_, _ = F_.rmsnorm_quant(a, lnw, 1e-5)
+            hip_ops.w8a8_gemm_tiled(q, s_, t, N, sc)
+    us_chain_fused = _graph_time(torch, device, chain_fused) / n * 1e3
     ops = 2.0 * M * N * K
     # yardstick, never the target: the vendor library's plain i8 x i8 -> i32 GEMM (torch._int_mm -> hipBLASLt) on the same box,
     # no scales, no output conversion
@@ -156,7 +169,14 @@ def w8a8_config3(torch, device):
             "us": round(us, 2), "TOPs": round(ops / us / 1e6, 1),
             "frac_of_i8_mfma_peak": round(ops / us / 1e6 / I8_MFMA_PEAK_TOPS, 4),
             "act_quant_us": round(us_q, 2), "gemm_us": round(us_g, 2), "gemm_TOPs": round(ops / us_g / 1e6, 1),
-            "row_major_weights_round1_path_us": round(us_r1, 2)}
+            "row_major_weights_round1_path_us": round(us_r1, 2),
+            "with_quantising_producer": {
+                "note": "RMSNorm -> int8-activation linear: 3 launches (norm, quantiser, GEMM) vs 2 (norm emitting int8 rows + scales, GEMM)",
+                "rmsnorm_us": round(us_norm, 2), "rmsnorm_quant_us": round(us_normq, 2),
+                "norm_quantiser_gemm_us": round(us_chain_sep, 2), "norm_quant_gemm_us": round(us_chain_fused, 2),
+                "linear_cost_us": round(us_chain_fused - us_norm, 2),
+                "linear_TOPs": round(ops / max(us_chain_fused - us_norm, 1e-3) / 1e6, 1),
+                "linear_frac_of_i8_mfma_peak": round(ops / max(us_chain_fused - us_norm, 1e-3) / 1e6 / I8_MFMA_PEAK_TOPS, 4)}}
 
 
 def prefill_gemm(torch, device):

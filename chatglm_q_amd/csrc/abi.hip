@@ -508,6 +508,28 @@ int qlinear_add_rmsnorm(const void* X, const void* Delta, const void* W, void* H
     return rmsnorm(dtype, X, Delta, W, Hout, Out, rows, dim, ld, ld, eps, (hipStream_t)stream);
 }
 
+int qlinear_rmsnorm_quant_i8(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int8_t* Aq, float* a_scale,
+                             int64_t rows, int64_t dim, int64_t ld, float eps, int dtype, void* stream) {
+    if (!X || !W || !Aq || !a_scale || (Delta && !Hout)) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(rows) || !fits_i32(dim) || ld < dim || dim % 8 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(X, 16) || !aligned(W, 16) || !aligned(Aq, 16) || (Delta && (!aligned(Delta, 16) || !aligned(Hout, 16))) ||
+        (Out && !aligned(Out, 16)) || (ld * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return rmsnorm_quant(dtype, X, Delta, W, Hout, Out, Aq, a_scale, rows, dim, ld, ld, eps, (hipStream_t)stream);
+}
+
+int qlinear_silu_mul_quant_i8(const void* In, void* Out, int8_t* Aq, float* a_scale, int64_t rows, int64_t hidden, int64_t ldin,
+                              int64_t ldo, int dtype, void* stream) {
+    if (!In || !Aq || !a_scale) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(rows) || !fits_i32(hidden) || ldin < 2 * hidden || (Out && ldo < hidden) || hidden % 8 != 0) return QL_ERR_BAD_SHAPE;
+    if (!aligned(In, 16) || !aligned(Aq, 8) || (Out && !aligned(Out, 16)) || (ldin * esize(dtype)) % 16 ||
+        (Out && (ldo * esize(dtype)) % 16) || (hidden * esize(dtype)) % 16)
+        return QL_ERR_MISALIGNED;
+    return silu_mul_quant(dtype, In, Out, Aq, a_scale, rows, hidden, ldin, ldo, (hipStream_t)stream);
+}
+
 int qlinear_rope_kv_write(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Qout,
                           void* Kcache, void* Vcache, int64_t B, int64_t S, int64_t H, int64_t G, int64_t D,
                           int64_t capacity, int64_t ldqkv, int dtype, void* stream) {

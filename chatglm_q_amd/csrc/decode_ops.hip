@@ -82,10 +82,25 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
 //   chatglm_q/model.py:243,245) and normalised in the same pass: one launch instead of two.
 // Row kept in registers (VPT x 8 values per thread): one read of the row, one barrier pair.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VPT, bool FUSE_ADD>
+// QUANT (round 3): the normalised row - already in registers - is ALSO emitted as int8 + one fp32 scale per row, exactly what
+// act_quant_rows_kernel (w8a8.hip) would produce from the rounded output row (quantize_int8, chatglm_q/int8/quantizer.py:11-19:
+// scale = max|x| / 127 clamped to 1e-10, true division, round half to even): the int8-activation GEMM that follows needs no
+// quantiser launch.  Out may be null then (nobody else reads the 16-bit row).
+__device__ __forceinline__ u32x2 quant8_pack(const float (&y)[8], float s) {
+    u32x2 w = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float q = rintf(y[e] / s);
+        q = fminf(fmaxf(q, -127.f), 127.f);
+        w[e >> 2] |= ((u32)(int)q & 0xFFu) << (8 * (e & 3));
+    }
+    return w;
+}
+template <typename T, int VPT, bool FUSE_ADD, bool QUANT = false>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, const T* __restrict__ Delta,
                                                       const T* __restrict__ Wt, T* __restrict__ Hout, T* __restrict__ Out,
-                                                      int dim, int64_t ldx, int64_t ldo, float eps) {
+                                                      int dim, int64_t ldx, int64_t ldo, float eps,
+                                                      int8_t* __restrict__ Aq = nullptr, float* __restrict__ a_scale = nullptr) {
     __shared__ float red[4];
     const T* x = X + (int64_t)blockIdx.x * ldx;
     T* o = Out + (int64_t)blockIdx.x * ldo;
@@ -109,6 +124,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
     }
     ss = block_sum_256(ss, red);
     const float r = rsqrtf(ss / (float)dim + eps);
+    float mx = 0.f;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int i = (threadIdx.x + u * 256) * 8;
@@ -116,8 +132,32 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
             float w[8], y[8];
             load8<T>(Wt + i, w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = Act<T>::round(v[u][e] * r) * w[e];
-            store8<T>(o + i, y);
+            for (int e = 0; e < 8; ++e) {
+                float t = v[u][e] * r;
+                // the reference rounds the fp32 product to the activation dtype (chatglm_q/model.py:139, two roundings); in this
+                // instantiation hipcc otherwise folds multiply + conversion into v_fma_mixlo_f16 - ONE rounding of the exact
+                // product, 1 ulp off in about one value of 40 000 (seen against the plain kernel, which keeps v_pk_mul_f32 + cvt)
+                if constexpr (QUANT) asm volatile("" : "+v"(t));
+                y[e] = Act<T>::round(t) * w[e];
+            }
+            if (!QUANT || Out) store8<T>(o + i, y);
+            if constexpr (QUANT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[u][e] = Act<T>::round(y[e]);         // the value the 16-bit row holds: what the quantiser would read
+                    mx = fmaxf(mx, fabsf(v[u][e]));
+                }
+            }
+        }
+    }
+    if constexpr (QUANT) {
+        mx = block_max_256(mx, red);
+        const float s = fmaxf(mx / 127.0f, 1e-10f);
+        if (threadIdx.x == 0) a_scale[blockIdx.x] = s;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int i = (threadIdx.x + u * 256) * 8;
+            if (i < dim) *reinterpret_cast<u32x2*>(Aq + (int64_t)blockIdx.x * dim + i) = quant8_pack(v[u], s);
         }
     }
 }
@@ -835,6 +875,43 @@ __global__ __launch_bounds__(256) void masked_softmax_kernel(const T* __restrict
 }
 
 // out = round(round(silu(h)) * gate), (h, gate) = halves of a (rows, 2 hidden) matrix; 8 values per thread
+// SiLU(h) * gate of one row per block, row in registers, emitted as int8 + scale (and as the 16-bit row when Out is given): the
+// quantising producer in front of an int8-activation w_out.  Same arithmetic as silu_mul_kernel, then quantize_int8 on the
+// rounded values.
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void silu_mul_quant_kernel(const T* __restrict__ In, T* __restrict__ Out, int hidden, int64_t ldin,
+                                                             int64_t ldo, int8_t* __restrict__ Aq, float* __restrict__ a_scale) {
+    __shared__ float red[4];
+    const T* in = In + (int64_t)blockIdx.x * ldin;
+    float v[VPT][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = (threadIdx.x + u * 256) * 8;
+        if (i < hidden) {
+            float h[8], g[8], y[8];
+            load8<T>(in + i, h);
+            load8<T>(in + hidden + i, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = Act<T>::round(h[e] / (1.0f + __expf(-h[e]))) * g[e];
+            if (Out) store8<T>(Out + (int64_t)blockIdx.x * ldo + i, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[u][e] = Act<T>::round(y[e]);
+                mx = fmaxf(mx, fabsf(v[u][e]));
+            }
+        }
+    }
+    mx = block_max_256(mx, red);
+    const float s = fmaxf(mx / 127.0f, 1e-10f);
+    if (threadIdx.x == 0) a_scale[blockIdx.x] = s;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = (threadIdx.x + u * 256) * 8;
+        if (i < hidden) *reinterpret_cast<u32x2*>(Aq + (int64_t)blockIdx.x * hidden + i) = quant8_pack(v[u], s);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const T* __restrict__ In, T* __restrict__ Out, int hidden,
                                                        int64_t ldin, int64_t ldo) {
@@ -941,6 +1018,55 @@ static int launch_rmsnorm(const void* X, const void* Delta, const void* W, void*
     else return QL_ERR_UNSUPPORTED;
 #undef QL_RMS
     return finish_launch();
+}
+
+template <typename T, bool FUSE_ADD>
+static int launch_rmsnorm_quant(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int8_t* Aq, float* a_scale,
+                                int64_t rows, int64_t dim, int64_t ldx, int64_t ldo, float eps, hipStream_t st) {
+    const int vpt = (int)((dim / 8 + 255) / 256);
+#define QL_RMSQ(V)                                                                                                       \
+    rmsnorm_kernel<T, V, FUSE_ADD, true><<<(unsigned)rows, 256, 0, st>>>((const T*)X, (const T*)Delta, (const T*)W, (T*)Hout, \
+                                                                         (T*)Out, (int)dim, ldx, ldo, eps, Aq, a_scale)
+    if (vpt <= 1) QL_RMSQ(1);
+    else if (vpt <= 2) QL_RMSQ(2);
+    else if (vpt <= 4) QL_RMSQ(4);
+    else if (vpt <= 8) QL_RMSQ(8);
+    else return QL_ERR_UNSUPPORTED;
+#undef QL_RMSQ
+    return finish_launch();
+}
+
+int rmsnorm_quant(int dtype, const void* X, const void* Delta, const void* W, void* Hout, void* Out, int8_t* Aq, float* a_scale,
+                  int64_t rows, int64_t dim, int64_t ldx, int64_t ldo, float eps, hipStream_t st) {
+    if (dtype == QL_DTYPE_F32) return QL_ERR_UNSUPPORTED;
+    if (Delta) {
+        QL_DT(dtype, return (launch_rmsnorm_quant<T, true>(X, Delta, W, Hout, Out, Aq, a_scale, rows, dim, ldx, ldo, eps, st)))
+    } else {
+        QL_DT(dtype, return (launch_rmsnorm_quant<T, false>(X, Delta, W, Hout, Out, Aq, a_scale, rows, dim, ldx, ldo, eps, st)))
+    }
+    return QL_ERR_BAD_DTYPE;
+}
+
+template <typename T>
+static int launch_silu_mul_quant(const void* In, void* Out, int8_t* Aq, float* a_scale, int64_t rows, int64_t hidden, int64_t ldin,
+                                 int64_t ldo, hipStream_t st) {
+    const int vpt = (int)((hidden / 8 + 255) / 256);
+#define QL_SMQ(V) silu_mul_quant_kernel<T, V><<<(unsigned)rows, 256, 0, st>>>((const T*)In, (T*)Out, (int)hidden, ldin, ldo, Aq, a_scale)
+    if (vpt <= 1) QL_SMQ(1);
+    else if (vpt <= 2) QL_SMQ(2);
+    else if (vpt <= 4) QL_SMQ(4);
+    else if (vpt <= 7) QL_SMQ(7);
+    else if (vpt <= 8) QL_SMQ(8);
+    else return QL_ERR_UNSUPPORTED;
+#undef QL_SMQ
+    return finish_launch();
+}
+
+int silu_mul_quant(int dtype, const void* In, void* Out, int8_t* Aq, float* a_scale, int64_t rows, int64_t hidden, int64_t ldin,
+                   int64_t ldo, hipStream_t st) {
+    if (dtype == QL_DTYPE_F32) return QL_ERR_UNSUPPORTED;
+    QL_DT(dtype, return (launch_silu_mul_quant<T>(In, Out, Aq, a_scale, rows, hidden, ldin, ldo, st)))
+    return QL_ERR_BAD_DTYPE;
 }
 
 int rmsnorm(int dtype, const void* X, const void* Delta, const void* W, void* Hout, void* Out, int64_t rows, int64_t dim,

@@ -218,6 +218,11 @@ void w4_gemv_blocks(int64_t N, int64_t K, int64_t* w_block_bytes, int64_t* s_blo
 void w8_gemv_blocks(int64_t N, int64_t K, int64_t ldw, int64_t* w_block_bytes, int64_t* blocks);
 size_t decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, hipStream_t st);
+// quantising producers (decode_ops.hip): the same rows, also (or only: Out == nullptr) as int8 + one fp32 scale per row
+int rmsnorm_quant(int dtype, const void* X, const void* Delta, const void* W, void* Hout, void* Out, int8_t* Aq, float* a_scale,
+                  int64_t rows, int64_t dim, int64_t ldx, int64_t ldo, float eps, hipStream_t st);
+int silu_mul_quant(int dtype, const void* In, void* Out, int8_t* Aq, float* a_scale, int64_t rows, int64_t hidden, int64_t ldin,
+                   int64_t ldo, hipStream_t st);
 int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_t rows, int64_t Tn, int64_t mask_rows, int64_t lds,
                    int64_t ldm, int64_t ldp, hipStream_t st);
 int greedy_advance(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,

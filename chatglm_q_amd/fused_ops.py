@@ -41,6 +41,48 @@ def add_rmsnorm(x: Tensor, delta: Tensor, weight: Tensor, eps: float):
     return h.reshape(shape), out.reshape(shape)
 
 
+def rmsnorm_quant(x: Tensor, weight: Tensor, eps: float, delta: Tensor | None = None, want_out: bool = False):
+    """RMSNorm (of ``x + delta`` when ``delta`` is given) emitted as int8 rows + one fp32 scale per row in the SAME launch
+    (``qlinear_rmsnorm_quant_i8``): bit for bit ``act_quant_rowwise(rmsnorm(...))``.  Returns ``(h, a_q, a_scale, out)``:
+    ``h`` = the rounded ``x + delta`` (``x`` itself without delta), ``out`` = the 16-bit row only with ``want_out``."""
+    lib = _lib.get_lib()
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1]).contiguous()
+    rows, dim = x2.shape
+    d2 = delta.reshape(-1, dim).contiguous() if delta is not None else None
+    h = torch.empty_like(x2) if d2 is not None else x2
+    out = torch.empty_like(x2) if want_out else None
+    a_q = torch.empty((rows, dim), device=x.device, dtype=torch.int8)
+    a_s = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    if rows:
+        with torch.cuda.device(x.device):
+            st = lib.qlinear_rmsnorm_quant_i8(x2.data_ptr(), _lib.ptr(d2), weight.data_ptr(), h.data_ptr() if d2 is not None else None,
+                                              _lib.ptr(out), a_q.data_ptr(), a_s.data_ptr(), rows, dim, dim, float(eps),
+                                              _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
+        _lib.check(st, "qlinear_rmsnorm_quant_i8")
+    return h.reshape(shape), a_q, a_s, (out.reshape(shape) if out is not None else None)
+
+
+def silu_mul_quant(x: Tensor, hidden: int, want_out: bool = False):
+    """``silu(x[..., :hidden]) * x[..., hidden:]`` as int8 rows + scales in one launch (``qlinear_silu_mul_quant_i8``): bit for
+    bit ``act_quant_rowwise(silu_mul(x, hidden))``.  Returns ``(a_q, a_scale, out_or_None)``."""
+    lib = _lib.get_lib()
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    out = torch.empty((rows, hidden), device=x.device, dtype=x.dtype) if want_out else None
+    a_q = torch.empty((rows, hidden), device=x.device, dtype=torch.int8)
+    a_s = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    if rows:
+        with torch.cuda.device(x.device):
+            st = lib.qlinear_silu_mul_quant_i8(x2.data_ptr(), _lib.ptr(out), a_q.data_ptr(), a_s.data_ptr(), rows, hidden,
+                                               x2.stride(0) if rows > 1 else 2 * hidden, hidden, _lib.dtype_code(x.dtype),
+                                               _lib.stream_ptr(x.device))
+        _lib.check(st, "qlinear_silu_mul_quant_i8")
+    return a_q, a_s, (out.reshape(*x.shape[:-1], hidden) if out is not None else None)
+
+
 def _check_rope_table(table: Tensor, k_cache: Tensor, d_head: int):
     """The kernels clamp positions to [0, capacity] (1-based positions: row r holds position <= r + 1) and skip cache
     rows outside the cache - the ABI carries no table length - so the rotary table must hold capacity + 1 positions."""

@@ -114,6 +114,14 @@ class DynamicQuantizeLinear(nn.Module):
         self.invalidate()
         return super()._apply(fn, *args, **kwargs)
 
+    def forward_quantized(self, a_q: Tensor, a_scale: Tensor) -> Tensor:
+        """The int8-activation path (``act_quant``) for rows that arrive ALREADY quantised - int8 ``(rows, in_features)`` +
+        one fp32 scale per row, e.g. from ``fused_ops.rmsnorm_quant`` / ``silu_mul_quant`` - : the GEMM launch alone, bit for
+        bit what ``forward`` computes from the 16-bit rows those came from (chatglm_q/int8/qlinear.py:56-62)."""
+        if a_q.dtype != torch.int8 or a_q.dim() != 2 or a_q.shape[1] != self.in_features or self.in_features % 16:
+            raise ValueError("forward_quantized takes int8 rows of in_features (a multiple of 16) values")
+        return hip_ops.w8a8_gemm_tiled(a_q, a_scale, self.prepare()._tiled, self.out_features, self.weight_scale, self.bias)
+
     def forward(self, input: Tensor):
         plan = self._plans.get(input.numel())      # pre-bound launch for this row count (re-validates buffers and input)
         if plan is not None:

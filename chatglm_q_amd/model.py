@@ -31,6 +31,8 @@ MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False"
 # the MLP of a one-row int4 decode step as ONE persistent launch (qlinear_w4g32_mlp_engine: LDS-DMA loader wave + consumer waves
 # per CU)
 MLP_ENGINE = os.environ.get("QLINEAR_MLP_ENGINE", "0") not in ("0", "false", "False")
+# int8-activation modules (act_quant): RMSNorm / SiLU * gate emit the int8 rows + scales themselves (quantising producers)
+PREQUANT = os.environ.get("QLINEAR_PREQUANT", "1") not in ("0", "false", "False")
 
 
 @dataclass
@@ -266,12 +268,22 @@ class ChatGLM2Model(nn.Module):
         # batched decode at 2 rows: residual add + RMSNorm inside the projections' launches (the entry point serves 2..4 rows, but the
         # prologue handles two rows per pass: measured 1.45 -> 1.41 ms per step at 2 rows, 1.56 -> 1.59 / 1.61 -> 1.64 at 3 / 4)
         few = S == 1 and 2 <= B <= ROWS_FUSED_MAX and h.dtype in (torch.float16, torch.bfloat16)
+        from .int8.qlinear import DynamicQuantizeLinear as Q8
+
+        def prequant(mod):
+            # int8-activation modules (act_quant, row-wise scales): the producer in front emits the int8 rows + scales itself
+            # (qlinear_rmsnorm_quant_i8 / qlinear_silu_mul_quant_i8) - no quantiser launch, no 16-bit copy of the row
+            return (PREQUANT and isinstance(mod, Q8) and mod.act_quant is True and mod.in_features % 16 == 0
+                    and h.dtype in (torch.float16, torch.bfloat16) and mod.weight_scale.dtype == h.dtype)
         delta = None                                   # pending residual contribution of the previous sub-block
         for i, layer in enumerate(self.layers):
             qkv = self._rows_fused(layer.attn.qkv_proj, h, delta, layer.attn_ln) if few else None
             if qkv is not None:                        # h += delta, RMSNorm and qkv_proj: one launch
                 qkv, hn = qkv
                 h = hn if hn is not None else h
+            elif prequant(layer.attn.qkv_proj):
+                h, a_q, a_s, _ = F_.rmsnorm_quant(h, layer.attn_ln.weight, layer.attn_ln.eps, delta)
+                qkv = layer.attn.qkv_proj.forward_quantized(a_q, a_s).view(B, S, -1)
             else:
                 if delta is None:
                     x = F_.rmsnorm(h, layer.attn_ln.weight, layer.attn_ln.eps)
@@ -290,10 +302,19 @@ class ChatGLM2Model(nn.Module):
             if y is not None:                          # h += o, RMSNorm, w_in and SiLU * gate: one launch
                 y, h = y
             else:
-                h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
-                y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
+                if prequant(layer.ffn.w_in):
+                    h, a_q, a_s, _ = F_.rmsnorm_quant(h, layer.ffn_ln.weight, layer.ffn_ln.eps, o)
+                    y, u = None, layer.ffn.w_in.forward_quantized(a_q, a_s).view(B, S, -1)
+                else:
+                    h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
+                    y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
+                    u = layer.ffn.w_in(x) if y is None else None
+                if y is None and prequant(layer.ffn.w_out):
+                    a_q, a_s, _ = F_.silu_mul_quant(u, layer.ffn.hidden_dim)
+                    delta = layer.ffn.w_out.forward_quantized(a_q, a_s).view(B, S, -1)
+                    continue
                 if y is None:
-                    y = F_.silu_mul(layer.ffn.w_in(x), layer.ffn.hidden_dim)
+                    y = F_.silu_mul(u, layer.ffn.hidden_dim)
             delta = layer.ffn.w_out(y)
         if last_only:
             h, delta = h[:, -1:], delta[:, -1:]

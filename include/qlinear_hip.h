@@ -387,6 +387,16 @@ int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64
                            int64_t lds, int64_t ldm, int64_t ldp, int dtype, void* stream);
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream);
+/* Quantising producers (round 3): the row a norm / activation kernel holds in registers is ALSO emitted as int8 + one fp32 scale
+ * per row - bit for bit what qlinear_act_quant_i8 (row-wise: quantize_int8, chatglm_q/int8/quantizer.py:11-19) makes of the
+ * rounded 16-bit output row - so that the int8-activation GEMM behind it (qlinear_w8a8_fwd_tiled / qlinear_w8a8_fwd) needs no
+ * quantiser launch ("pre-quantized activations", north_star).  Aq is (rows, dim) contiguous, a_scale (rows).  Out is nullable
+ * (nobody else reads the 16-bit row); Delta / Hout as in qlinear_add_rmsnorm (both null: plain qlinear_rmsnorm).  fp16 / bf16.
+ * Callers: chatglm_q/model.py:213,244 (RMSNorm in front of qkv_proj / w_in), :200-201 (SiLU * gate in front of w_out). */
+int qlinear_rmsnorm_quant_i8(const void* X, const void* Delta, const void* W, void* Hout, void* Out, int8_t* Aq, float* a_scale,
+                             int64_t rows, int64_t dim, int64_t ld, float eps, int dtype, void* stream);
+int qlinear_silu_mul_quant_i8(const void* In, void* Out, int8_t* Aq, float* a_scale, int64_t rows, int64_t hidden, int64_t ldin,
+                              int64_t ldo, int dtype, void* stream);
 /* greedy decode bookkeeping in one launch (chatglm_q/decoder.py:85,97 with temperature -> 0): tok[b] = argmax of logits
  * row b (lowest index on ties), pos[b] += 1, write_index[0] += 1, mask[b][new write_index] = 0 for every row. */
 int qlinear_greedy_advance(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,

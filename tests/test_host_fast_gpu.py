@@ -344,3 +344,93 @@ def test_decode_only_session_frees_prefill_layouts_and_decodes_the_same():
     assert lean < full
     w_in = model.layers[0].ffn.w_in
     assert w_in.derived_nbytes()["tiled"] == 0 and w_in.derived_nbytes()["packed"] == 0 and w_in.derived_nbytes()["gated"] > 0
+
+
+# ---- quantising producers (round 3): RMSNorm / SiLU * gate emit the int8 rows + scales of the int8-activation GEMM behind them ----
+@pytest.mark.parametrize("rows,dim", [(5, 4096), (1, 256), (37, 1024), (3, 13696 // 2), (2, 16384), (9, 264)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_rmsnorm_quant_equals_norm_then_quantiser_and_the_oracle(rows, dim, dtype, with_delta):
+    """qlinear_rmsnorm_quant_i8: int8 rows and scales bit for bit what the quantiser launch (and the oracle's quantize_int8
+    restatement, chatglm_q/int8/quantizer.py:11-19) make of the rounded 16-bit output row; h and the optional 16-bit row equal
+    the plain launches'.  Includes an all-zero row (scale floor) and a row of ties."""
+    import numpy as np
+    from oracle import qlinear_oracle as O
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int8 import hip_ops as h8
+    g = torch.Generator(device=DEV).manual_seed(rows * 131 + dim)
+    x = torch.randn(rows, dim, device=DEV, generator=g).to(dtype)
+    x[0] = 0
+    delta = (torch.randn(rows, dim, device=DEV, generator=g) * 0.3).to(dtype) if with_delta else None
+    if with_delta:
+        delta[0] = 0
+    w = (1 + 0.1 * torch.randn(dim, device=DEV, generator=g)).to(dtype)
+    if with_delta:
+        want_h, want_out = F_.add_rmsnorm(x, delta, w, 1e-5)
+    else:
+        want_h, want_out = x, F_.rmsnorm(x, w, 1e-5)
+    want_q, want_s = h8.act_quant_rowwise(want_out)
+    before = _lib.launch_count()
+    h, a_q, a_s, out = F_.rmsnorm_quant(x, w, 1e-5, delta, want_out=True)
+    assert _lib.launch_count() - before == 1
+    assert torch.equal(h, want_h) and torch.equal(out, want_out)
+    assert torch.equal(a_q, want_q) and torch.equal(a_s, want_s)
+    q_ref, s_ref = O.act_quant_rowwise(want_out.float().cpu().numpy() if dtype == torch.bfloat16 else want_out.cpu().numpy())
+    assert np.array_equal(a_q.cpu().numpy(), q_ref) and np.array_equal(a_s.cpu().numpy(), s_ref)
+    _, a_q2, a_s2, none = F_.rmsnorm_quant(x, w, 1e-5, delta)                # without the 16-bit row
+    assert none is None and torch.equal(a_q2, want_q) and torch.equal(a_s2, want_s)
+
+
+@pytest.mark.parametrize("rows,hidden", [(4, 13696), (1, 384), (33, 1024), (2, 16384), (7, 8)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_silu_mul_quant_equals_silu_mul_then_quantiser(rows, hidden, dtype):
+    import numpy as np
+    from oracle import qlinear_oracle as O
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int8 import hip_ops as h8
+    g = torch.Generator(device=DEV).manual_seed(rows * 7 + hidden)
+    x = (torch.randn(rows, 2 * hidden + 8, device=DEV, generator=g) * 2).to(dtype)[:, :2 * hidden]     # row stride != 2 * hidden
+    want = F_.silu_mul(x, hidden)
+    want_q, want_s = h8.act_quant_rowwise(want)
+    before = _lib.launch_count()
+    a_q, a_s, out = F_.silu_mul_quant(x, hidden, want_out=True)
+    assert _lib.launch_count() - before == 1
+    assert torch.equal(out, want) and torch.equal(a_q, want_q) and torch.equal(a_s, want_s)
+    q_ref, s_ref = O.act_quant_rowwise(want.float().cpu().numpy() if dtype == torch.bfloat16 else want.cpu().numpy())
+    assert np.array_equal(a_q.cpu().numpy(), q_ref) and np.array_equal(a_s.cpu().numpy(), s_ref)
+    a_q2, a_s2, none = F_.silu_mul_quant(x, hidden)
+    assert none is None and torch.equal(a_q2, want_q) and torch.equal(a_s2, want_s)
+
+
+def test_int8_activation_model_prefill_with_quantising_producers_is_bit_equal(monkeypatch):
+    """An int8 model whose QLinear modules take int8 activations (``act_quant``): the prefill with the quantising producers
+    (3 fewer launches per layer, no 16-bit copies of the rows) produces the logits of the path with separate quantiser
+    launches bit for bit, and the module's ``forward_quantized`` equals its ``forward``."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd import model as M
+    cfg = M.ChatGLM2Config(hidden_size=256, inner_hidden_size=384, head_hidden_size=32, num_multi_query_groups=2,
+                           num_attention_heads=8, num_layers=2, vocab_size=320, max_sequence_length=64)
+    with torch.device(DEV):
+        model = M.create_quant_int8_model(cfg, dtype=torch.float16)
+    M.fill_synthetic_(model, 5)
+    model.eval()
+    for m in model.modules():
+        if hasattr(m, "act_quant"):
+            m.act_quant = True
+    ids = torch.randint(0, 320, (2, 24), device=DEV)
+    outs, launches = {}, {}
+    DecodeSession(model, 2, 32, use_graph=False).prefill(ids)                # builds the tile-major weight copies
+    for pre in (False, True):
+        monkeypatch.setattr(M, "PREQUANT", pre)
+        sess = DecodeSession(model, 2, 32, use_graph=False)
+        before = _lib.launch_count()
+        outs[pre] = sess.prefill(ids).clone()
+        launches[pre] = _lib.launch_count() - before
+    assert torch.equal(outs[True], outs[False])
+    assert launches[False] - launches[True] == 3 * cfg.num_layers, launches
+    mod = model.layers[0].attn.qkv_proj
+    x = torch.randn(5, cfg.hidden_size, device=DEV).half()
+    w = model.layers[0].attn_ln.weight
+    _, a_q, a_s, out = F_.rmsnorm_quant(x, w, 1e-5, want_out=True)
+    with torch.no_grad():
+        assert torch.equal(mod.forward_quantized(a_q, a_s), mod(out))
