@@ -158,6 +158,10 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
     return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(float) : 0;
 }
 
+// w4_gemm256.hip: many rows (prefill) on 256 x 256 tiles, weights dequantised once per block into LDS, A by LDS-DMA
+bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
+int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+               int64_t ldc, hipStream_t st);
 // w8_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
             int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);

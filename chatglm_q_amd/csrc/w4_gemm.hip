@@ -328,6 +328,8 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
 template <typename T>
 static int launch_gemm_any(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (w4_gemm256_supported(M, N, K, lda, A, sizeof(T)))      // prefill-sized row counts: 256 x 256 tiles (w4_gemm256.hip)
+        return w4_gemm256(Act<T>::code, A, tiled, bias, C, M, N, K, lda, ldc, st);
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
     static const int forced_nw = [] { const char* e = getenv("QLINEAR_GEMM_NW"); return e ? atoi(e) : 0; }();   // 4: two 4-wave blocks per CU (measurement)

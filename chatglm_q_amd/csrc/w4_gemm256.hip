@@ -1,0 +1,266 @@
+// int4g32 GEMM for MANY activation rows (prefill: BASELINE config 5) on 256 x 256 output tiles, gfx950 - round 3.
+//
+//   C[M,N] = A[M,K] . dequant(W)      fp16 / bf16 activations, fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16}
+//   (the reference's contraction, chatglm_q/int4/triton_ops.py:66-80: every weight dequantised to (n - 8) * s ROUNDED to the
+//   activation dtype before the dot, :72-73)
+//
+// Why another kernel beside w4_gemm.hip (128 x 256 tiles, weights dequantised in registers straight into B fragments): there
+// every weight is dequantised once per 128 rows and every MFMA needs a fresh 1 KB A fragment from LDS - 25 % of the SIMD cycles
+// ran neither pipe and 19 % dequant VALU alone (profiles/r02_gemm_pmc.txt).  Here (MI355X guide, the 256 x 256
+// template's geometry):
+//   * block = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles: 6 fragment reads feed 8 MFMAs (was 4 + a
+//     13-instruction dequant for 4), 128 accumulator registers per lane, two waves per SIMD;
+//   * the weights of a 64-deep K tile are dequantised ONCE per block: the block's 512 threads each take one 16-byte unit of the
+//     tile-major layout (32 nibbles of one column and group), build its four 8-half B fragments and store them FRAGMENT-MAJOR
+//     in LDS ([column tile][sub-step][lane][16 B]: every ds_write_b128 / ds_read_b128 is lane-linear, conflict-free) - half the
+//     dequant work per flop of the 128-row kernel, and it is spread word by word behind the MFMAs of the tile before;
+//   * the A tile (256 rows x 128 bytes) goes global -> LDS by LDS-DMA (no VGPR round trip, no ds_write pass), swizzled through
+//     the SOURCE address (chunk c of row r at position 8 r + (c ^ ((r >> 1) & 7)): conflict-free 128-byte-pitch fragment reads);
+//   * two LDS buffers per operand (128 KB), ONE block barrier per K tile (32 MFMAs per wave), every load hand-counted (vmq.h).
+#include "launch.h"
+#include "vmq.h"
+#include "w4_dequant.h"
+#include "w4_mma.h"
+
+#ifndef QL_G256_PIN
+#define QL_G256_PIN 1
+#endif
+
+namespace ql {
+
+constexpr int kG256ABuf = 256 * 128;               // one A tile: 256 rows x 64 halves
+constexpr int kG256BBuf = 8 * 4 * 64 * 16;         // one B tile: 8 column tiles x 4 sub-steps x 64 lanes x 16 bytes
+constexpr int kG256Lds = 2 * kG256ABuf + 2 * kG256BBuf;
+
+__device__ __forceinline__ void gload2(unsigned& dst, unsigned voff, unsigned long long base) {   // 16 bits, zero-extended
+    asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_imm(i32x4& w, unsigned& s) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w), "+v"(s) : "n"(N) : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                         int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
+                                                         const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+    typedef Mma<T> MM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2]; reused by the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int j = lane & 31, kb = lane >> 5;
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * 256, n0 = tile.x * 256;
+
+    u32 k_mask_lo, k_mask_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
+
+    // ---- this wave's share of the staging work -----------------------------------------------------------------------------------
+    // weights: column tile `wave` of the block's 8, one 16-byte unit (+ its scale) per lane and K tile, 1 KB contiguous per wave
+    const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile.x * 8 + wave;
+    const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;          // clamped: loads stay in bounds, stores are masked
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
+    const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
+    const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
+    // activations: pieces 4 wave .. 4 wave + 3 of the tile's 32 (1 KB = 8 rows each); lane -> (row, stored chunk position),
+    // source chunk = position ^ swizzle(row)
+    unsigned a_off[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
+    }
+    const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;    // + buffer * kG256ABuf + n * 1024
+    char* b_lds = smem + 2 * kG256ABuf;
+    const int b_wr = ((wave * 4) * 64 + lane) * 16;                // + buffer * kG256BBuf + s * 1024
+    // fragment read offsets (per sub-step s): A rows 128 wr + 32 mt + (lane & 31), chunk 4 kb + s; B column tiles 2 wc + nt
+    int a_rd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
+    const int b_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    i32x4 wq[2];                                       // packed weight unit of K tile (kt + 1), (kt + 2): two register sets
+    unsigned wsc[2];
+    auto issue_a = [&](int kt, int buf) {
+        const int k = kt < ksteps ? kt : ksteps - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
+        const unsigned long long base = sgpr64(a_base + (unsigned long long)k * 128ull);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(buf * kG256ABuf + n * 1024), a_off[n], base);
+    };
+    auto issue_w = [&](int kt, int set) {
+        const int k = kt < ksteps ? kt : ksteps - 1;
+        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * 1024ull));
+        gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
+    };
+    typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
+    auto scale_of = [&](unsigned bits) {
+        const uint16_t h = (uint16_t)bits;
+        T sv;
+        __builtin_memcpy(&sv, &h, 2);
+        return MM::scale_pair(&sv, true);
+    };
+    auto dequant_store = [&](int set, int buf, int s, scale_t sc) {     // word s of the unit -> B fragment (sub-step s) of the tile
+        const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+        *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 1024) = f;
+    };
+    u32x4 fa[2][4], fb[2][2];
+    auto read_frags = [&](int buf, int s, u32x4 (&xa)[4], u32x4 (&xb)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 4096 + s * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + mt * 4096 + a_rd[s]);
+    };
+
+    // ---- prologue: A(0), W(0), W(1) requested; W(0) dequantised into B[0]; then the block every barrier is followed by ---------
+    issue_a(0, 0);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    vm_wait_imm<2>(wq[0], wsc[0]);                     // A(0) and W(0) have landed (this wave's pieces)
+    {
+        const scale_t sc = scale_of(wsc[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dequant_store(0, 0, s, sc);
+    }
+    __syncthreads();
+    issue_a(1, 1);
+    issue_w(2, 0);
+    read_frags(0, 0, fa[0], fb[0]);
+
+    // ---- K loop: one iteration = one 64-deep K tile = 32 MFMAs per wave, ONE block barrier - placed in front of the tile's LAST
+    // sub-step, whose fragments are in registers by then: behind the barrier nobody reads the tile's buffers any more, so the
+    // refill of them (A pieces of tile kt + 2, the unit of tile kt + 3) and the first fragment reads of tile kt + 1 go out at
+    // once and their latency hides behind the 8 MFMAs of that last sub-step instead of idling the matrix pipe after every barrier
+    // (first version, barrier at the end of the tile: 1 005 -> 1 048 TFLOP/s at 8192 x 4096 x 4096 with this skew).
+    // Queue: behind each barrier 4 A pieces, then unit + scale.  W(kt + 1) (requested behind the barrier of iteration kt - 2) has 6
+    // younger loads when iteration kt dequantises it; A(kt + 1) (behind the barrier of kt - 1) has 2 when iteration kt reaches its barrier.
+    auto mma_sub = [&](int s) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
+                                      __builtin_bit_cast(typename MM::frag, fb[s & 1][nt]), acc[mt][nt]);
+    };
+    auto k_tile = [&](int kt, auto curc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+        vm_wait_imm<6>(wq[nxt], wsc[nxt]);             // W(kt + 1) has landed
+        const scale_t sc = scale_of(wsc[nxt]);
+        static_for<3>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            mma_sub(s);
+            dequant_store(nxt, nxt, s, sc);            // tile kt + 1's fragments 0..2 (3 with sub-step 2), behind these MFMAs
+            if constexpr (s == 2) dequant_store(nxt, nxt, 3, sc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);             // the 6 fragment reads of the next sub-step first
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // each MFMA with its share of the dequant VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, s == 2 ? 4 : 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, s == 2 ? 2 : 1, 0);
+#if QL_G256_PIN
+            __builtin_amdgcn_sched_barrier(0);         // sub-steps do not mix: left alone hipcc chains the MFMAs of one accumulator
+#endif
+        });
+        vm_wait_imm<2>();                              // A(kt + 1) has landed
+        __syncthreads();                               // B(kt + 1), A(kt + 1) complete; fragments (kt, 3) are in registers
+        issue_a(kt + 2, cur);
+        issue_w(kt + 3, nxt);                          // register set nxt held W(kt + 1): dequantised above
+        read_frags(nxt, 0, fa[0], fb[0]);
+        mma_sub(3);
+#if QL_G256_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+    int kt = 0;
+    for (; kt + 1 < ksteps; kt += 2) {
+        k_tile(kt, std::integral_constant<int, 0>{});
+        k_tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < ksteps) k_tile(kt, std::integral_constant<int, 0>{});
+    vm_wait_imm<0>(wq[0], wsc[0]);                     // the queue is empty before the registers / LDS are reused
+    vm_wait_imm<0>(wq[1], wsc[1]);
+    __syncthreads();                                   // ... and every wave is past its last fragment read
+
+    // ---- epilogue: rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global (ql_common.h) -------------
+    const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
+    if ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nw + 32 * nt + j;
+        if (n >= N) continue;
+        const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) store_out<T>(C + (int64_t)m * ldc + n, acc[mt][nt][i], bn);
+            }
+    }
+}
+
+template <typename T>
+static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
+                          hipStream_t st) {
+    const W4Layout L = w4_layout(N, K, sizeof(T));
+    const u32x4* Wt = (const u32x4*)tiled;
+    const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kG256Lds) == hipSuccess;
+    }();
+    (void)attr_set;
+    const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
+    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
+    const int sy = 4;                                  // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+    w4_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
+        (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
+        super ? sy : 0, (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+// rows / shapes the 256 x 256 kernel takes (the launcher in w4_gemm.hip asks): whole 64-deep K tiles, 16-byte aligned rows,
+// 32-bit byte offsets into A, and enough 256-row tiles to fill the chip
+bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize) {
+    static const int off = [] { const char* e = getenv("QLINEAR_GEMM_256"); return e && atoi(e) == 0; }();         // A/B switch
+    if (off || esize != 2 || K % 64 != 0 || K < 128 || (lda * (int64_t)esize) % 16 != 0 || ((uintptr_t)A & 15) != 0) return false;
+    if (M * lda * (int64_t)esize >= ((int64_t)1 << 31)) return false;
+    const int64_t blocks = ((N + 255) / 256) * ((M + 255) / 256);
+    return M >= 1024 && blocks >= 192;
+}
+
+int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+               int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256<f16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_gemm256<__bf16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql
