@@ -6,6 +6,7 @@ the 256 MB Infinity Cache where the shape is small enough to be cached).
 """
 from __future__ import annotations
 
+import os
 import time
 
 HBM_PEAK_GBPS = 8000.0
@@ -183,7 +184,7 @@ def prefill_gemm(torch, device):
     """BASELINE config 5 building block: int4g32 GEMM with M = 8192 rows (seq 2048 x batch 4) per layer shape,
     fp16 MFMA with in-register dequant (reference rounding sequence)."""
     gen = torch.Generator(device=device).manual_seed(17)
-    M = 8192
+    M = int(os.environ.get("PREFILL_GEMM_M", 8192))          # tools/prefill_gemm_ab.py sweeps it
     out = {}
     for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 4096, 27392), ("w_out", 13696, 4096)]:
         layer = _w4_layer(torch, device, K, N, False, gen)

@@ -70,6 +70,8 @@ EXPORTS = {
     "qlinear_w4g32_tile": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_fwd_tiled256": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                           c_int, c_void_p]),
     "qlinear_w4g32_fwd_tiled_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                          c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),

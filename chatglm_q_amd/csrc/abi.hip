@@ -144,6 +144,17 @@ int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int6
     return w4_tile(dtype, gemv, tiled, N, K, (hipStream_t)stream);
 }
 
+int qlinear_w4g32_fwd_tiled256(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                               int64_t group, int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!A || !tiled || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
+    if (!w4_gemm256_can_run(M, N, K, lda, A, esize(dtype))) return QL_ERR_UNSUPPORTED;
+    return w4_gemm256(dtype, A, tiled, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
 int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                             int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
                             void* stream) {

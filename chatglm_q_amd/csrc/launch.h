@@ -160,6 +160,7 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
 
 // w4_gemm256.hip: many rows (prefill) on 256 x 256 tiles, weights dequantised once per block into LDS, A by LDS-DMA
 bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
+bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                int64_t ldc, hipStream_t st);
 // w8_gemm.hip (M > 4, fp16 / bf16, MFMA)

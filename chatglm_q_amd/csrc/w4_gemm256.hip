@@ -25,8 +25,32 @@
 #ifndef QL_G256_PIN
 #define QL_G256_PIN 1
 #endif
+#ifndef QL_G256_PRIO
+#define QL_G256_PRIO 0
+#endif
+#ifndef QL_G256_SPREAD
+#define QL_G256_SPREAD 1
+#endif
+#ifndef QL_G256_ABLATE
+#define QL_G256_ABLATE 0
+#endif
+#ifndef QL_G256_ALT_PRIO
+#define QL_G256_ALT_PRIO 0
+#endif
+#ifndef QL_G256_YOUNG_PRIO
+#define QL_G256_YOUNG_PRIO 0
+#endif
 
 namespace ql {
+
+// QL_G256_STAMPS (developer build, tools/ab/build_g256_variant.sh + tools/g256_timeline.py): lane 0 of waves 0 and 4 of every block sums
+// the shader-clock cycles it spends in the two queue waits and the barrier of the K loop ([block][wave / 4][4] = W wait, A wait,
+// barrier, whole loop).  s_memtime returns through lgkmcnt: the probes drain the LDS queue - read proportions, not absolutes.
+#ifdef QL_G256_STAMPS
+__device__ unsigned long long ql_g256_stamps[8192 * 2 * 4];
+#define QL_G256_T() (unsigned long long)__builtin_amdgcn_s_memtime()
+#define QL_G256_D() (QL_G256_STAMPS > 1 ? QL_G256_T() : 0ull)     // detailed probes (each drains the wave's LDS queue)
+#endif
 
 constexpr int kG256ABuf = 256 * 128;               // one A tile: 256 rows x 64 halves
 constexpr int kG256BBuf = 8 * 4 * 64 * 16;         // one B tile: 8 column tiles x 4 sub-steps x 64 lanes x 16 bytes
@@ -46,6 +70,9 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
                                                          const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
     typedef Mma<T> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2]; reused by the epilogue
+#ifdef QL_G256_STAMPS
+    const unsigned long long t_block0 = QL_G256_T();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -97,6 +124,12 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     i32x4 wq[2];                                       // packed weight unit of K tile (kt + 1), (kt + 2): two register sets
     unsigned wsc[2];
     auto issue_a = [&](int kt, int buf) {
+#if QL_G256_ABLATE & 8                              // timing ablation: no A pieces in the loop (4 dummy loads keep the queue counts)
+        if (kt > 1) {
+            for (int n = 0; n < 4; ++n) asm volatile("s_nop 0" ::: "memory");
+            return;
+        }
+#endif
         const int k = kt < ksteps ? kt : ksteps - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
         const unsigned long long base = sgpr64(a_base + (unsigned long long)k * 128ull);
 #pragma unroll
@@ -115,11 +148,24 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         return MM::scale_pair(&sv, true);
     };
     auto dequant_store = [&](int set, int buf, int s, scale_t sc) {     // word s of the unit -> B fragment (sub-step s) of the tile
+#if QL_G256_ABLATE & 1                              // timing ablation (results wrong): no dequant arithmetic
+        const u32x4 f = {(u32)wq[set][s], (u32)wq[set][s] ^ k_magic, (u32)wq[set][s], k_magic};
+        (void)sc;
+#else
         const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+#endif
+#if QL_G256_ABLATE & 2                              // ... no B-fragment stores either
+        if (f[0] == 0x12345678u && f[3] == 0x9abcdef0u)
+#endif
         *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 1024) = f;
     };
     u32x4 fa[2][4], fb[2][2];
     auto read_frags = [&](int buf, int s, u32x4 (&xa)[4], u32x4 (&xb)[2]) {
+#if QL_G256_ABLATE & 4                              // timing ablation: no fragment reads
+        for (int nt = 0; nt < 2; ++nt) xb[nt] = u32x4{(u32)buf, (u32)s, 0x3c003c00u, (u32)nt};
+        for (int mt = 0; mt < 4; ++mt) xa[mt] = u32x4{(u32)a_rd[s], (u32)buf, 0x3c003c00u, (u32)mt};
+        return;
+#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 4096 + s * 1024);
 #pragma unroll
@@ -149,16 +195,46 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     // Queue: behind each barrier 4 A pieces, then unit + scale.  W(kt + 1) (requested behind the barrier of iteration kt - 2) has 6
     // younger loads when iteration kt dequantises it; A(kt + 1) (behind the barrier of kt - 1) has 2 when iteration kt reaches its barrier.
     auto mma_sub = [&](int s) {
+#if QL_G256_ALT_PRIO
+        // the matrix pipe changes hands twice per K tile: group 0 is served first in sub-steps 3 and 0 (the two behind the barrier),
+        // group 1 in sub-steps 1 and 2
+        if (s == 3 || s == 1) {
+            if ((s == 3) == (wave < 4)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
+#if QL_G256_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
                                       __builtin_bit_cast(typename MM::frag, fb[s & 1][nt]), acc[mt][nt]);
+#if QL_G256_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
+#if QL_G256_YOUNG_PRIO
+    // the two waves of a SIMD (w, w + 4) share its matrix pipe; issue is arbitrated by priority, then AGE: at equal priority the
+    // older wave ran ahead and parked ~1 000 cycles per K tile at the barrier while the younger one finished alone, its own
+    // stalls uncovered (QL_G256_STAMPS=2).  One static raise for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4).
+    if (wave >= 4) __builtin_amdgcn_s_setprio(QL_G256_YOUNG_PRIO);
+#endif
+#ifdef QL_G256_STAMPS
+    unsigned long long t_w = 0, t_a = 0, t_b = 0;
+    const unsigned long long t_loop0 = QL_G256_T();
+#endif
     auto k_tile = [&](int kt, auto curc) {
         constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+#ifdef QL_G256_STAMPS
+        const unsigned long long t0 = QL_G256_D();
+#endif
         vm_wait_imm<6>(wq[nxt], wsc[nxt]);             // W(kt + 1) has landed
+#ifdef QL_G256_STAMPS
+        t_w += QL_G256_D() - t0;
+#endif
         const scale_t sc = scale_of(wsc[nxt]);
         static_for<3>([&](auto sc_) {
             constexpr int s = decltype(sc_)::value;
@@ -177,14 +253,44 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
             __builtin_amdgcn_sched_barrier(0);         // sub-steps do not mix: left alone hipcc chains the MFMAs of one accumulator
 #endif
         });
+#ifdef QL_G256_STAMPS
+        const unsigned long long t1 = QL_G256_D();
+#endif
         vm_wait_imm<2>();                              // A(kt + 1) has landed
+#ifdef QL_G256_STAMPS
+        const unsigned long long t2 = QL_G256_D();
+        t_a += t2 - t1;
+#endif
         __syncthreads();                               // B(kt + 1), A(kt + 1) complete; fragments (kt, 3) are in registers
+#ifdef QL_G256_STAMPS
+        t_b += QL_G256_D() - t2;
+#endif
+#if QL_G256_SPREAD
+        // behind the barrier both waves of a SIMD would issue their six requests (~100 issue cycles of M0 moves and wait states)
+        // at the same time with the matrix pipe idle: the fragment reads go first, then one request behind each of the last
+        // sub-step's MFMAs (whose fragments are in registers)
+        read_frags(nxt, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int ka = kt + 2 < ksteps ? kt + 2 : ksteps - 1, kw = kt + 3 < ksteps ? kt + 3 : ksteps - 1;
+            const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ka * 128ull);
+            static_for<8>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
+                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
+                if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
+                else if constexpr (q == 4) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * 1024ull));
+                else if constexpr (q == 5) gload2(wsc[nxt], s_voff, sgpr64(s_base + (unsigned long long)kw * (64ull * sizeof(T))));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+#else
         issue_a(kt + 2, cur);
         issue_w(kt + 3, nxt);                          // register set nxt held W(kt + 1): dequantised above
         read_frags(nxt, 0, fa[0], fb[0]);
         mma_sub(3);
 #if QL_G256_PIN
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
     };
     int kt = 0;
@@ -193,6 +299,13 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         k_tile(kt + 1, std::integral_constant<int, 1>{});
     }
     if (kt < ksteps) k_tile(kt, std::integral_constant<int, 0>{});
+#ifdef QL_G256_STAMPS
+    if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = ql_g256_stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 4;
+        o[0] = t_w; o[1] = t_a; o[2] = t_loop0 - t_block0; o[3] = QL_G256_T() - t_loop0;      // [2]: prologue (barrier time with STAMPS=2 is lost)
+    }
+    const unsigned long long t_loop1 = QL_G256_T();
+#endif
     vm_wait_imm<0>(wq[0], wsc[0]);                     // the queue is empty before the registers / LDS are reused
     vm_wait_imm<0>(wq[1], wsc[1]);
     __syncthreads();                                   // ... and every wave is past its last fragment read
@@ -206,6 +319,9 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+#ifdef QL_G256_STAMPS
+        if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_g256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 1] = QL_G256_T() - t_loop1;
+#endif
         return;
     }
 #pragma unroll
@@ -251,7 +367,19 @@ bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const vo
     if (off || esize != 2 || K % 64 != 0 || K < 128 || (lda * (int64_t)esize) % 16 != 0 || ((uintptr_t)A & 15) != 0) return false;
     if (M * lda * (int64_t)esize >= ((int64_t)1 << 31)) return false;
     const int64_t blocks = ((N + 255) / 256) * ((M + 255) / 256);
-    return M >= 1024 && blocks >= 192;
+    static const int min_blocks = [] { const char* e = getenv("QLINEAR_GEMM_256_MIN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    if (min_blocks > 0) return M >= 256 && blocks >= min_blocks;
+    // one block per CU at a time (128 KB of LDS): the grid pays in whole rounds of 256 blocks.  Measured against the 128-row-tile
+    // kernel (tools/prefill_gemm_ab.py, M = 1024 .. 8192 x the four layer shapes): ahead from one full round on when the last
+    // round is at least ~70 % full (256 blocks +11 %, 428 +13 %, 576 +3.5 %, 856 +3 %), behind below that (288 blocks -9 %, 128 -25 %)
+    const int64_t rounds = (blocks + 255) / 256;
+    return blocks >= 256 && blocks * 10 >= rounds * 256 * 7;
+}
+
+// what the kernel itself needs (the dispatch heuristic above is a speed choice on top of this)
+bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize) {
+    return esize == 2 && M > 0 && N > 0 && K % 64 == 0 && K >= 128 && (lda * (int64_t)esize) % 16 == 0 && ((uintptr_t)A & 15) == 0 &&
+           M * lda * (int64_t)esize < ((int64_t)1 << 31);
 }
 
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -264,3 +392,9 @@ int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, vo
 }
 
 }  // namespace ql
+
+#ifdef QL_G256_STAMPS
+extern "C" int qlinear_g256_stamps_read(unsigned long long* out, int blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_g256_stamps), sizeof(unsigned long long) * 8 * blocks);
+}
+#endif

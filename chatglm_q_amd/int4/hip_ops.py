@@ -151,6 +151,22 @@ def tile_w4g32(gemv: Tensor, N: int, K: int, dtype: torch.dtype) -> Tensor:
     return tiled
 
 
+def w4_gemm256(a: Tensor, tiled: Tensor, n_out: int, bias: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+    """The many-row kernel alone (``qlinear_w4g32_fwd_tiled256``: 256 x 256 tiles) on part 2 of the derived layout, for any row
+    count - ``w4_forward`` / the modules pick it by themselves at prefill row counts.  ``out``: optional (M, >= n_out) buffer
+    whose row stride becomes ``ldc``."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype) if out is None else out
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_tiled256(a2.data_ptr(), tiled.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out, K, 32,
+                                            a2.stride(0) if M > 1 else K, c.stride(0) if M > 1 else n_out,
+                                            _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w4g32_fwd_tiled256")
+    return c[:, :n_out]
+
+
 def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None,
                packed: Tensor | None = None, strict: bool | None = None, tiled: Tensor | None = None,
                plan_out: list | None = None) -> Tensor:

@@ -151,6 +151,13 @@ int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int6
 int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                             int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* The many-row kernel of qlinear_w4g32_fwd_tiled alone (round 3, w4_gemm256.hip: 256 x 256 output tiles, the weights of a K tile
+ * dequantised once per block into LDS, A by LDS-DMA; same arithmetic: every weight (n - 8) * s rounded to the activation dtype,
+ * chatglm_q/int4/triton_ops.py:72-73, fp32 accumulation).  qlinear_w4g32_fwd_tiled picks it by itself when the grid fills the
+ * chip in whole rounds (prefill row counts); this entry runs it for any M.  QL_ERR_UNSUPPORTED unless K % 64 == 0, K >= 128,
+ * 16-byte aligned rows of A and M * lda * 2 < 2^31.  fp16 / bf16. */
+int qlinear_w4g32_fwd_tiled256(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                               int64_t group, int64_t lda, int64_t ldc, int dtype, void* stream);
 
 /* One-row (decode) forward on the derived layout with an activation PROLOGUE fused into the staging of the
  * activation row, so that the small op in front of the QLinear call costs no launch of its own (SURVEY.md 8f

@@ -186,6 +186,38 @@ def test_int4_vs_oracle(M, K, N, dt, has_bias, layout):
         assert O.rel_l2(t2n(out), ref) <= 1.5e-4, O.rel_l2(t2n(out), ref)
 
 
+G256_SHAPES = [(256, 128, 256, "f16", False), (300, 192, 264, "f16", True), (1000, 4096, 1000, "bf16", False),
+               (512, 13696, 520, "f16", False), (2048, 1024, 4608, "bf16", True), (1, 256, 40, "f16", True),
+               (777, 320, 36, "f16", False)]
+
+
+@pytest.mark.parametrize("M,K,N,dt,has_bias", G256_SHAPES)
+def test_int4_gemm256_vs_oracle(M, K, N, dt, has_bias):
+    """The 256 x 256-tile many-row kernel (w4_gemm256.hip) called directly (qlinear_w4g32_fwd_tiled256), at sizes the dispatch
+    would not give it: ragged M and N (partial tiles, clamped column tiles), odd and even K-tile counts, bf16, bias, one row,
+    N % 8 != 0 and an output with a row stride that is no multiple of 8 (the element-wise store path).  Reference rounding
+    kept: fp16 within 1.5e-4 of the oracle, bf16 within 1e-3."""
+    qw, sc = _rand_w4(K, N, dt, seed=K * 7 + N)
+    g = torch.Generator().manual_seed(M + 17)
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt]) if has_bias else None
+    ref = O.w4_matmul(t2n(a), qw.numpy(), t2n(sc), None if bias is None else t2n(bias), dtype=dt)
+    qd, sd = qw.to(DEV), sc.to(DEV)
+    tiled = h4.tile_w4g32(h4.repack_w4g32_gemv(qd, sd), N, K, TDT[dt])
+    bd = None if bias is None else bias.to(DEV)
+    before = launches()
+    out = h4.w4_gemm256(a.to(DEV), tiled, N, bd)
+    assert launches() - before == 1
+    assert_close(out, ref, dt, f"{M}x{K}x{N}")
+    assert O.rel_l2(t2n(out), ref) <= (1.5e-4 if dt == "f16" else 1e-3)
+    assert torch.equal(out, h4.w4_gemm256(a.to(DEV), tiled, N, bd))                 # run to run: bit-identical
+    wide = torch.full((M, N + 3), 7.0, device=DEV, dtype=TDT[dt])                    # ldc = N + 3: element-wise stores
+    got = h4.w4_gemm256(a.to(DEV), tiled, N, bd, out=wide)
+    assert torch.equal(got, out) and bool((wide[:, N:] == 7.0).all())
+    with pytest.raises(ValueError):
+        h4.w4_gemm256(a.to(DEV)[:, :32].contiguous(), tiled, N)                      # K = 32: not served
+
+
 @pytest.mark.parametrize("layout", ["packed", "packed_strict"])
 @pytest.mark.parametrize("M,K,N", [(8192, 4096, 4096), (8192, 13696, 4096)])
 def test_int4_config5_gemm_shapes(M, K, N, layout):
