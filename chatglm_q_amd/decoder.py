@@ -296,6 +296,11 @@ class ChatGLMDecoder:
                                       sync_every_token)
         finally:
             sess.busy = False
+            from . import model as _M
+            if _M.MLP_PAIR:                                     # experiment switch: a consumer that gave up waiting set the error word
+                from .int4 import hip_ops as _h4
+                if _h4.mlp_pair_timed_out(sess.device):
+                    raise RuntimeError("QLINEAR_MLP_PAIR: a workgroup timed out waiting inside the one-launch MLP; this generation's tokens are invalid")
 
     def _generate(self, sess: DecodeSession, prefix, budget: int, top_k: int, top_p: float, temperature: float, greedy: bool,
                   ignore_eos: bool, prefill_chunk: Optional[int], sync_every_token: bool):

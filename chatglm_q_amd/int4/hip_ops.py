@@ -551,9 +551,10 @@ def w4_mlp_pair(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, 
     _check_row_operands("w4_mlp_pair", x, K, ln_weight=ln_weight, bias_in=bias_in, bias_out=bias_out, residual=residual)
     if gated_packed.numel() < gemv_nbytes(n_in, K, x.dtype) or packed_out.numel() < gemv_nbytes(n_out, n_in // 2, x.dtype):
         raise AssertionError("w4_mlp_pair: derived buffers too small for the two projections")
-    ws = _PAIR_WS.get(x.device)
+    ws_key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)   # two launches in flight on two streams must not share counters
+    ws = _PAIR_WS.get(ws_key)
     if ws is None:                                        # arrival counters: zeroed once, reset by the kernel itself
-        ws = _PAIR_WS[x.device] = torch.zeros(int(lib.qlinear_w4g32_mlp_pair_workspace_bytes()) + 64, dtype=torch.uint8, device=x.device)
+        ws = _PAIR_WS[ws_key] = torch.zeros(int(lib.qlinear_w4g32_mlp_pair_workspace_bytes()) + 64, dtype=torch.uint8, device=x.device)
     off = (-ws.data_ptr()) % 64
     x = x.contiguous()
     residual = residual.contiguous()
@@ -572,11 +573,12 @@ def w4_mlp_pair(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, 
 def mlp_pair_timed_out(device) -> bool:
     """True when a consumer workgroup of an earlier ``w4_mlp_pair`` launch gave up waiting (host-synchronous read of the
     error word; the results of that launch are then garbage)."""
-    ws = _PAIR_WS.get(torch.device(device))
-    if ws is None:
-        return False
-    off = (-ws.data_ptr()) % 64
-    return bool(ws[off + 4 * 16 * 65: off + 4 * 16 * 65 + 4].view(torch.int32).item())
+    hit = False
+    for (dev, _stream), ws in list(_PAIR_WS.items()):
+        if dev == torch.device(device):
+            off = (-ws.data_ptr()) % 64
+            hit |= bool(ws[off + 4 * 16 * 65: off + 4 * 16 * 65 + 4].view(torch.int32).item())
+    return hit
 
 
 def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:

@@ -189,16 +189,19 @@ class DynamicQuantizeLinear(nn.Module):
             self._packed, self._packed_key = None, None
             self._tiled, self._tiled_key = None, None
             return self
+        self._build_part1()
+        dt = self.weight_scale.dtype
+        if hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, dt, _lib.strict_for(dt)):
+            self.tiled()
+        return self
+
+    def _build_part1(self):
         key = self._canonical_key()
         if self._packed is None or self._packed_key != key:
             self._packed = hip_ops.repack_w4g32_gemv(self.weight, self.weight_scale)
             self._packed_key = key
             self._plans, self._fast = {}, {}
             _lib.bump_layout_epoch()
-        dt = self.weight_scale.dtype
-        if hip_ops.rows_on_tiled(rows, self.out_features, self.in_features, dt, _lib.strict_for(dt)):
-            self.tiled()
-        return self
 
     @torch.no_grad()
     def tiled(self) -> Tensor:
@@ -206,7 +209,7 @@ class DynamicQuantizeLinear(nn.Module):
         on first use and cached like it."""
         key = self._canonical_key()
         if self._tiled is None or self._tiled_key != key:
-            self.prepare()
+            self._build_part1()                     # not prepare(): with QLINEAR_GEMV_MAX_ROWS=0 that would call tiled() again
             self._tiled = hip_ops.tile_w4g32(self._packed, self.out_features, self.in_features, self.weight_scale.dtype)
             self._tiled_key = key
             _lib.bump_layout_epoch()
