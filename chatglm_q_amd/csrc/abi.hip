@@ -401,6 +401,16 @@ int qlinear_act_quant_i8(const void* A, int8_t* Aq, float* a_scale, int64_t M, i
     return act_quant_rowwise(dtype, A, Aq, a_scale, M, K, lda, (flags & QL_FLAG_ACT_PER_TENSOR) != 0, (hipStream_t)stream);
 }
 
+int qlinear_w8a8_fwd_tiled256(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                              int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+    if (!Aq || !a_scale || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(Aq, 16) || !aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    if (!w8a8_gemm256_can_run(dtype, M, N, K, Aq)) return QL_ERR_UNSUPPORTED;
+    return w8a8_gemm256(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
+}
+
 int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
                            int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
     if (!Aq || !a_scale || !tiled || !S || !C) return QL_ERR_NULL_POINTER;

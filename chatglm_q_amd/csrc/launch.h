@@ -163,6 +163,11 @@ bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const vo
 bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                int64_t ldc, hipStream_t st);
+// w8a8_gemm256.hip: int8 activations x tile-major int8 weights, many rows, 256 x 256 tiles, both operands by LDS-DMA
+bool w8a8_gemm256_can_run(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq);
+bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq);
+int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                 int64_t N, int64_t K, int64_t ldc, hipStream_t st);
 // w8_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
             int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);

@@ -759,6 +759,8 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
 
 int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
                     int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    if (w8a8_gemm256_supported(dtype, M, N, K, Aq))    // prefill row counts: 256 x 256 tiles (w8a8_gemm256.hip)
+        return w8a8_gemm256(dtype, Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     switch (dtype) {
     case QL_DTYPE_F32: return launch_w8a8_tiled<float>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     case QL_DTYPE_F16: return launch_w8a8_tiled<f16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);

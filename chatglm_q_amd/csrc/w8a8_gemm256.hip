@@ -1,0 +1,220 @@
+// int8 activations x int8 weights for MANY rows (prefill of an int8 model with act_quant) on 256 x 256 output tiles, gfx950 - round 3.
+//
+//   acc_i32 = Aq (M,K) . W (N,K)^T on v_mfma_i32_32x32x32_i8, C = acc * a_scale[m] * w_scale[n] (+ bias)
+//   (chatglm_q/int8/qlinear.py:56-62; the integer stage is exact)
+//
+// The structure of w4_gemm256.hip with nothing to dequantise: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 4 x 2 MFMA tiles, a K
+// tile of 128 bytes = 4 sub-steps = 32 MFMAs per wave, two LDS buffers per operand (128 KB), ONE block barrier per K tile placed in
+// front of the tile's last sub-step, every load an LDS-DMA (vmq.h):
+//   * A tile (256 rows x 128 bytes of the row-major int8 rows): 32 pieces of 1 KB, swizzle in the SOURCE address (chunk c of row r
+//     at position 8 r + (c ^ ((r >> 1) & 7)): conflict-free ds_read_b128 at a 128-byte pitch);
+//   * W tile: the tile-major derived copy (qlinear_w8_tile: [column tile][64-deep K step][half][lane][16 B]) IS fragment-major -
+//     the four 1 KB units of a column tile and K tile are 4 KB contiguous in memory and land in LDS as they lie;
+//   * no VALU in the loop at all: fragment reads, MFMAs, eight LDS-DMA requests per wave and K tile spread behind the MFMAs.
+// Round 2's many-row kernel (w8a8_tiled_kernel, 128 x 128 tiles, W global -> VGPR, A through ds_write) reaches 1.6 - 1.7 POP/s at
+// 8192 rows; DESIGN.md 4a named 256 x 256 tiles as its next step.
+#include "launch.h"
+#include "vmq.h"
+
+namespace ql {
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef QL_I256_STAMPS                                // developer build: lane 0 of waves 0 / 4 stamps the K loop's shader cycles
+__device__ unsigned long long ql_i256_stamps[8192 * 2 * 4];
+#endif
+constexpr int kI256Tile = 256 * 128;               // one operand tile: 256 rows (columns) x 128 bytes of K
+constexpr int kI256Lds = 4 * kI256Tile;            // A[2] | W[2]
+
+template <typename T>
+__global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M, int N, int K,
+                                                           int nbx, int super_rows, const float* __restrict__ a_scale,
+                                                           const T* __restrict__ Sc, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | W[2]; reused by the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int j = lane & 31, kb = lane >> 5;
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * 256, n0 = tile.x * 256;
+    const int ktiles = K >> 7, ksteps64 = K >> 6;
+
+    // ---- this wave's share of the staging work: A pieces 4 wave .. 4 wave + 3 (8 rows each), W column tile `wave` ---------------
+    unsigned a_off[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_off[n] = (unsigned)row * (unsigned)K + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
+    }
+    const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile.x * 8 + wave;
+    const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;          // clamped: loads stay in bounds, stores are masked
+    const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)Aq);
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wm + (unsigned long long)ct * (unsigned long long)ksteps64 * 2048ull);
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;                          // + buffer * tile + n * 1024
+    const unsigned w_dma = lds0 + (unsigned)(2 * kI256Tile) + (unsigned)(4 * wave) * 1024u;
+    char* w_lds = smem + 2 * kI256Tile;
+    // fragment read offsets: sub-step s = (unit u, half h) of the K tile reads chunk 4 u + 2 kb + h of row 128 wr + 32 mt + j
+    // (the K assignment of the tile-major weights, w8a8.hip) and unit (column tile 2 wc + nt, s) of the W tile
+    int a_rd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * (s >> 1) + 2 * kb + (s & 1)) ^ ((j >> 1) & 7))) * 16;
+    const int w_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
+
+    i32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0;
+
+    auto issue_piece = [&](int kt, int buf, int q) {   // q = 0..3: A pieces, 4..7: the column tile's four W units
+        const int k = kt < ktiles ? kt : ktiles - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
+        if (q < 4) glds16(a_dma + (unsigned)(buf * kI256Tile + q * 1024), a_off[q], sgpr64(a_base + (unsigned long long)k * 128ull));
+        else glds16(w_dma + (unsigned)(buf * kI256Tile + (q - 4) * 1024), w_voff, sgpr64(w_base + (unsigned long long)(4 * k + (q - 4)) * 1024ull));
+    };
+    i32x4 fa[2][4], fb[2][2];
+    auto read_frags = [&](int buf, int s, i32x4 (&xa)[4], i32x4 (&xb)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const i32x4*>(w_lds + buf * kI256Tile + w_rd + nt * 4096 + s * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const i32x4*>(smem + buf * kI256Tile + mt * 4096 + a_rd[s]);
+    };
+
+    // ---- prologue: tiles 0 and 1 requested; tile 0 landed ------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue_piece(0, 0, q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue_piece(1, 1, q);
+    vm_wait_imm<8>();
+    __syncthreads();
+    read_frags(0, 0, fa[0], fb[0]);
+
+    // ---- K loop (w4_gemm256.hip): sub-steps 0..2, barrier (tile kt + 1 complete, tile kt's last fragments in registers), then the
+    // eight requests of tile kt + 2 one behind each MFMA of sub-step 3, with the first fragment reads of tile kt + 1 in front
+    auto mma_sub = [&](int s) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt], 0, 0, 0);
+    };
+    auto k_tile = [&](int kt, auto curc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+        static_for<3>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);         // the next fragments are requested before these MFMAs; sub-steps do not mix
+            mma_sub(s);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        vm_wait_imm<0>();                              // tile kt + 1 has landed (this wave's pieces)
+        __syncthreads();
+        read_frags(nxt, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
+            acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[1][mt], fb[1][nt], acc[mt][nt], 0, 0, 0);
+            issue_piece(kt + 2, cur, q);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#ifdef QL_I256_STAMPS
+    const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+    int kt = 0;
+    for (; kt + 1 < ktiles; kt += 2) {
+        k_tile(kt, std::integral_constant<int, 0>{});
+        k_tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < ktiles) k_tile(kt, std::integral_constant<int, 0>{});
+#ifdef QL_I256_STAMPS
+    if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_i256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 3] = __builtin_amdgcn_s_memtime() - t_loop0;
+#endif
+    vm_wait_imm<0>();                                  // the queue is empty before LDS is reused
+    __syncthreads();                                   // ... and every wave is past its last fragment read
+
+    // ---- epilogue: rank-1 scales, rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global ----------------
+    const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
+    const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nw + 32 * nt + j;
+        const float ws = Act<T>::load(Sc + (n < N ? n : N - 1));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float asc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                asc[i] = a_scale[m < M ? m : M - 1];
+            }
+            if (wide) {
+                store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane,
+                                    [&](int i) { return (float)acc[mt][nt][i] * (asc[i] * ws); });
+            } else if (n < N) {
+                const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                    if (m < M) store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][nt][i] * (asc[i] * ws), bn);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                       int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kI256Lds) == hipSuccess;
+    }();
+    (void)attr_set;
+    const int nbx = (int)((N + 255) / 256), nby = (int)((M + 255) / 256);
+    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
+    const int sy = 4;
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+    w8a8_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kI256Lds, st>>>(
+        Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), super ? sy : 0, a_scale,
+        (const T*)S, (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+// what the kernel needs: 16-bit outputs, whole 128-byte K tiles (two at least), 32-bit byte offsets into Aq
+bool w8a8_gemm256_can_run(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq) {
+    return (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && M > 0 && N > 0 && K % 128 == 0 && K >= 256 && ((uintptr_t)Aq & 15) == 0 &&
+           M * K < ((int64_t)1 << 31);
+}
+// ... and when the launcher of w8a8.hip takes it: the grid pays in whole rounds of 256 blocks (one block per CU at a time)
+bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq) {
+    static const int off = [] { const char* e = getenv("QLINEAR_W8A8_256"); return e && atoi(e) == 0; }();            // A/B switch
+    static const int min_blocks = [] { const char* e = getenv("QLINEAR_W8A8_256_MIN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    if (off || !w8a8_gemm256_can_run(dtype, M, N, K, Aq)) return false;
+    const int64_t blocks = ((N + 255) / 256) * ((M + 255) / 256);
+    if (min_blocks > 0) return blocks >= min_blocks;
+    const int64_t rounds = (blocks + 255) / 256;
+    return blocks >= 256 && blocks * 10 >= rounds * 256 * 7;
+}
+
+int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                 int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_i256<f16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    case QL_DTYPE_BF16: return launch_i256<__bf16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+}  // namespace ql
+
+#ifdef QL_I256_STAMPS
+extern "C" int qlinear_i256_stamps_read(unsigned long long* out, int blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_i256_stamps), sizeof(unsigned long long) * 8 * blocks);
+}
+#endif

@@ -291,6 +291,21 @@ def w8a8_gemm_tiled(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale
     return c
 
 
+def w8a8_gemm256(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None,
+                 out: Tensor | None = None) -> Tensor:
+    """The many-row kernel alone (``qlinear_w8a8_fwd_tiled256``: 256 x 256 tiles, both operands by LDS-DMA) for any row count -
+    ``w8a8_gemm_tiled`` picks it by itself at prefill row counts.  ``out``: optional (M, >= n_out) buffer (its row stride = ldc)."""
+    lib = _lib.get_lib()
+    M, K = a_q.shape
+    c = torch.empty((M, n_out), device=a_q.device, dtype=w_scale.dtype) if out is None else out
+    with torch.cuda.device(a_q.device):
+        st = lib.qlinear_w8a8_fwd_tiled256(a_q.data_ptr(), a_s.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(),
+                                           _lib.ptr(bias), c.data_ptr(), M, n_out, K, c.stride(0) if M > 1 else n_out,
+                                           _lib.dtype_code(w_scale.dtype), _lib.stream_ptr(a_q.device))
+    _lib.check(st, "qlinear_w8a8_fwd_tiled256")
+    return c[:, :n_out]
+
+
 def w8a8_forward(a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
     """fp activations -> int8 rows -> i8 x i8 -> i32 MFMA -> ``acc * a_scale[m] * w_scale[n]`` (+ bias).
     ``weight_nk`` is the module's (N, K) row-major int8 buffer."""

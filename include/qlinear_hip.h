@@ -304,6 +304,12 @@ int qlinear_w8a8_fwd(const int8_t* Aq, const float* a_scale, const int8_t* W, co
  * MFMA operand: W bypasses LDS; two K-parity wave groups per block).  K % 16 == 0.  No workspace. */
 int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias,
                            void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
+/* The many-row kernel of qlinear_w8a8_fwd_tiled alone (round 3, w8a8_gemm256.hip: 256 x 256 output tiles, both operands global ->
+ * LDS by LDS-DMA - the tile-major weights land as the MFMA fragments they are -, v_mfma_i32_32x32x32_i8; integer stage exact, same
+ * epilogue).  qlinear_w8a8_fwd_tiled picks it by itself at prefill row counts; this entry runs it for any M.  QL_ERR_UNSUPPORTED
+ * unless fp16 / bf16, K % 128 == 0, K >= 256 and M * K < 2^31. */
+int qlinear_w8a8_fwd_tiled256(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                              int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
 /* Both steps of the int8-activation linear in ONE call (two launches): quantise A (M, K) row-wise (or per tensor:
  * flags & QL_FLAG_ACT_PER_TENSOR) into the workspace, then the tile-major GEMM.  workspace: qlinear_workspace_bytes(
  * QL_OP_W8A8_LINEAR_TILED, M, N, K, 0) bytes, 16-byte aligned; it holds Aq (M * K bytes) followed by a_scale (M floats)

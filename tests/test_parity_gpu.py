@@ -522,6 +522,42 @@ def test_w8a8_tiled_vs_oracle(M, K, N, dt):
         assert O.rel_l2(t2n(layer(a.to(DEV))), ref_t) <= {"f32": 1e-6, "f16": 3e-4, "bf16": 2e-3}[dt]
 
 
+I256_SHAPES = [(256, 256, 256, "f16"), (300, 384, 264, "f16"), (1000, 4096, 1000, "bf16"), (512, 13696 - 13696 % 128, 520, "f16"),
+               (2048, 1024, 4608, "bf16"), (1, 256, 40, "f16"), (777, 640, 36, "f16")]
+
+
+@pytest.mark.parametrize("M,K,N,dt", I256_SHAPES)
+def test_w8a8_gemm256_integer_stage_exact_and_epilogue(M, K, N, dt):
+    """The 256 x 256-tile many-row int8 kernel (w8a8_gemm256.hip) called directly (qlinear_w8a8_fwd_tiled256): ragged M and N,
+    odd and even K-tile counts, bf16, bias, one row, a strided output.  Bit-equal to the 128-row-tile kernel (same exact integer
+    sums, same epilogue), epilogue against the oracle, integer stage checked directly where a half holds the sums exactly."""
+    g = torch.Generator().manual_seed(M + K + N)
+    w = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g)
+    sc = (torch.rand(N, generator=g) * 0.01 + 0.001).to(TDT[dt])
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt])
+    tiled = h8.tile_w8(w.to(DEV))
+    a_q, a_s = h8.act_quant_rowwise(a.to(DEV))
+    ref = O.w8a8_matmul(t2n(a), w.numpy(), t2n(sc), t2n(bias), dtype=dt)
+    before = launches()
+    out = h8.w8a8_gemm256(a_q, a_s, tiled, N, sc.to(DEV), bias.to(DEV))
+    assert launches() - before == 1
+    assert O.rel_l2(t2n(out), ref) <= {"f16": 3e-4, "bf16": 2e-3}[dt]
+    assert torch.equal(out, h8.w8a8_gemm_tiled(a_q, a_s, tiled, N, sc.to(DEV), bias.to(DEV)))       # same integer sums, same epilogue
+    small_a = torch.randint(-3, 4, (M, K), dtype=torch.int8, generator=g)
+    small_w = torch.randint(-3, 4, (N, K), dtype=torch.int8, generator=g)
+    ones_m, ones_n = torch.ones(M, device=DEV), torch.ones(N, device=DEV, dtype=TDT[dt])
+    acc = h8.w8a8_gemm256(small_a.to(DEV), ones_m, h8.tile_w8(small_w.to(DEV)), N, ones_n)
+    want = O.w8a8_acc_i32(small_a.numpy(), small_w.numpy()).astype(np.float64)
+    ok = np.abs(want) <= (2048 if dt == "f16" else 256)                     # integers the output dtype holds exactly
+    assert np.array_equal(t2n(acc).astype(np.float64)[ok], want[ok]) and ok.mean() > 0.5
+    wide = torch.full((M, N + 3), 7.0, device=DEV, dtype=TDT[dt])               # ldc = N + 3: element-wise stores
+    got = h8.w8a8_gemm256(a_q, a_s, tiled, N, sc.to(DEV), bias.to(DEV), out=wide)
+    assert torch.equal(got, out) and bool((wide[:, N:] == 7.0).all())
+    with pytest.raises(ValueError):
+        h8.w8a8_gemm256(a_q[:, :64].contiguous(), a_s, tiled, N, sc.to(DEV))      # K = 64: not served
+
+
 # ---- W4A8: int4g32 weights x int8-quantised activations (SURVEY.md 8d config 5; VERDICT r1 row A10) -------------------
 W4A8_SHAPES = [(512, 4096, 4096, "f16"), (70, 1024, 200, "f16"), (33, 512, 96, "bf16"), (1, 4096, 256, "f16"),
                (130, 13696, 136, "f16"), (2048, 1024, 512, "bf16"), (513, 4160, 264, "f16"), (40, 64, 40, "f16"),

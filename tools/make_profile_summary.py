@@ -5,7 +5,8 @@ import csv, json, os, shutil, statistics, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof")
-dst = os.path.join(root, "profiles")
+dst = os.environ.get("PROFILE_DST", os.path.join(root, "profiles"))     # profile_round.sh: a directory under gpurun_out/ on the GPU box
+os.makedirs(dst, exist_ok=True)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 csv.field_size_limit(1 << 30)
 
