@@ -313,9 +313,11 @@ def e2e_generate(torch, device):
     out["resident_bytes"] = _resident_bytes(model)
     out["drop_in_reference_graph"] = drop_in_generate(torch, model, prompt)
     out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, greedy, fp16, synthetic weights"
-    # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 512 positions (M = 2048 rows per forward)
+    # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 1024 positions (M = 4096 rows per forward: the 256 x 256-tile
+    # GEMM takes o_proj / w_in / w_out there; tools/prefill_chunks.py, round 3: 0.154 / 0.128 / 0.120 / 0.131 s for chunks of 256 / 512 /
+    # 1024 / 2048)
     from chatglm_q_amd.decoder import DecodeSession
-    B, S, CH = 4, 2048, 512
+    B, S, CH = 4, 2048, 1024
     ids = torch.randint(0, cfg.vocab_size, (B, S), device=device)
     lin_flops = 2.0 * B * S * (4096 * 4608 + 4096 * 4096 + 4096 * 27392 + 13696 * 4096) * 28
     sess = DecodeSession(model, B, S, use_graph=False)

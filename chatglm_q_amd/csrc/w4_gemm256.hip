@@ -352,7 +352,8 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     (void)attr_set;
     const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
     static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
-    const int sy = 4;                                  // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
+    static const int sy_env = [] { const char* e = getenv("QLINEAR_GEMM_SY"); return e ? atoi(e) : 0; }();            // tuning sweeps
+    const int sy = sy_env > 0 ? sy_env : 4;            // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w4_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
