@@ -81,6 +81,8 @@ EXPORTS = {
                                c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8_tiled_bytes": (c_size_t, [c_int64, c_int64]),
     "qlinear_w8_tile": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "qlinear_w8_fwd_tiled256": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                        c_int, c_void_p]),
     "qlinear_w8_fwd_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                      c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8_fwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,

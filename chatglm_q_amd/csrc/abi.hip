@@ -349,6 +349,16 @@ int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t 
     return w8_tile(W, (int8_t*)tiled, N, K, ldw_n, (hipStream_t)stream);
 }
 
+int qlinear_w8_fwd_tiled256(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                            int64_t K, int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!A || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || K % 16 != 0 || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
+    if (!w4_gemm256_can_run(M, N, K, lda, A, esize(dtype))) return QL_ERR_UNSUPPORTED;
+    return w8_gemm256(dtype, A, (const int8_t*)tiled, S, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
 int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (!A || !tiled || !S || !C) return QL_ERR_NULL_POINTER;

@@ -63,8 +63,46 @@ template <int N>
 __device__ __forceinline__ void vm_wait_imm(i32x4& w, unsigned& s) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w), "+v"(s) : "n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void vm_wait_imm(i32x4& w, i32x4& w2) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w), "+v"(w2) : "n"(N) : "memory");
+}
 
+// int8 per-channel weights (W8 = true: the module layout's tile-major copy, qlinear_w8_tile): 8 bytes -> the 8 halves b * s ROUNDED
+// to the activation dtype (chatglm_q/int8/triton_ops.py:62-73) in NATURAL k order - the A tile arrives by LDS-DMA and cannot be
+// regrouped on the way like w8_gemm.hip's register-staged tile.  fp16: v_perm_b32 splices the bytes (b ^ 0x80) under 0x64 = 1152 + b
+// pair by pair in k order (one instruction per pair, no shift), minus 1152 (exact), times s (ONE rounding).
 template <typename T>
+__device__ __forceinline__ u32x4 w8_dequant_natural(u32 w0, u32 w1, float s) {
+    if constexpr (sizeof(T) == 2 && Act<T>::code == QL_DTYPE_F16) {
+        const h2 k1152 = {(f16)1152.0f, (f16)1152.0f};
+        const f16 sh = (f16)s;
+        const h2 s2 = {sh, sh};
+        const u32 t0 = w0 ^ 0x80808080u, t1 = w1 ^ 0x80808080u, k64 = 0x64646464u;
+        const h2 e0 = (as_h2(__builtin_amdgcn_perm(k64, t0, 0x04010400u)) - k1152) * s2;      // (b0, b1)
+        const h2 e1 = (as_h2(__builtin_amdgcn_perm(k64, t0, 0x04030402u)) - k1152) * s2;      // (b2, b3)
+        const h2 e2 = (as_h2(__builtin_amdgcn_perm(k64, t1, 0x04010400u)) - k1152) * s2;
+        const h2 e3 = (as_h2(__builtin_amdgcn_perm(k64, t1, 0x04030402u)) - k1152) * s2;
+        return u32x4{as_u32(e0), as_u32(e1), as_u32(e2), as_u32(e3)};
+    } else {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 w = i < 2 ? w0 : w1;
+            const int sh = 16 * (i & 1);
+            const float lo = (float)((int)(w << (24 - sh)) >> 24) * s;            // byte 2 i of the octet
+            const float hi = (float)((int)(w << (16 - sh)) >> 24) * s;            // byte 2 i + 1
+            const bf2 pr = {(__bf16)lo, (__bf16)hi};                              // one rounding each
+            r[i] = __builtin_bit_cast(u32, pr);
+        }
+        return r;
+    }
+}
+
+// W8 = false: int4g32, Wt / Sp = part 2 of the derived layout (units + scales, [column tile][K tile][lane]).
+// W8 = true: int8 per channel, Wt = the tile-major copy ([column tile][K tile][half][lane][16 B]: two units per lane and K tile), Sp = S[n].
+template <typename T, bool W8 = false>
 __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                          int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
                                                          const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
@@ -90,8 +128,10 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * 8 + wave;
     const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;          // clamped: loads stay in bounds, stores are masked
-    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
+    constexpr unsigned long long kWTile = W8 ? 2048ull : 1024ull;     // bytes of one column tile and K tile
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * kWTile);
     const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
+    const float sc8 = W8 ? Act<T>::load(Sp + (32 * ct + j < N ? 32 * ct + j : N - 1)) : 0.f;     // the lane's output channel
     const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
     // activations: pieces 4 wave .. 4 wave + 3 of the tile's 32 (1 KB = 8 rows each); lane -> (row, stored chunk position),
     // source chunk = position ^ swizzle(row)
@@ -122,7 +162,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
     i32x4 wq[2];                                       // packed weight unit of K tile (kt + 1), (kt + 2): two register sets
-    unsigned wsc[2];
+    std::conditional_t<W8, i32x4, unsigned> wsc[2];    // int4: the unit's scale; int8: the lane's second unit (half 1)
     auto issue_a = [&](int kt, int buf) {
 #if QL_G256_ABLATE & 8                              // timing ablation: no A pieces in the loop (4 dummy loads keep the queue counts)
         if (kt > 1) {
@@ -137,22 +177,36 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     };
     auto issue_w = [&](int kt, int set) {
         const int k = kt < ksteps ? kt : ksteps - 1;
-        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * 1024ull));
-        gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
+        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * kWTile));
+        if constexpr (W8) gload16(wsc[set], w_voff, sgpr64(w_base + (unsigned long long)k * kWTile + 1024ull));
+        else gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
+    };
+    auto issue_w2 = [&](int k, int set) {              // second request of a K tile's weights: int8: half 1 of the lane's bytes; int4: the scale
+        if constexpr (W8) gload16(wsc[set], w_voff, sgpr64(w_base + (unsigned long long)k * kWTile + 1024ull));
+        else gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
     };
     typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
-    auto scale_of = [&](unsigned bits) {
-        const uint16_t h = (uint16_t)bits;
-        T sv;
-        __builtin_memcpy(&sv, &h, 2);
-        return MM::scale_pair(&sv, true);
+    auto scale_of = [&](auto raw) {
+        if constexpr (W8) return MM::scale_pair((const T*)nullptr, false);          // unused: the channel scale is sc8
+        else {
+            const uint16_t h = (uint16_t)raw;
+            T sv;
+            __builtin_memcpy(&sv, &h, 2);
+            return MM::scale_pair(&sv, true);
+        }
     };
     auto dequant_store = [&](int set, int buf, int s, scale_t sc) {     // word s of the unit -> B fragment (sub-step s) of the tile
 #if QL_G256_ABLATE & 1                              // timing ablation (results wrong): no dequant arithmetic
         const u32x4 f = {(u32)wq[set][s], (u32)wq[set][s] ^ k_magic, (u32)wq[set][s], k_magic};
         (void)sc;
 #else
-        const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+        u32x4 f;
+        if constexpr (W8) {                            // sub-step s = (half s >> 1, octet s & 1) of the lane's 32 bytes
+            const i32x4& unit = (s >> 1) ? wsc[set] : wq[set];
+            f = w8_dequant_natural<T>((u32)unit[2 * (s & 1)], (u32)unit[2 * (s & 1) + 1], sc8);
+        } else {
+            f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+        }
 #endif
 #if QL_G256_ABLATE & 2                              // ... no B-fragment stores either
         if (f[0] == 0x12345678u && f[3] == 0x9abcdef0u)
@@ -278,8 +332,8 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
                 constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
                 acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
                 if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
-                else if constexpr (q == 4) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * 1024ull));
-                else if constexpr (q == 5) gload2(wsc[nxt], s_voff, sgpr64(s_base + (unsigned long long)kw * (64ull * sizeof(T))));
+                else if constexpr (q == 4) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile));
+                else if constexpr (q == 5) issue_w2(kw, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -359,6 +413,34 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc);
     return finish_launch();
+}
+
+template <typename T>
+static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int M, int N, int K, int64_t lda,
+                             int64_t ldc, hipStream_t st) {
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kG256Lds) == hipSuccess;
+    }();
+    (void)attr_set;
+    const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
+    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
+    const int sy = 4;
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+    w4_gemm256_kernel<T, true><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
+        (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K),
+        super ? sy : 0, (const T*)bias, (T*)C, ldc);
+    return finish_launch();
+}
+
+// int8 per-channel weights (tile-major copy) through the same kernel: C = A . (W^T * s[n]) with the reference's per-weight rounding
+int w8_gemm256(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+               int64_t lda, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256_w8<f16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_gemm256_w8<__bf16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
 }
 
 // rows / shapes the 256 x 256 kernel takes (the launcher in w4_gemm.hip asks): whole 64-deep K tiles, 16-byte aligned rows,

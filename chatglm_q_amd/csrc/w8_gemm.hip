@@ -354,6 +354,9 @@ static int launch_w8_gemm_tiled(const void* A, const int8_t* Wm, const void* S, 
 
 int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    static const int off256 = [] { const char* e = getenv("QLINEAR_W8_256"); return e && atoi(e) == 0; }();         // A/B switch
+    if (!off256 && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && w4_gemm256_supported(M, N, K, lda, A, 2))
+        return w8_gemm256(dtype, A, Wm, S, bias, C, M, N, K, lda, ldc, st);     // prefill row counts: 256 x 256 tiles (w4_gemm256.hip)
     switch (dtype) {
     case QL_DTYPE_F16: return launch_w8_gemm_tiled<f16>(A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
     case QL_DTYPE_BF16: return launch_w8_gemm_tiled<__bf16>(A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);

@@ -104,6 +104,21 @@ def w8_tiled_supported(a: Tensor, weight_nk: Tensor) -> bool:
             and a.numel() // max(a.shape[-1], 1) > 2)
 
 
+def w8_gemm256(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+    """The many-row weight-only kernel alone (``qlinear_w8_fwd_tiled256``: 256 x 256 tiles) for any row count - ``w8_forward_tiled``
+    picks it by itself at prefill row counts.  ``out``: optional (M, >= n_out) buffer (its row stride = ldc)."""
+    lib = _lib.get_lib()
+    a2 = _rows(a)
+    M, K = a2.shape
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype) if out is None else out
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd_tiled256(a2.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(), _lib.ptr(bias), c.data_ptr(),
+                                         M, n_out, K, a2.stride(0) if M > 1 else K, c.stride(0) if M > 1 else n_out,
+                                         _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_w8_fwd_tiled256")
+    return c[:, :n_out]
+
+
 def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None,
                      plan_out: list | None = None, guards=()) -> Tensor:
     """``a @ (W * scale).T (+ bias)`` for >= 3 rows on the tile-major copy (few-row kernel / tiled MFMA GEMM)."""

@@ -202,6 +202,12 @@ size_t qlinear_w8_tiled_bytes(int64_t N, int64_t K);
 int qlinear_w8_tile(const int8_t* W, void* tiled, int64_t N, int64_t K, int64_t ldw_n, void* stream);
 int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The many-row kernel of qlinear_w8_fwd_tiled alone (round 3: the 256 x 256-tile kernel of w4_gemm256.hip fed from the tile-major
+ * int8 copy; every weight b * s rounded to the activation dtype, chatglm_q/int8/triton_ops.py:62-73, fp32 accumulation).  Picked
+ * automatically at prefill row counts; this entry runs it for any M.  QL_ERR_UNSUPPORTED unless K % 64 == 0, K >= 128, 16-byte
+ * aligned rows of A and M * lda * 2 < 2^31. */
+int qlinear_w8_fwd_tiled256(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                            int64_t K, int64_t lda, int64_t ldc, int dtype, void* stream);
 
 /* Few rows (batched decode: 2..32) through a first MLP projection with the SiLU * gate EPILOGUE: `packed` holds the
  * gate-interleaved column order (h_2t, h_2t+1, gate_2t, gate_2t+1), C gets N / 2 columns,

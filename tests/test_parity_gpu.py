@@ -522,6 +522,32 @@ def test_w8a8_tiled_vs_oracle(M, K, N, dt):
         assert O.rel_l2(t2n(layer(a.to(DEV))), ref_t) <= {"f32": 1e-6, "f16": 3e-4, "bf16": 2e-3}[dt]
 
 
+W8_256_SHAPES = [(256, 128, 256, "f16", False), (300, 192, 264, "f16", True), (1000, 4096, 1000, "bf16", False),
+                 (512, 13696, 520, "f16", False), (2048, 1024, 4608, "bf16", True), (1, 256, 40, "f16", True), (777, 320, 36, "f16", False)]
+
+
+@pytest.mark.parametrize("M,K,N,dt,has_bias", W8_256_SHAPES)
+def test_int8_gemm256_vs_oracle(M, K, N, dt, has_bias):
+    """int8 per-channel weights through the 256 x 256-tile many-row kernel (qlinear_w8_fwd_tiled256): the reference's per-weight
+    rounding kept (fp16 <= 1.5e-4 of the oracle, bf16 <= 1e-3), incl. -128, negative scales, ragged M / N, odd K-tile counts, strided C."""
+    g = torch.Generator().manual_seed(M * 3 + K + N)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g)
+    sc = ((torch.rand(N, generator=g) * 0.01 + 0.001) * (torch.randint(0, 2, (N,), generator=g) * 2 - 1)).to(TDT[dt])
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt]) if has_bias else None
+    ref = O.w8_matmul(t2n(a), np.ascontiguousarray(w.numpy().T), t2n(sc), None if bias is None else t2n(bias), dtype=dt)
+    tiled = h8.tile_w8(w.to(DEV))
+    bd = None if bias is None else bias.to(DEV)
+    before = launches()
+    out = h8.w8_gemm256(a.to(DEV), tiled, N, sc.to(DEV), bd)
+    assert launches() - before == 1
+    assert_close(out, ref, dt, f"{M}x{K}x{N}")
+    assert O.rel_l2(t2n(out), ref) <= (1.5e-4 if dt == "f16" else 1e-3)
+    wide = torch.full((M, N + 3), 7.0, device=DEV, dtype=TDT[dt])
+    got = h8.w8_gemm256(a.to(DEV), tiled, N, sc.to(DEV), bd, out=wide)
+    assert torch.equal(got, out) and bool((wide[:, N:] == 7.0).all())
+
+
 I256_SHAPES = [(256, 256, 256, "f16"), (300, 384, 264, "f16"), (1000, 4096, 1000, "bf16"), (512, 13696 - 13696 % 128, 520, "f16"),
                (2048, 1024, 4608, "bf16"), (1, 256, 40, "f16"), (777, 640, 36, "f16")]
 
