@@ -203,6 +203,29 @@ def prefill_gemm(torch, device):
     return out
 
 
+def int8_prefill_gemm(torch, device):
+    """The int8 model's many-row GEMMs at M = 8192 (o_proj and w_out shapes): weight-only (the reference's int8 forward,
+    chatglm_q/int8/triton_ops.py:62-73) in TFLOP/s and int8-activation (act_quant) in TOP/s, GEMM launch alone."""
+    from chatglm_q_amd.int8 import hip_ops
+    gen = torch.Generator(device=device).manual_seed(19)
+    M, out = 8192, {}
+    for name, K, N in [("o_proj", 4096, 4096), ("w_out", 13696 - 13696 % 128, 4096)]:
+        tiled = [hip_ops.tile_w8(torch.randint(-127, 128, (N, K), dtype=torch.int8, device=device, generator=gen)) for _ in range(3)]
+        sc = (torch.rand(N, device=device, generator=gen) * 0.01 + 0.001).half()
+        a = torch.randn(M, K, device=device, dtype=torch.float16)
+        a_q, a_s = hip_ops.act_quant_rowwise(a)
+        us_w = _graph_time(torch, device, lambda: [hip_ops.w8_forward_tiled(a, t, N, sc) for t in tiled]) / len(tiled) * 1e3
+        us_a = _graph_time(torch, device, lambda: [hip_ops.w8a8_gemm_tiled(a_q, a_s, t, N, sc) for t in tiled]) / len(tiled) * 1e3
+        ops = 2.0 * M * N * K
+        out[name] = {"M": M, "K": K, "N": N, "weight_only_us": round(us_w, 1), "weight_only_TFLOPs": round(ops / us_w / 1e6, 1),
+                     "weight_only_frac_of_2.5PF_f16_mfma": round(ops / us_w / 1e6 / 2500.0, 4),
+                     "int8_activations_us": round(us_a, 1), "int8_activations_TOPs": round(ops / us_a / 1e6, 1),
+                     "int8_activations_frac_of_i8_mfma_peak": round(ops / us_a / 1e6 / I8_MFMA_PEAK_TOPS, 4)}
+        del tiled
+        torch.cuda.empty_cache()
+    return out
+
+
 def _chatglm2_6b(torch, device, dtype, seed=0):
     from chatglm_q_amd import model as M
     cfg = M.ChatGLM2Config()
@@ -377,7 +400,8 @@ def run(torch, device):
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
-                     ("prefill_gemm_M8192", prefill_gemm), ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
+                     ("prefill_gemm_M8192", prefill_gemm), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
+                     ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)
         except Exception as e:      # keep going: extras are informative only
