@@ -91,6 +91,9 @@ __device__ __forceinline__ void store_out(T* c, float acc, const T* bias_n) {
 // reads it back as 16-byte row chunks: 2 stores per lane instead of 16.  `val(i)` = final fp32 value of accumulator
 // element i (row (i & 3) + 8 (i >> 2) + 4 kb, column j) BEFORE the output rounding; bias (nullable) is added as a
 // second rounded operation (store_out's sequence).  Requires 16-byte aligned C rows (n0 % 8 == 0, ldc % 8 == 0).
+#ifndef QL_STORE_TILE_WAIT
+#define QL_STORE_TILE_WAIT 0
+#endif
 template <typename T, typename F>
 __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
                                                  const T* __restrict__ bias, int lane, F val) {
@@ -104,9 +107,14 @@ __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C,
         if (bias) y = y + bj;
         Act<T>::store(lds_wave + row * 32 + j, y);
     }
+    // One wave's LDS instructions execute in issue order, so the reads below see the writes above without a wait (round 3: the
+    // explicit lgkmcnt(0) here cost one LDS round trip per 32 x 32 tile, 8 tiles per wave in the 256 x 256-tile GEMMs); the wave
+    // barrier only keeps the compiler from moving the reads up.
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's own LDS writes have landed
+#if QL_STORE_TILE_WAIT
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int q = lane + 64 * h, row = q >> 2, c8 = (q & 3) * 8;
