@@ -44,6 +44,19 @@ int main() {
                 hipDeviceSynchronize();
             }
             hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+            // sustained: a 100 x longer run under HIP events -> wall-clock rate and the clock the chip holds on this instruction alone
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            const int long_iters = iters * 100;
+            hipEventRecord(e0);
+            if (kind == 0) k<0><<<256, waves * 64>>>(d, long_iters);
+            if (kind == 1) k<1><<<256, waves * 64>>>(d, long_iters);
+            if (kind == 2) k<2><<<256, waves * 64>>>(d, long_iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long h2[2]; hipMemcpy(h2, d, 16, hipMemcpyDeviceToHost);
+            const double macs_total = (kind == 1 ? 16.0 * 16 * 64 : kind == 0 ? 32.0 * 32 * 32 : 32.0 * 32 * 16) * 4.0 * long_iters * waves * 256;
+            printf("    sustained %.2f ms: %.2f P(FL)OP/s wall, clock %.2f GHz\n", ms, macs_total * 2 / (ms * 1e-3) / 1e15, (double)h2[0] / (ms * 1e-3) / 1e9);
             const double per_wave = (double)h[0] / (iters * 4.0), per_simd = per_wave / (waves / 4);
             const double macs = kind == 1 ? 16.0 * 16 * 64 : kind == 0 ? 32.0 * 32 * 32 : 32.0 * 32 * 16;
             printf("%-26s %d wave(s) per SIMD: %6.1f cycles per MFMA per wave = %5.1f per SIMD issue -> %6.0f MAC/cycle/SIMD -> %5.2f P(FL)OP/s at 2.4 GHz\n",
