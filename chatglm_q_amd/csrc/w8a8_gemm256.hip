@@ -16,6 +16,10 @@
 #include "launch.h"
 #include "vmq.h"
 
+#ifndef QL_I256_ABLATE
+#define QL_I256_ABLATE 0
+#endif
+
 namespace ql {
 
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -73,6 +77,9 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restr
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0;
 
     auto issue_piece = [&](int kt, int buf, int q) {   // q = 0..3: A pieces, 4..7: the column tile's four W units
+#if QL_I256_ABLATE & 2                              // energy ablation: no requests in the loop (tiles 0 / 1 stay in LDS)
+        if (kt >= 2) return;
+#endif
         const int k = kt < ktiles ? kt : ktiles - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
         if (q < 4) glds16(a_dma + (unsigned)(buf * kI256Tile + q * 1024), a_off[q], sgpr64(a_base + (unsigned long long)k * 128ull));
         else glds16(w_dma + (unsigned)(buf * kI256Tile + (q - 4) * 1024), w_voff, sgpr64(w_base + (unsigned long long)(4 * k + (q - 4)) * 1024ull));
@@ -82,7 +89,12 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restr
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const i32x4*>(w_lds + buf * kI256Tile + w_rd + nt * 4096 + s * 1024);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const i32x4*>(smem + buf * kI256Tile + mt * 4096 + a_rd[s]);
+        for (int mt = 0; mt < 4; ++mt) {
+#if QL_I256_ABLATE & 1                              // energy ablation (results wrong): half the A fragment reads, the other half reused
+            if (mt >= 2) { xa[mt] = xa[mt - 2]; continue; }
+#endif
+            xa[mt] = *reinterpret_cast<const i32x4*>(smem + buf * kI256Tile + mt * 4096 + a_rd[s]);
+        }
     };
 
     // ---- prologue: tiles 0 and 1 requested; tile 0 landed ------------------------------------------------------------------------
