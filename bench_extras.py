@@ -11,6 +11,10 @@ import time
 
 HBM_PEAK_GBPS = 8000.0
 I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA peak (~2x the 2.5 PF bf16 figure)
+# what an MFMA-ONLY loop (no memory, no LDS) sustains on RANDOM operands on this chip (round 3, profiles/r03_mfma_power.txt,
+# tools/microbench/mfma_data_power.hip): the power budget holds the nominal dense peaks on constant operands only
+F16_MFMA_RANDOM_DATA_TFLOPS = 1700.0
+I8_MFMA_RANDOM_DATA_TOPS = 3270.0
 
 
 def _graph_time(torch, device, fn, reps=3):
@@ -197,7 +201,8 @@ def prefill_gemm(torch, device):
         ms = _graph_time(torch, device, fn)
         flops = 2.0 * M * N * K
         out[name] = {"M": M, "K": K, "N": N, "ms": round(ms, 4), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
-                     "frac_of_2.5PF_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 4)}
+                     "frac_of_2.5PF_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 4),
+                     "frac_of_mfma_only_loop_on_random_data_1.7PF": round(flops / (ms * 1e-3) / 1e12 / F16_MFMA_RANDOM_DATA_TFLOPS, 4)}
         del layer, x
         torch.cuda.empty_cache()
     return out
@@ -219,6 +224,8 @@ def int8_prefill_gemm(torch, device):
         ops = 2.0 * M * N * K
         out[name] = {"M": M, "K": K, "N": N, "weight_only_us": round(us_w, 1), "weight_only_TFLOPs": round(ops / us_w / 1e6, 1),
                      "weight_only_frac_of_2.5PF_f16_mfma": round(ops / us_w / 1e6 / 2500.0, 4),
+                     "weight_only_frac_of_mfma_only_loop_on_random_data_1.7PF": round(ops / us_w / 1e6 / F16_MFMA_RANDOM_DATA_TFLOPS, 4),
+                     "int8_activations_frac_of_mfma_only_loop_on_random_data_3.27POPs": round(ops / us_a / 1e6 / I8_MFMA_RANDOM_DATA_TOPS, 4),
                      "int8_activations_us": round(us_a, 1), "int8_activations_TOPs": round(ops / us_a / 1e6, 1),
                      "int8_activations_frac_of_i8_mfma_peak": round(ops / us_a / 1e6 / I8_MFMA_PEAK_TOPS, 4)}
         del tiled
