@@ -191,19 +191,22 @@ def prefill_gemm(torch, device):
     M = int(os.environ.get("PREFILL_GEMM_M", 8192))          # tools/prefill_gemm_ab.py sweeps it
     out = {}
     for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 4096, 27392), ("w_out", 13696, 4096)]:
-        layer = _w4_layer(torch, device, K, N, False, gen)
+        # four weight sets per captured graph: a fresh set of weights per launch (as in a model), and the ~10 us a graph replay costs on
+        # its own (MI355X_MICROARCH.md, graph-replay-floor) is spread over four launches instead of charged to one 250 us kernel
+        layers = [_w4_layer(torch, device, K, N, False, gen) for _ in range(4)]
         x = torch.randn(M, K, device=device, dtype=torch.float16)
 
         def fn():
             with torch.no_grad():
-                layer(x)
+                for layer in layers:
+                    layer(x)
 
-        ms = _graph_time(torch, device, fn)
+        ms = _graph_time(torch, device, fn) / len(layers)
         flops = 2.0 * M * N * K
         out[name] = {"M": M, "K": K, "N": N, "ms": round(ms, 4), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
                      "frac_of_2.5PF_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 4),
                      "frac_of_mfma_only_loop_on_random_data_1.7PF": round(flops / (ms * 1e-3) / 1e12 / F16_MFMA_RANDOM_DATA_TFLOPS, 4)}
-        del layer, x
+        del layers, x
         torch.cuda.empty_cache()
     return out
 
