@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 model, cfg = bench_extras._chatglm2_6b(torch, dev, torch.float16)
 B, S = 4, 2048
 ids = torch.randint(0, cfg.vocab_size, (B, S), device=dev)
-for CH in (256, 512, 1024, 2048):
+for CH in (int(c) for c in os.environ.get("CHUNKS", "256,512,1024,2048").split(",")):
     sess = DecodeSession(model, B, S, use_graph=False)
     sess.prefill(ids[:, :CH], CH)
     torch.cuda.synchronize()
