@@ -41,8 +41,16 @@ TOL_CPU = 2e-3
 
 @pytest.fixture(scope="module")
 def real_cpu():
+    """The modules' CPU branch with its dense product accumulated by the fp32 GEMM and rounded once (torch's fp16 CPU GEMM
+    does the same arithmetic in another summation order at 0.1 GFLOP/s: this file took 14 minutes with it)."""
+    from chatglm_q_amd.int4 import qlinear as Q4
     torch.set_num_threads(8)
-    return build_real()
+    saved = Q4._dense_matmul
+    Q4._dense_matmul = lambda A, W: (A.float() @ W.float()).to(A.dtype) if A.dtype == torch.float16 else saved(A, W)
+    try:
+        yield build_real()
+    finally:
+        Q4._dense_matmul = saved
 
 
 def test_b1_prefill_and_cached_decode_match_reference(real_cpu):
