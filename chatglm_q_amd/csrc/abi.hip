@@ -656,6 +656,27 @@ int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64
     return masked_softmax(dtype, scores, mask, P, rows, T, mask ? mask_rows : 1, lds, ldm, ldp, (hipStream_t)stream);
 }
 
+int qlinear_prefill_attention_tiles(int64_t* q_block, int64_t* k_tile) {
+    if (!q_block || !k_tile) return QL_ERR_NULL_POINTER;
+    prefill_attention_tiles(q_block, k_tile);
+    return 0;
+}
+
+int qlinear_prefill_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, const uint8_t* tile_flags,
+                              void* Out, int64_t B, int64_t S, int64_t T, int64_t H, int64_t G, int64_t D, int64_t capacity,
+                              int64_t ldm, int dtype, void* stream) {
+    if (!Q || !Kcache || !Vcache || !Out) return QL_ERR_NULL_POINTER;
+    if (tile_flags && !mask) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (B < 0 || !fits_i32(S) || !fits_i32(T) || !fits_i32(H) || !fits_i32(G) || !fits_i32(capacity) || T > capacity ||
+        (mask && ldm < T) || B * G * ((S + 15) / 16) >= ((int64_t)1 << 31) || capacity * G * D >= ((int64_t)1 << 31))
+        return QL_ERR_BAD_SHAPE;
+    if (D != 128 || H != 16 * G || dtype == QL_DTYPE_F32) return QL_ERR_UNSUPPORTED;
+    if ((((uintptr_t)Q | (uintptr_t)Kcache | (uintptr_t)Vcache | (uintptr_t)Out) & 15) != 0) return QL_ERR_MISALIGNED;
+    if (B == 0) return 0;
+    return prefill_attention(dtype, Q, Kcache, Vcache, mask, tile_flags, Out, B, S, T, H, G, capacity, ldm, (hipStream_t)stream);
+}
+
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream) {
     if (!In || !Out) return QL_ERR_NULL_POINTER;

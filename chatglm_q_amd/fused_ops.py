@@ -194,6 +194,78 @@ def masked_softmax(scores: Tensor, mask: Tensor | None) -> Tensor:
     return out
 
 
+_PF_TILES = None
+
+
+def prefill_attention_tiles():
+    """(query positions per workgroup, keys per tile) of qlinear_prefill_attention: the granularity of its tile flags."""
+    global _PF_TILES
+    if _PF_TILES is None:
+        import ctypes
+        qb, kb = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(_lib.get_lib().qlinear_prefill_attention_tiles(ctypes.byref(qb), ctypes.byref(kb)), "qlinear_prefill_attention_tiles")
+        _PF_TILES = (int(qb.value), int(kb.value))
+    return _PF_TILES
+
+
+def attention_tile_flags(mask: Tensor) -> Tensor:
+    """Per (sequence, query block, key tile) of an additive fp32 mask (B, S, T): 0 = the tile can be skipped (every entry
+    <= -1e9 and every row of the block has an entry >= -1e6: the probabilities are exactly 0 in fp32), 2 = every entry is 0
+    (no mask loads), 1 = otherwise.  One pass over the mask per prefill chunk, shared by all layers."""
+    QB, KB = prefill_attention_tiles()
+    B, S, T = mask.shape
+    nq, nk = (S + QB - 1) // QB, (T + KB - 1) // KB
+    blocked, zero, row_ok = mask <= -1e9, mask == 0, (mask >= -1e6).any(dim=-1)
+    if nq * QB != S or nk * KB != T:                       # rows / keys past the end never force a load or forbid a skip
+        pad = (0, nk * KB - T, 0, nq * QB - S)
+        blocked = torch.nn.functional.pad(blocked, pad, value=True)
+        zero = torch.nn.functional.pad(zero, pad, value=True)
+        row_ok = torch.nn.functional.pad(row_ok, (0, nq * QB - S), value=True)
+    skip = blocked.view(B, nq, QB, nk, KB).all(dim=4).all(dim=2) & row_ok.view(B, nq, QB).all(dim=2)[:, :, None]
+    clear = zero.view(B, nq, QB, nk, KB).all(dim=4).all(dim=2)
+    flags = torch.ones((B, nq, nk), dtype=torch.uint8, device=mask.device)
+    flags[clear] = 2
+    flags[skip] = 0
+    return flags.contiguous()
+
+
+def prefill_attention_supported(q_dtype, H: int, G: int, D: int) -> bool:
+    return D == 128 and H == 16 * G and q_dtype in (torch.float16, torch.bfloat16)
+
+
+def prefill_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor | None, flags: Tensor | None, T: int,
+                      H: int, G: int, D: int) -> Tensor:
+    """softmax(round(q / sqrt(D)) k^T + mask) v for S new positions against cache rows [0, T) in one launch
+    (chatglm_q/model.py:157-175).  q (B, S, H * D) rotated queries, caches (B, capacity, G, D), mask (B, S, T) additive fp32
+    (or None), flags from attention_tile_flags(mask) (or None: every tile is processed with its mask).  Returns (B, S, H * D)."""
+    lib = _lib.get_lib()
+    B, S = q.shape[0], q.shape[1]
+    if not (q.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise ValueError("prefill_attention: q and the caches must be contiguous")
+    if k_cache.shape != v_cache.shape or k_cache.shape[0] != B or tuple(k_cache.shape[2:]) != (G, D) or q.numel() != B * S * H * D:
+        raise ValueError("prefill_attention: shape mismatch")
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise ValueError("prefill_attention: dtype mismatch")
+    ldm = 0
+    if mask is not None:
+        if mask.dtype != torch.float32 or tuple(mask.shape) != (B, S, T):
+            raise ValueError("mask must be an fp32 (B, S, T) tensor")
+        mask = mask.contiguous()
+        ldm = T
+    if flags is not None:
+        QB, KB = prefill_attention_tiles()
+        if mask is None or flags.dtype != torch.uint8 or tuple(flags.shape) != (B, (S + QB - 1) // QB, (T + KB - 1) // KB):
+            raise ValueError("tile flags do not match the mask's shape")
+        flags = flags.contiguous()
+    out = torch.empty((B, S, H * D), device=q.device, dtype=q.dtype)
+    with torch.cuda.device(q.device):
+        st = lib.qlinear_prefill_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), _lib.ptr(mask), _lib.ptr(flags),
+                                           out.data_ptr(), B, S, T, H, G, D, k_cache.shape[1], ldm, _lib.dtype_code(q.dtype),
+                                           _lib.stream_ptr(q.device))
+    _lib.check(st, "qlinear_prefill_attention")
+    return out
+
+
 def silu_mul(x: Tensor, hidden: int) -> Tensor:
     lib = _lib.get_lib()
     x2 = x.reshape(-1, x.shape[-1])

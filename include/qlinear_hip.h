@@ -404,6 +404,21 @@ int qlinear_decode_attention_rope_prefetch(const void* QKV, const void* table, c
  * between the two GEMMs of the many-position attention (chatglm_q/model.py:166-170) in one pass; mask nullable. */
 int qlinear_masked_softmax(const void* scores, const float* mask, void* P, int64_t rows, int64_t T, int64_t mask_rows,
                            int64_t lds, int64_t ldm, int64_t ldp, int dtype, void* stream);
+/* prefill_attention (round 3): the many-position attention between qkv_proj and o_proj of a prefill chunk in ONE launch
+ * (chatglm_q/model.py:157-175: q / sqrt(d), q k^T, + mask, fp32 softmax, cast, p v) instead of two batched GEMMs around
+ * qlinear_masked_softmax - the (heads x S x T) score matrix is never written.  Q (B, S, H, D) rotated queries (qlinear_rope_kv_write),
+ * Kcache / Vcache (B, capacity, G, D) of which rows [0, T) are attended, mask (B, S, T) additive fp32 with row stride ldm
+ * (nullable = no mask), Out (B, S, H * D).  Applied exactly as the reference applies it: round(score) + mask in fp32, so a row
+ * whose keys are all blocked comes out as the uniform average.  tile_flags (nullable; uint8 (B, ceil(S / q_block), ceil(T / k_tile)),
+ * block sizes from qlinear_prefill_attention_tiles) lets the kernel skip key tiles and mask loads:
+ *   0 = every mask entry of the tile <= -1e9 AND every query row of the block has an entry >= -1e6 somewhere (the tile's
+ *       probabilities are exactly 0 in fp32 for any fp16-range score): skipped;  2 = every entry == 0: no mask loads;  1 = otherwise.
+ * The caller derives them from the SAME mask (fused_ops.attention_tile_flags); wrong flags give wrong results, not faults.
+ * QL_ERR_UNSUPPORTED unless D == 128, H == 16 G and fp16 / bf16 (ChatGLM2's geometry): callers keep the GEMM route then. */
+int qlinear_prefill_attention_tiles(int64_t* q_block, int64_t* k_tile);
+int qlinear_prefill_attention(const void* Q, const void* Kcache, const void* Vcache, const float* mask, const uint8_t* tile_flags,
+                              void* Out, int64_t B, int64_t S, int64_t T, int64_t H, int64_t G, int64_t D, int64_t capacity,
+                              int64_t ldm, int dtype, void* stream);
 int qlinear_silu_mul(const void* In, void* Out, int64_t rows, int64_t hidden, int64_t ldin, int64_t ldo, int dtype,
                      void* stream);
 /* Quantising producers (round 3): the row a norm / activation kernel holds in registers is ALSO emitted as int8 + one fp32 scale

@@ -1,0 +1,140 @@
+"""qlinear_prefill_attention (one-launch many-position attention, csrc/prefill_attention.hip) against the reference's op
+sequence (chatglm_q/model.py:157-175): q / sqrt(d) rounded, q k^T rounded, + additive fp32 mask, fp32 softmax, cast, p v."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, G, D = 32, 2, 128
+
+
+def reference(q, k, v, mask, T):
+    """q (B, S, H*D), k / v (B, cap, G, D), mask (B, S, T) or None -> (B, S, H*D); fp32 GEMMs with the reference's roundings."""
+    B, S = q.shape[:2]
+    dt = q.dtype
+    qh = (q.view(B, S, G, H // G, D) / math.sqrt(D)).permute(0, 2, 3, 1, 4).float()          # B G Hg S D (rounded by the division)
+    kk = k[:, :T].permute(0, 2, 3, 1).float()                                               # B G D T
+    qk = torch.matmul(qh, kk[:, :, None]).to(dt).float()                                     # B G Hg S T
+    if mask is not None:
+        qk = qk + mask[:, None, None]
+    p = torch.softmax(qk, dim=-1).to(dt).float()
+    out = torch.matmul(p, v[:, :T].permute(0, 2, 1, 3)[:, :, None].float()).to(dt)           # B G Hg S D
+    return out.permute(0, 3, 1, 2, 4).reshape(B, S, H * D)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def causal_mask(B, S, T, first_row, pad_cols=None, dev="cuda"):
+    t = torch.arange(T, device=dev)
+    rows = torch.arange(first_row, first_row + S, device=dev)
+    blocked = (t[None, None, :] > rows[None, :, None]).expand(B, S, T).clone()
+    if pad_cols is not None:
+        blocked |= pad_cols[:, None, :T]
+    return blocked.float() * -1e10
+
+
+def make(B, S, T, cap, dtype, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, S, H * D, device="cuda", generator=g).to(dtype)
+    k = torch.randn(B, cap, G, D, device="cuda", generator=g).to(dtype)
+    v = torch.randn(B, cap, G, D, device="cuda", generator=g).to(dtype)
+    return q, k, v
+
+
+CASES = [
+    # B, S, T, cap, first_row (cache row of the chunk's first position)
+    (2, 256, 256, 256, 0),
+    (1, 128, 320, 384, 192),        # second chunk against a prefix; T not a multiple of 64
+    (2, 37, 42, 64, 5),             # ragged block of query rows
+    (1, 1024, 2048, 2048, 1024),    # config 5's second chunk of one sequence
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("use_flags", [True, False])
+def test_causal_chunks_match_reference_sequence(dtype, tol, case, use_flags):
+    from chatglm_q_amd import fused_ops as F_
+    B, S, T, cap, first = case
+    q, k, v = make(B, S, T, cap, dtype)
+    mask = causal_mask(B, S, T, first)
+    flags = F_.attention_tile_flags(mask) if use_flags else None
+    got = F_.prefill_attention(q, k, v, mask, flags, T, H, G, D)
+    want = reference(q, k, v, mask, T)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, want) < tol
+    # row-wise too: no single position may be off
+    per_row = ((got.float() - want.float()).norm(dim=-1) / want.float().norm(dim=-1).clamp_min(1e-6)).max()
+    assert float(per_row) < 4 * tol
+
+
+def test_tile_flags_of_a_causal_mask():
+    from chatglm_q_amd import fused_ops as F_
+    QB, KB = F_.prefill_attention_tiles()
+    mask = causal_mask(1, 256, 256, 0)
+    flags = F_.attention_tile_flags(mask)[0].cpu()
+    assert flags.shape == (256 // QB, 256 // KB)
+    for qb in range(flags.shape[0]):
+        for kt in range(flags.shape[1]):
+            lo_row, hi_row = qb * QB, qb * QB + QB - 1
+            if kt * KB > hi_row:
+                assert flags[qb, kt] == 0              # above the diagonal for every row of the block
+            elif kt * KB + KB - 1 <= lo_row:
+                assert flags[qb, kt] == 2              # fully visible
+            else:
+                assert flags[qb, kt] == 1
+
+
+@pytest.mark.parametrize("use_flags", [True, False])
+def test_left_padded_batch_including_all_blocked_rows(use_flags):
+    """Pad columns are blocked for every query (chatglm_q/model.py:297-318), so a pad position's own row has no visible key
+    at all: the reference's softmax of (-1e10, ..., -1e10) is the uniform average over all T keys, and so is this kernel's."""
+    from chatglm_q_amd import fused_ops as F_
+    B, S, T, cap = 4, 96, 96, 128
+    q, k, v = make(B, S, T, cap, torch.float16, seed=3)
+    pads = [0, 7, 33, 70]
+    pad_cols = torch.zeros(B, cap, dtype=torch.bool, device="cuda")
+    for b, n in enumerate(pads):
+        pad_cols[b, :n] = True
+    mask = causal_mask(B, S, T, 0, pad_cols)
+    flags = F_.attention_tile_flags(mask) if use_flags else None
+    got = F_.prefill_attention(q, k, v, mask, flags, T, H, G, D)
+    want = reference(q, k, v, mask, T)
+    assert rel_l2(got, want) < 1.5e-3
+    for b, n in enumerate(pads):
+        if n:
+            assert rel_l2(got[b, :n], want[b, :n]) < 1.5e-3          # the all-blocked rows themselves
+            uniform = v[b, :T].float().mean(dim=0).repeat_interleave(H // G, dim=0).reshape(-1)
+            assert rel_l2(got[b, 0], uniform) < 2e-3
+
+
+def test_no_mask_and_general_additive_mask():
+    from chatglm_q_amd import fused_ops as F_
+    B, S, T, cap = 1, 64, 200, 256
+    q, k, v = make(B, S, T, cap, torch.float16, seed=5)
+    got = F_.prefill_attention(q, k, v, None, None, T, H, G, D)
+    assert rel_l2(got, reference(q, k, v, None, T)) < 1.5e-3
+    # a soft (ALiBi-like) bias: finite values everywhere, nothing skippable, flags must all be 1 (or 2 where it is zero)
+    bias = -0.05 * (torch.arange(T, device="cuda")[None, None, :] - torch.arange(S, device="cuda")[None, :, None]).abs().float()
+    flags = F_.attention_tile_flags(bias)
+    assert int((flags == 0).sum()) == 0
+    got = F_.prefill_attention(q, k, v, bias, flags, T, H, G, D)
+    assert rel_l2(got, reference(q, k, v, bias, T)) < 1.5e-3
+
+
+def test_abi_rejects_other_geometries():
+    from chatglm_q_amd import _lib
+    lib = _lib.get_lib()
+    x = torch.zeros(1, 16, 8 * 64, device="cuda", dtype=torch.float16)
+    kc = torch.zeros(1, 16, 2, 64, device="cuda", dtype=torch.float16)
+    st = lib.qlinear_prefill_attention(x.data_ptr(), kc.data_ptr(), kc.data_ptr(), None, None, x.data_ptr(), 1, 16, 16, 8, 2, 64, 16, 0,
+                                       _lib.dtype_code(torch.float16), _lib.stream_ptr(x.device))
+    assert st == -7                                                   # QL_ERR_UNSUPPORTED: callers keep the GEMM route
+    st = lib.qlinear_prefill_attention(None, kc.data_ptr(), kc.data_ptr(), None, None, x.data_ptr(), 1, 16, 16, 32, 2, 128, 16, 0,
+                                       _lib.dtype_code(torch.float16), _lib.stream_ptr(x.device))
+    assert st == -1
