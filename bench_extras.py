@@ -346,11 +346,11 @@ def e2e_generate(torch, device):
     out["resident_bytes"] = _resident_bytes(model)
     out["drop_in_reference_graph"] = drop_in_generate(torch, model, prompt)
     out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, greedy, fp16, synthetic weights"
-    # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 1024 positions (M = 4096 rows per forward: the 256 x 256-tile
-    # GEMM takes o_proj / w_in / w_out there; tools/prefill_chunks.py, round 3: 0.154 / 0.128 / 0.120 / 0.131 s for chunks of 256 / 512 /
-    # 1024 / 2048)
+    # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 2048 positions (M = 8192 rows per forward: every projection on
+    # the 256 x 256-tile GEMM; attention = one launch per layer, csrc/prefill_attention.hip; tools/prefill_chunks.py, round 3:
+    # 0.127 / 0.107 / 0.095 / 0.092 s for chunks of 256 / 512 / 1024 / 2048 - with the GEMM-route attention 0.153 / 0.131 / 0.122 / 0.130)
     from chatglm_q_amd.decoder import DecodeSession
-    B, S, CH = 4, 2048, 1024
+    B, S, CH = 4, 2048, int(os.environ.get("PREFILL_CHUNK", 2048))
     ids = torch.randint(0, cfg.vocab_size, (B, S), device=device)
     lin_flops = 2.0 * B * S * (4096 * 4608 + 4096 * 4096 + 4096 * 27392 + 13696 * 4096) * 28
     sess = DecodeSession(model, B, S, use_graph=False)
@@ -364,9 +364,9 @@ def e2e_generate(torch, device):
     out["chunked_prefill_seq2048_batch4"] = {
         "chunk": CH, "seconds": round(dt, 4), "tokens_per_s": round(B * S / dt, 1),
         "linear_TFLOPs_if_all_time_were_linear": round(lin_flops / dt / 1e12, 1),
-        "note": "whole forward incl. attention (reference op sequence: torch batched GEMMs on strided cache views, keys limited "
-                "to the filled prefix, mask add + fp32 softmax + cast in one HIP launch) and norms; lm_head for the last "
-                "position only; torch's fused SDPA measured slower here (0.236 s)"}
+        "note": "whole forward incl. attention (qlinear_prefill_attention: one launch per layer on the matrix cores, scores never "
+                "written; QLINEAR_PREFILL_ATTENTION=0 = the reference op sequence as two batched GEMMs + one mask / softmax launch, "
+                "0.122 s) and norms; lm_head for the last position only"}
     # batched greedy decode (graph-replayed step, 32-token prompts): aggregate tokens per second
     bd = {}
     for Bd in (2, 4, 8, 32):

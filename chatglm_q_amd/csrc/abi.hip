@@ -209,6 +209,9 @@ int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* 
         ldc < N / 2)
         return QL_ERR_BAD_SHAPE;
     if (!aligned(tiled, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
+    // prefill row counts: the 256 x 256-tile GEMM with the same epilogue (8-byte output chunks)
+    if (N % 32 == 0 && w4_gemm256_supported(M, N, K, lda, A, 2) && ldc % 4 == 0 && aligned(C, 8))
+        return w4_gemm256_gated(dtype, A, tiled, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
     // the epilogue lives in the few-row kernel without K slabs (wide first MLP projections, 3..32 rows)
     if (!w4_rows_use_gemm(M, N, K) || !w4_fewrow_supported(M, N, K) || w4_fewrow_workspace_bytes(M, N, K) != 0 || N % 32 != 0)
         return QL_ERR_UNSUPPORTED;

@@ -163,6 +163,8 @@ bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const vo
 bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                int64_t ldc, hipStream_t st);
+int w4_gemm256_gated(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldc, hipStream_t st);   // gate-interleaved copy, SiLU * gate epilogue: C (M, N / 2)
 int w8_gemm256(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldc, hipStream_t st);   // int8 per-channel weights (tile-major copy) through the same kernel
 // w8a8_gemm256.hip: int8 activations x tile-major int8 weights, many rows, 256 x 256 tiles, both operands by LDS-DMA

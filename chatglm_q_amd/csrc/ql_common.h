@@ -250,6 +250,45 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {   // rounds each v
     return r;
 }
 
+// The same epilogue with SiLU * gate (chatglm_q/model.py:200-201) on GATE-INTERLEAVED columns: column quad t of the weight copy is
+// (h[2t], h[2t+1], gate[2t], gate[2t+1]), so an 8-column row chunk of the tile holds two complete quads and becomes 4 outputs -
+// out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias as a second rounded operation) - stored as ONE 8-byte
+// chunk of C, which has N / 2 columns.  Requires N % 8 == 0, ldc % 4 == 0 and 8-byte aligned C rows.
+template <typename T, typename F>
+__device__ __forceinline__ void store_tile_32x32_gated(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
+                                                       const T* __restrict__ bias, int lane, F val) {
+    static_assert(sizeof(T) == 2, "16-bit outputs");
+    const int j = lane & 31, kb = lane >> 5;
+    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
+        float y = Act<T>::round(val(i));
+        if (bias) y = y + bj;
+        Act<T>::store(lds_wave + row * 32 + j, y);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h, row = q >> 2, c8 = (q & 3) * 8;
+        const int m = m_base + row, n = n0 + c8;
+        if (m >= M || n >= N) continue;
+        float y[8];
+        unpack8<T>(*reinterpret_cast<const u32x4*>(lds_wave + row * 32 + c8), y);
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float hv = y[4 * t + i], gv = y[4 * t + 2 + i];
+                o[2 * t + i] = Act<T>::round(hv / (1.0f + __expf(-hv))) * gv;
+            }
+        *reinterpret_cast<u32x2*>(C + (int64_t)m * ldc + (n >> 1)) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace ql

@@ -102,7 +102,8 @@ __device__ __forceinline__ u32x4 w8_dequant_natural(u32 w0, u32 w1, float s) {
 
 // W8 = false: int4g32, Wt / Sp = part 2 of the derived layout (units + scales, [column tile][K tile][lane]).
 // W8 = true: int8 per channel, Wt = the tile-major copy ([column tile][K tile][half][lane][16 B]: two units per lane and K tile), Sp = S[n].
-template <typename T, bool W8 = false>
+// GATE: the weight copy is gate-interleaved (a first MLP projection) and the epilogue applies SiLU * gate: C has N / 2 columns.
+template <typename T, bool W8 = false, bool GATE = false>
 __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                          int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
                                                          const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
@@ -366,13 +367,16 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 
     // ---- epilogue: rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global (ql_common.h) -------------
     const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
-    if ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+    if (GATE || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)) {   // GATE: 8-byte chunks, alignment checked by the ABI
         T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                if constexpr (GATE)
+                    store_tile_32x32_gated<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else
+                    store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
 #ifdef QL_G256_STAMPS
         if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_g256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 1] = QL_G256_T() - t_loop1;
 #endif
@@ -393,14 +397,14 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     }
 }
 
-template <typename T>
+template <typename T, bool GATE = false>
 static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
                           hipStream_t st) {
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const u32x4* Wt = (const u32x4*)tiled;
     const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, false, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kG256Lds) == hipSuccess;
     }();
     (void)attr_set;
@@ -409,7 +413,7 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     static const int sy_env = [] { const char* e = getenv("QLINEAR_GEMM_SY"); return e ? atoi(e) : 0; }();            // tuning sweeps
     const int sy = sy_env > 0 ? sy_env : 4;            // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
-    w4_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
+    w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc);
     return finish_launch();
@@ -470,6 +474,16 @@ int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, vo
     switch (dtype) {
     case QL_DTYPE_F16: return launch_gemm256<f16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
     case QL_DTYPE_BF16: return launch_gemm256<__bf16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// gate-interleaved copy of a first MLP projection, SiLU * gate in the epilogue: C is (M, N / 2)
+int w4_gemm256_gated(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256<f16, true>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_gemm256<__bf16, true>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

@@ -33,6 +33,12 @@ MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False"
 MLP_ENGINE = os.environ.get("QLINEAR_MLP_ENGINE", "0") not in ("0", "false", "False")
 # int8-activation modules (act_quant): RMSNorm / SiLU * gate emit the int8 rows + scales themselves (quantising producers)
 PREQUANT = os.environ.get("QLINEAR_PREQUANT", "1") not in ("0", "false", "False")
+# many-position attention (prefill chunks) as one launch per layer (qlinear_prefill_attention) instead of two batched GEMMs around
+# the masked-softmax launch; QLINEAR_PREFILL_ATTENTION=0 keeps the GEMM route (A/B measurements)
+PREFILL_ATTENTION = os.environ.get("QLINEAR_PREFILL_ATTENTION", "1") not in ("0", "false", "False")
+# prefill row counts: w_in on its gate-interleaved copy with SiLU * gate in the 256 x 256-tile GEMM's epilogue (no (rows, 2 * hidden)
+# intermediate, no silu_mul launch); QLINEAR_GATED_PREFILL=0 keeps the two launches
+GATED_PREFILL = os.environ.get("QLINEAR_GATED_PREFILL", "1") not in ("0", "false", "False")
 
 
 @dataclass
@@ -275,6 +281,15 @@ class ChatGLM2Model(nn.Module):
             # (qlinear_rmsnorm_quant_i8 / qlinear_silu_mul_quant_i8) - no quantiser launch, no 16-bit copy of the row
             return (PREQUANT and isinstance(mod, Q8) and mod.act_quant is True and mod.in_features % 16 == 0
                     and h.dtype in (torch.float16, torch.bfloat16) and mod.weight_scale.dtype == h.dtype)
+        # many-position attention in one launch per layer for ChatGLM2's head geometry; the tile flags (which key tiles a block of
+        # query rows can skip / needs no mask for) come from one pass over the mask, shared by all layers
+        one_launch = (S > 1 and PREFILL_ATTENTION and F_.prefill_attention_supported(h.dtype, H, G, D) and mask.dtype == torch.float32
+                      and mask.dim() == 3 and cache.k[0].is_contiguous())
+        if one_launch:
+            T_kv = mask.shape[-1]
+            if mask.shape[0] != B:
+                mask = mask.expand(B, S, T_kv).contiguous()
+            tile_flags = F_.attention_tile_flags(mask)
         delta = None                                   # pending residual contribution of the previous sub-block
         for i, layer in enumerate(self.layers):
             qkv = self._rows_fused(layer.attn.qkv_proj, h, delta, layer.attn_ln) if few else None
@@ -296,7 +311,10 @@ class ChatGLM2Model(nn.Module):
             else:
                 q = F_.rope_kv_write(qkv, self.freqs_cis_cache, position_ids, write_index,
                                      cache.k[i], cache.v[i], H, G, D)
-                att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
+                if one_launch:                         # many positions: scores never leave the chip (csrc/prefill_attention.hip)
+                    att = F_.prefill_attention(q.view(B, S, H * D), cache.k[i], cache.v[i], mask, tile_flags, T_kv, H, G, D)
+                else:
+                    att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
             o = layer.attn.o_proj(att)
             y = self._rows_fused(layer.ffn.w_in, h, o, layer.ffn_ln, gate_hidden=layer.ffn.hidden_dim) if few else None
             if y is not None:                          # h += o, RMSNorm, w_in and SiLU * gate: one launch
@@ -307,7 +325,7 @@ class ChatGLM2Model(nn.Module):
                     y, u = None, layer.ffn.w_in.forward_quantized(a_q, a_s).view(B, S, -1)
                 else:
                     h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
-                    y = self._gated_w_in(layer.ffn, x) if S == 1 and 2 <= B <= 32 else None   # SiLU * gate in w_in's epilogue
+                    y = self._gated_w_in(layer.ffn, x) if (S == 1 and 2 <= B <= 32) or (GATED_PREFILL and B * S >= 1024) else None   # SiLU * gate in w_in's epilogue
                     u = layer.ffn.w_in(x) if y is None else None
                 if y is None and prequant(layer.ffn.w_out):
                     a_q, a_s, _ = F_.silu_mul_quant(u, layer.ffn.hidden_dim)

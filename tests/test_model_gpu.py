@@ -316,6 +316,32 @@ def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatc
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [4096, 2048 + 200])
+def test_gemm256_gate_epilogue_equals_separate_ops(dtype, bias, M):
+    """Prefill row counts: qlinear_w4g32_fwd_tiled_gated on the 256 x 256-tile GEMM (SiLU * gate in its epilogue, output
+    (M, hidden)) against the same GEMM followed by silu_mul - same sums, same rounding sequence, bit for bit
+    (chatglm_q/model.py:199-201)."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(11)
+    K, hidden = 4096, 13696
+    layer = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(1, M, K, device=DEV, generator=g).to(dtype)
+    gp, gb = layer.gated_tiled(hidden)
+    got = H4.w4_forward_gated(x, gp, 2 * hidden, gb)
+    with torch.no_grad():
+        want = F_.silu_mul(layer(x), hidden)                 # the module takes the same 256 x 256-tile kernel at these row counts
+    assert got is not None and got.shape == (1, M, hidden)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("M", [3, 8, 32])
 def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     """qlinear_w4g32_fwd_packed_gated (few rows, SiLU * gate in the MFMA kernel's epilogue) against the projection
