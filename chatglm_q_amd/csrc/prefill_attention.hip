@@ -26,6 +26,7 @@
 // relative error, not the same bits); the exp-sum uses the unrounded values.
 #include "launch.h"
 #include "ql_common.h"
+#include <type_traits>
 
 namespace ql {
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
     const int b = bg / G, g = bg - b * G;
     const int pos0 = qblk * QB + wv * R;
 
+    const float rcp_d = 1.0f / sqrt_d;
     // the wave's query rows: B operand of the first product, lane (li, q) = head li, d = 32 j + 8 q .. + 7
     u32x4 qf[R][4];
 #pragma unroll
@@ -84,8 +86,14 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
         for (int j = 0; j < 4; ++j) {
             float x[8];
             unpack8<T>(*reinterpret_cast<const u32x4*>(qrow + 32 * j + 8 * q), x);
+            // x / sqrt(d) as one Newton-corrected multiply (the IEEE division sequence is 12 instructions x 64 values per lane): the
+            // corrected quotient is the correctly rounded one except when it lands within an fp32 ulp of a tie, and the result is
+            // rounded to T right after
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = x[e] / sqrt_d;
+            for (int e = 0; e < 8; ++e) {
+                const float q0 = x[e] * rcp_d;
+                x[e] = __builtin_fmaf(__builtin_fmaf(-q0, sqrt_d, x[e]), rcp_d, q0);
+            }
             qf[r][j] = pack8<T>(x);
         }
     }
@@ -128,52 +136,44 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
         for (int dt = 0; dt < 8; ++dt) o[r][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    int kt = next_tile(-1);
-    if (kt < nkt) {
-        load_tile(kt);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    while (kt < nkt) {
-        const int nk = next_tile(kt);
-        if (nk < nkt) load_tile(nk);                          // in flight under this tile's arithmetic
-
+    auto tile_body = [&](auto general_tag, const int t0, const int fl, const int buf) {
+        constexpr bool GEN = decltype(general_tag)::value;
         const unsigned char* kb = kimg + buf * kPfKeys * KP;
         const unsigned char* vb = vimg + buf * kPfKeys * VP;
-        const int t0 = kt * kPfKeys;
-        const int fl = !mask ? 2 : frow ? (int)frow[kt] : 1;   // no mask at all: every tile is 'all zero'
-        const bool ragged = t0 + kPfKeys > Tkv;              // the last tile of a T that is not a multiple of 64
-
-        float mv[R][4][4];
-        if (fl == 1) {                                        // block-uniform
+        float mv[GEN ? R : 1][4][4];
+        if constexpr (GEN) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int pos = pos0 + r < S ? pos0 + r : S - 1;
-                const float* mrow = mask + ((int64_t)b * S + pos) * ldm;
+                // unconditional loads (a load under a per-element condition becomes a branch per element): tiles that only need
+                // the range check read in-bounds bytes of the key cache and select 0
+                const float* mrow = fl == 1 ? mask + ((int64_t)b * S + pos) * ldm : reinterpret_cast<const float*>(kbase);
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int key = t0 + 16 * pt + 4 * q + e;
-                        mv[r][pt][e] = mrow[key < Tkv ? key : Tkv - 1];
+                        const float lv = mrow[key < Tkv ? key : Tkv - 1];
+                        mv[r][pt][e] = fl == 1 ? lv : 0.f;
                     }
             }
         }
 
-        // S^T = K Q^T: lane (li, q) ends with the scores of head li against keys t0 + 16 pt + 4 q + e
+        // S^T = K Q^T: lane (li, q) ends with the scores of head li against keys t0 + 16 pt + 4 q + e.  d chunk j outermost:
+        // consecutive MFMAs go to 8 different accumulators (a dependent 16 x 16 x 32 pair costs the pipe's full latency)
         f32x4 s[R][4];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
             for (int r = 0; r < R; ++r) s[r][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
                 const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (16 * pt + li) * KP + 64 * j + 16 * q);
 #pragma unroll
                 for (int r = 0; r < R; ++r) s[r][pt] = PfMma<T>::mma(kf, qf[r][j], s[r][pt]);
             }
-        }
 
         u32x2 pf[R][4];
 #pragma unroll
@@ -184,8 +184,10 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = Act<T>::round(s[r][pt][e]);
-                    if (fl == 1) x += mv[r][pt][e];
-                    if (ragged && t0 + 16 * pt + 4 * q + e >= Tkv) x = -INFINITY;
+                    if constexpr (GEN) {
+                        x += mv[r][pt][e];
+                        if (t0 + 16 * pt + 4 * q + e >= Tkv) x = -INFINITY;
+                    }
                     s[r][pt][e] = x;
                     mx = fmaxf(mx, x);
                 }
@@ -231,6 +233,26 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
                     o[r][dt] = PfMma<T>::mma(a, u32x4{pf[r][2 * c][0], pf[r][2 * c][1], pf[r][2 * c + 1][0], pf[r][2 * c + 1][1]}, o[r][dt]);
             }
         }
+    };
+
+    int kt = next_tile(-1);
+    if (kt < nkt) {
+        load_tile(kt);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (kt < nkt) {
+        const int nk = next_tile(kt);
+        if (nk < nkt) load_tile(nk);                          // in flight under this tile's arithmetic
+
+        const int t0 = kt * kPfKeys;
+        const int fl = !mask ? 2 : frow ? (int)frow[kt] : 1;   // no mask at all: every tile is 'all zero'
+        const bool ragged = t0 + kPfKeys > Tkv;              // the last tile of a T that is not a multiple of 64
+        // two copies of the tile body: the general one (mask loads, range checks) runs on the few tiles that need it - left to one
+        // body the compiler if-converts both into selects on every score of every tile
+        if (fl == 1 || ragged) tile_body(std::true_type{}, t0, fl, buf);
+        else tile_body(std::false_type{}, t0, fl, buf);
 
         if (nk < nkt) store_tile(buf ^ 1);                    // nobody reads that buffer: its readers passed the last barrier
         __syncthreads();
