@@ -28,6 +28,16 @@
 #include "ql_common.h"
 #include <type_traits>
 
+// developer switches (tools/ab/build_pf_variant.sh; always 0 / 8 in the library): QL_PF_ABLATE bits strip parts of the tile body to
+// attribute time (results wrong): 1 no softmax arithmetic, 2 no second product, 4 no first product, 8 no K / V staging in the loop,
+// 16 no barrier in the loop.  QL_PF_WAVES: waves per workgroup (8 or 4).
+#ifndef QL_PF_ABLATE
+#define QL_PF_ABLATE 0
+#endif
+#ifndef QL_PF_WAVES
+#define QL_PF_WAVES 8
+#endif
+
 namespace ql {
 
 typedef short pf_s16x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +60,8 @@ constexpr int kPfKeys = 64;                                   // keys per tile
 constexpr int kPfKP = 272;                                    // bytes per key row in LDS (b128 fragment reads conflict-free)
 constexpr int kPfVP = 288;                                    // bytes per value row in LDS (tr reads conflict-free)
 constexpr int kPfR = 2;                                       // query positions per wave
-constexpr int kPfLds = 2 * kPfKeys * (kPfKP + kPfVP);         // two buffers of a K and a V tile: 71 680 bytes
+constexpr int kPfMaxTiles = 2048;                             // key tiles per row of flags kept in LDS (T <= 131 072)
+constexpr int kPfLds = kPfKeys * (2 * kPfKP + 3 * kPfVP) + kPfMaxTiles;   // two K tiles, three V tiles, the flags: 92 160 bytes
 
 template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kc,
@@ -63,7 +74,8 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
     constexpr int CH = kPfKeys * 16 / NTH;                    // 16-byte chunks of a K (and of a V) tile staged per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char pf_smem[];
     unsigned char* const kimg = pf_smem;                      // [2][64][KP]
-    unsigned char* const vimg = pf_smem + 2 * kPfKeys * KP;   // [2][64][VP]
+    unsigned char* const vimg = pf_smem + 2 * kPfKeys * KP;   // [3][64][VP]
+    uint8_t* const fimg = pf_smem + kPfKeys * (2 * KP + 3 * VP);   // [kPfMaxTiles] this block's tile flags
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, q = lane >> 4;
 
     // Workgroups go to the 8 XCDs round robin; the blocks of one (sequence, group) share its keys and values, so they are
@@ -97,10 +109,18 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
             qf[r][j] = pack8<T>(x);
         }
     }
-    const uint8_t* frow = flags ? flags + ((int64_t)b * nqb + qblk) * nkt : nullptr;
+    // The block's row of tile flags is copied into LDS once: read from global inside the loop, every look-up is a vector load whose
+    // wait (vmcnt(0)) also drains the K / V staging loads in flight - the load latency of every tile would be exposed
+    const bool have_flags = flags != nullptr;
+    if (have_flags) {
+        const uint8_t* frow_g = flags + ((int64_t)b * nqb + qblk) * nkt;
+        for (int i = tid; i < nkt; i += NTH) fimg[i] = frow_g[i];
+    }
+    __syncthreads();
+    const uint8_t* frow = fimg;
     auto next_tile = [&](int kt) {
         ++kt;
-        while (frow && kt < nkt && frow[kt] == 0) ++kt;
+        while (have_flags && kt < nkt && frow[kt] == 0) ++kt;
         return kt;
     };
 
@@ -117,29 +137,52 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
             vst[i] = *reinterpret_cast<const u32x4*>(vbase + t * pitch + 8 * col);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int kbuf, int vbuf) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = tid + NTH * i, row = c >> 4, col = c & 15;
-            *reinterpret_cast<u32x4*>(kimg + (buf * kPfKeys + row) * KP + 16 * col) = kst[i];
-            *reinterpret_cast<u32x4*>(vimg + (buf * kPfKeys + row) * VP + 16 * col) = vst[i];
+            *reinterpret_cast<u32x4*>(kimg + (kbuf * kPfKeys + row) * KP + 16 * col) = kst[i];
+            *reinterpret_cast<u32x4*>(vimg + (vbuf * kPfKeys + row) * VP + 16 * col) = vst[i];
         }
     };
 
-    float m[R], l[R];                                         // running maximum (same in the 4 lanes of a head), this lane's exp-sum
+    float m[R];                                               // running maximum (the same in the 4 lanes of a head)
+    f32x4 lacc[R];                                            // exp-sum of head li (four copies), accumulated by the matrix pipe
+    const u32 one2 = pack2<T>(1.0f, 1.0f);
+    const u32x4 ones = u32x4{one2, one2, one2, one2};
     f32x4 o[R][8];                                            // O^T: lane (li, q) = head li, d = 16 dt + 4 q + e
+    f32x4 s[R][4];                                            // S^T of the tile between the first product and its softmax
+    u32x4 pb[R][2];                                           // exp(S^T - max) as the B operands of the second product's two 32-key steps
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         m[r] = -INFINITY;
-        l[r] = 0.f;
+        lacc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) o[r][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    auto tile_body = [&](auto general_tag, const int t0, const int fl, const int buf) {
+    // S^T = K Q^T: lane (li, q) ends with the scores of head li against keys 16 pt + 4 q + e of the tile.  d chunk j outermost:
+    // consecutive MFMAs go to 8 different accumulators (a dependent 16 x 16 x 32 pair costs the pipe's full latency)
+    auto first_product = [&](const int kbuf) {
+        const unsigned char* kb = kimg + kbuf * kPfKeys * KP;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < ((QL_PF_ABLATE & 4) ? 0 : 4); ++j)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (16 * pt + li) * KP + 64 * j + 16 * q);
+#pragma unroll
+                for (int r = 0; r < R; ++r) s[r][pt] = PfMma<T>::mma(kf, qf[r][j], s[r][pt]);
+            }
+    };
+
+    // mask, running maximum, exponentials (rounded to T into pb), exp-sum, rescale of O.  Two copies: the general one (mask loads,
+    // range checks) runs on the few tiles that need it - left to one body the compiler if-converts both into selects on every score
+    auto softmax = [&](auto general_tag, const int t0, const int fl) {
         constexpr bool GEN = decltype(general_tag)::value;
-        const unsigned char* kb = kimg + buf * kPfKeys * KP;
-        const unsigned char* vb = vimg + buf * kPfKeys * VP;
         float mv[GEN ? R : 1][4][4];
         if constexpr (GEN) {
 #pragma unroll
@@ -158,67 +201,87 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
                     }
             }
         }
-
-        // S^T = K Q^T: lane (li, q) ends with the scores of head li against keys t0 + 16 pt + 4 q + e.  d chunk j outermost:
-        // consecutive MFMAs go to 8 different accumulators (a dependent 16 x 16 x 32 pair costs the pipe's full latency)
-        f32x4 s[R][4];
+        if constexpr ((QL_PF_ABLATE & 1) != 0) {
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int r = 0; r < R; ++r) s[r][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < 2; ++c)
+                    pb[r][c] = u32x4{pack2<T>(s[r][2 * c][0], s[r][2 * c][1]), pack2<T>(s[r][2 * c][2], s[r][2 * c][3]),
+                                     pack2<T>(s[r][2 * c + 1][0], s[r][2 * c + 1][1]), pack2<T>(s[r][2 * c + 1][2], s[r][2 * c + 1][3])};
+        }
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        constexpr float kLog2e = 1.4426950408889634f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < ((QL_PF_ABLATE & 1) ? 0 : R); ++r) {
+            // scores rounded to T two at a time (v_cvt_pk_*); they stay packed: the arithmetic below reads the halves in place
+            T2 xr[4][2];
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + (16 * pt + li) * KP + 64 * j + 16 * q);
-#pragma unroll
-                for (int r = 0; r < R; ++r) s[r][pt] = PfMma<T>::mma(kf, qf[r][j], s[r][pt]);
+                xr[pt][0] = __builtin_convertvector(F2{s[r][pt][0], s[r][pt][1]}, T2);
+                xr[pt][1] = __builtin_convertvector(F2{s[r][pt][2], s[r][pt][3]}, T2);
             }
-
-        u32x2 pf[R][4];
+            float mx;
+            if constexpr (GEN) {
+                mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float mx = -INFINITY;
+                for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = Act<T>::round(s[r][pt][e]);
-                    if constexpr (GEN) {
-                        x += mv[r][pt][e];
+                    for (int e = 0; e < 4; ++e) {
+                        float x = (float)xr[pt][e >> 1][e & 1] + mv[r][pt][e];
                         if (t0 + 16 * pt + 4 * q + e >= Tkv) x = -INFINITY;
+                        s[r][pt][e] = x;
+                        mx = fmaxf(mx, x);
                     }
-                    s[r][pt][e] = x;
-                    mx = fmaxf(mx, x);
-                }
+            } else if constexpr (Act<T>::code == QL_DTYPE_F16) {
+                T2 pm = xr[0][0];                             // the rounded scores are exact fp16 values: packed maximum
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) pm = __builtin_elementwise_max(pm, xr[pt][h]);
+                mx = fmaxf((float)pm[0], (float)pm[1]);
+            } else {
+                mx = -INFINITY;
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, (float)xr[pt][e >> 1][e & 1]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m[r], mx);                 // finite: key t0 is in range and its entry is finite
             const float alpha = __expf(m[r] - mn);            // first tile: exp(-inf) = 0
             m[r] = mn;
-            float ls = 0.f;
+            const float mnl = mn * kLog2e;
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 float ev[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ev[e] = __expf(s[r][pt][e] - mn);
-                    ls += ev[e];
+                    if constexpr (GEN)                        // masked values reach -1e10: the difference first, exactly
+                        ev[e] = __builtin_amdgcn_exp2f((s[r][pt][e] - mn) * kLog2e);
+                    else                                      // |x|, |mn| <= 65504: one fma, error <= 6e-8 |mn| in the exponent
+                        ev[e] = __builtin_amdgcn_exp2f(__builtin_fmaf((float)xr[pt][e >> 1][e & 1], kLog2e, -mnl));
                 }
-                pf[r][pt] = u32x2{pack2<T>(ev[0], ev[1]), pack2<T>(ev[2], ev[3])};
+                pb[r][pt >> 1][2 * (pt & 1)] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[0], ev[1]}, T2));
+                pb[r][pt >> 1][2 * (pt & 1) + 1] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[2], ev[3]}, T2));
             }
-            l[r] = __builtin_fmaf(l[r], alpha, ls);
             if (!__all(alpha == 1.0f)) {                      // wave-uniform: the maximum settles after the first tiles
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lacc[r][e] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[r][dt][e] *= alpha;
             }
         }
+    };
 
-        // O^T += V^T P^T, 32 keys per MFMA step
+    // O^T += V^T P^T, 32 keys per MFMA step
+    auto second_product = [&](const int vbuf) {
+        const unsigned char* vb = vimg + vbuf * kPfKeys * VP;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < ((QL_PF_ABLATE & 2) ? 0 : 2); ++c) {
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 const unsigned char* p0 = vb + (32 * c + 4 * q + (li >> 2)) * VP + 2 * (16 * dt + 4 * (li & 3));
@@ -226,45 +289,73 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
                     (pf_s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p0)));
                 const pf_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (pf_s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p0 + 16 * VP)));
-                const u32x2 w0 = __builtin_bit_cast(u32x2, a0), w1 = __builtin_bit_cast(u32x2, a1);
-                const u32x4 a = u32x4{w0[0], w0[1], w1[0], w1[1]};
+                typedef short pf_s16x8 __attribute__((ext_vector_type(8)));
+                const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    o[r][dt] = PfMma<T>::mma(a, u32x4{pf[r][2 * c][0], pf[r][2 * c][1], pf[r][2 * c + 1][0], pf[r][2 * c + 1][1]}, o[r][dt]);
+                for (int r = 0; r < R; ++r) o[r][dt] = PfMma<T>::mma(a, pb[r][c], o[r][dt]);
             }
+            // the exp-sum on the matrix pipe too: an all-ones A operand gives every lane of head li the sum over the step's 32 keys
+            // (of the ROUNDED probabilities - what the product above multiplies), with no cross-lane reduction and no VALU adds
+#pragma unroll
+            for (int r = 0; r < R; ++r) lacc[r] = PfMma<T>::mma(ones, pb[r][c], lacc[r]);
+        }
+        if constexpr ((QL_PF_ABLATE & 2) != 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) o[r][c][0] += __builtin_bit_cast(float, pb[r][c][0] ^ pb[r][c][1] ^ pb[r][c][2] ^ pb[r][c][3]);
         }
     };
 
-    int kt = next_tile(-1);
-    if (kt < nkt) {
-        load_tile(kt);
-        store_tile(0);
+    // Ping-pong over time slots (one block barrier per slot): a tile is two slots of work for a wave - X = the second product of
+    // the PREVIOUS tile + the first product of this one (matrix pipe), Y = this tile's softmax (VALU) - and the waves w and w + 4,
+    // which share a SIMD, run one slot apart: while one is in X the other is in Y.  Group A (waves 0..3) runs X(i) in slot 2i and
+    // Y(i) in slot 2i + 1, group B one slot later.  Tile i + 1 is requested at the start of slot 2i and stored at the end of slot
+    // 2i + 1: its K buffer (two of them) was last read in slot 2i - 1 (B's X(i - 1)), its V buffer (three) in slot 2i - 1 (B's
+    // second product of tile i - 2); the first reader is A in slot 2i + 2, behind the slot's barrier.
+    int NT = 0;                                               // tiles this block processes (block-uniform)
+    for (int kt = next_tile(-1); kt < nkt; kt = next_tile(kt)) ++NT;
+    const int grp = wv >= NWV / 2 ? 1 : 0;
+    int kt_stage = next_tile(-1), ord_stage = 0;
+    if (NT > 0) {
+        load_tile(kt_stage);
+        store_tile(0, 0);
+        kt_stage = next_tile(kt_stage);
+        ord_stage = 1;
     }
     __syncthreads();
-    int buf = 0;
-    while (kt < nkt) {
-        const int nk = next_tile(kt);
-        if (nk < nkt) load_tile(nk);                          // in flight under this tile's arithmetic
-
-        const int t0 = kt * kPfKeys;
-        const int fl = !mask ? 2 : frow ? (int)frow[kt] : 1;   // no mask at all: every tile is 'all zero'
-        const bool ragged = t0 + kPfKeys > Tkv;              // the last tile of a T that is not a multiple of 64
-        // two copies of the tile body: the general one (mask loads, range checks) runs on the few tiles that need it - left to one
-        // body the compiler if-converts both into selects on every score of every tile
-        if (fl == 1 || ragged) tile_body(std::true_type{}, t0, fl, buf);
-        else tile_body(std::false_type{}, t0, fl, buf);
-
-        if (nk < nkt) store_tile(buf ^ 1);                    // nobody reads that buffer: its readers passed the last barrier
-        __syncthreads();
-        kt = nk;
-        buf ^= 1;
+    int kt_x = next_tile(-1), kt_soft = 0;
+    for (int p = 0; p < 2 * NT + 2; ++p) {
+        const bool staging = ord_stage < NT && !(QL_PF_ABLATE & 8);
+        if (!(p & 1) && staging) load_tile(kt_stage);         // in flight under two slots of arithmetic
+        const int pp = p - grp;
+        if (pp >= 0 && pp <= 2 * NT) {
+            const int ii = pp >> 1;
+            if (!(pp & 1)) {
+                if (ii > 0) second_product((ii - 1) % 3);
+                if (ii < NT) {
+                    first_product(ii & 1);
+                    kt_soft = kt_x;
+                    kt_x = next_tile(kt_x);
+                }
+            } else if (ii < NT) {
+                const int t0 = kt_soft * kPfKeys;
+                const int fl = !mask ? 2 : have_flags ? (int)frow[kt_soft] : 1;   // no mask at all: every tile is 'all zero'
+                if (fl == 1 || t0 + kPfKeys > Tkv) softmax(std::true_type{}, t0, fl);
+                else softmax(std::false_type{}, t0, fl);
+            }
+        }
+        if ((p & 1) && ord_stage < NT) {
+            if (!(QL_PF_ABLATE & 8)) store_tile(ord_stage & 1, ord_stage % 3);
+            kt_stage = next_tile(kt_stage);
+            ++ord_stage;
+        }
+        if (!(QL_PF_ABLATE & 16)) __syncthreads();
     }
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float lt = l[r] + __shfl_xor(l[r], 16);
-        lt += __shfl_xor(lt, 32);
-        const float inv = 1.0f / lt;
+        const float inv = 1.0f / lacc[r][0];
         if (pos0 + r < S) {
             T* dst = Out + (((int64_t)b * S + pos0 + r) * H + g * HP + li) * D + 4 * q;
 #pragma unroll
@@ -276,15 +367,16 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
 }
 
 void prefill_attention_tiles(int64_t* q_block, int64_t* k_tile) {
-    *q_block = kPfR * 8;
+    *q_block = kPfR * QL_PF_WAVES;
     *k_tile = kPfKeys;
 }
 
 template <typename T>
 static int launch_prefill_attention(const void* Q, const void* Kc, const void* Vc, const float* mask, const uint8_t* flags, void* Out,
                                     int64_t B, int64_t S, int64_t Tkv, int64_t H, int64_t G, int64_t cap, int64_t ldm, hipStream_t st) {
-    constexpr int NWV = 8, QB = kPfR * NWV;
+    constexpr int NWV = QL_PF_WAVES, QB = kPfR * NWV;
     const int nqb = (int)((S + QB - 1) / QB), nkt = (int)((Tkv + kPfKeys - 1) / kPfKeys);
+    if (nkt > kPfMaxTiles) return QL_ERR_UNSUPPORTED;
     static bool attr_set = false;                             // > 64 KB of dynamic LDS needs the opt-in, once per process
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attention_kernel<T, NWV>),
