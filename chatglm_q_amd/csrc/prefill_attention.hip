@@ -38,6 +38,15 @@
 #define QL_PF_WAVES 8
 #endif
 
+// QL_PF_STAMPS (developer build): workgroup 0's waves stamp s_memtime (shader-clock ticks) at the start of every slot, after its
+// arithmetic, after its staging stores and behind its barrier - tools/pf_timeline.py prints where a slot's time goes
+#ifdef QL_PF_STAMPS
+__device__ unsigned long long ql_pf_stamps[8 * 160 * 4];
+#define QL_PF_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && p < 160) ql_pf_stamps[(wv * 160 + p) * 4 + (k)] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QL_PF_STAMP(k) do { } while (0)
+#endif
+
 namespace ql {
 
 typedef short pf_s16x4 __attribute__((ext_vector_type(4)));
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
     int kt_x = next_tile(-1), kt_soft = 0;
     for (int p = 0; p < 2 * NT + 2; ++p) {
         const bool staging = ord_stage < NT && !(QL_PF_ABLATE & 8);
+        QL_PF_STAMP(0);
         if (!(p & 1) && staging) load_tile(kt_stage);         // in flight under two slots of arithmetic
         const int pp = p - grp;
         if (pp >= 0 && pp <= 2 * NT) {
@@ -345,12 +355,15 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
                 else softmax(std::false_type{}, t0, fl);
             }
         }
+        QL_PF_STAMP(1);
         if ((p & 1) && ord_stage < NT) {
             if (!(QL_PF_ABLATE & 8)) store_tile(ord_stage & 1, ord_stage % 3);
             kt_stage = next_tile(kt_stage);
             ++ord_stage;
         }
+        QL_PF_STAMP(2);
         if (!(QL_PF_ABLATE & 16)) __syncthreads();
+        QL_PF_STAMP(3);
     }
 
 #pragma unroll
@@ -398,3 +411,9 @@ int prefill_attention(int dtype, const void* Q, const void* Kc, const void* Vc, 
 }
 
 }  // namespace ql
+
+#ifdef QL_PF_STAMPS
+extern "C" int qlinear_pf_stamps_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql_pf_stamps), sizeof(unsigned long long) * 8 * 160 * 4);
+}
+#endif
