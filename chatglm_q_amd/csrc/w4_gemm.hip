@@ -327,9 +327,23 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
 
 template <typename T>
 static int launch_gemm_any(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
-                           int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    if (w4_gemm256_supported(M, N, K, lda, A, sizeof(T)))      // prefill-sized row counts: 256 x 256 tiles (w4_gemm256.hip)
-        return w4_gemm256(Act<T>::code, A, tiled, bias, C, M, N, K, lda, ldc, st);
+                           int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool can_recurse = true) {
+    if (can_recurse && w4_gemm256_supported(M, N, K, lda, A, sizeof(T))) {    // prefill-sized row counts: 256 x 256 tiles (w4_gemm256.hip)
+        // That kernel pays in whole rounds of 256 workgroups.  When the last round would be less than 40 % full (qkv_proj at 8192 rows:
+        // 576 workgroups = 2.25 rounds at the price of 3), the row tiles that fill the whole rounds go to it and the remaining rows to
+        // the 128-row-tile kernel below as a second launch (same dequantised weights and fp32 sums; the two kernels add in different
+        // orders, so a row's last bit may depend on which one served it).  QLINEAR_GEMM_PEEL=0: one launch (A/B measurements).
+        static const int no_peel = [] { const char* e = getenv("QLINEAR_GEMM_PEEL"); return e && atoi(e) == 0; }();
+        const int64_t nbx = (N + 255) / 256, nby = (M + 255) / 256, blocks = nbx * nby;
+        const int64_t full = blocks / 256, tail = blocks - full * 256;
+        const int64_t nby_main = full * 256 / nbx, m_main = nby_main * 256;
+        if (no_peel || full < 1 || tail == 0 || tail * 10 > 256 * 4 || nby_main < 1 || m_main >= M)
+            return w4_gemm256(Act<T>::code, A, tiled, bias, C, M, N, K, lda, ldc, st);
+        const int rc = w4_gemm256(Act<T>::code, A, tiled, bias, C, m_main, N, K, lda, ldc, st);
+        if (rc != 0) return rc;
+        return launch_gemm_any<T>((const T*)A + m_main * lda, tiled, bias, (T*)C + m_main * ldc, M - m_main, N, K, lda, ldc, ws, ws_bytes, st,
+                                  false);
+    }
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
     static const int forced_nw = [] { const char* e = getenv("QLINEAR_GEMM_NW"); return e ? atoi(e) : 0; }();   // 4: two 4-wave blocks per CU (measurement)
