@@ -224,3 +224,38 @@ def test_lib_load_is_retried_when_the_file_changes(tmp_path, monkeypatch):
         _lib.get_lib()
     monkeypatch.setattr(_lib, "LIB_PATH", real)          # "the build finished": path now resolves, stamp differs
     assert _lib.available()
+
+
+def test_attention_tile_flags_against_brute_force():
+    """fused_ops.attention_tile_flags (host side of qlinear_prefill_attention): 0 only where every entry of the tile is <= -1e9 AND
+    every query row of the block sees an entry >= -1e6 somewhere, 2 only where the tile is all zero, 1 otherwise - for causal chunks,
+    left pads (rows with no visible key forbid skipping in their block), ragged shapes and a soft bias."""
+    import torch
+    from chatglm_q_amd import fused_ops as F_
+    QB, KB = F_.prefill_attention_tiles()
+    assert (QB, KB) == (16, 64)
+    g = torch.Generator().manual_seed(0)
+    cases = []
+    for (B, S, T, first) in [(2, 64, 192, 128), (1, 37, 42, 5), (3, 48, 130, 60)]:
+        t = torch.arange(T)
+        rows = torch.arange(first, first + S)
+        blocked = (t[None, None, :] > rows[None, :, None]).expand(B, S, T).clone()
+        pads = torch.randint(0, T // 2, (B,), generator=g)
+        for b in range(B):
+            blocked[b, :, : int(pads[b])] = True
+        cases.append(blocked.float() * -1e10)
+    cases.append(-0.05 * torch.rand(1, 40, 100, generator=g))          # soft bias: nothing skippable, nothing all-zero
+    cases.append(torch.zeros(1, 16, 64))                                # one all-zero tile
+    for mask in cases:
+        B, S, T = mask.shape
+        flags = F_.attention_tile_flags(mask)
+        nq, nk = (S + QB - 1) // QB, (T + KB - 1) // KB
+        assert flags.shape == (B, nq, nk) and flags.dtype == torch.uint8
+        for b in range(B):
+            for qb in range(nq):
+                rows = mask[b, qb * QB:(qb + 1) * QB]
+                rows_ok = bool((rows >= -1e6).any(dim=-1).all())
+                for kt in range(nk):
+                    tile = rows[:, kt * KB:(kt + 1) * KB]
+                    want = 0 if (bool((tile <= -1e9).all()) and rows_ok) else 2 if bool((tile == 0).all()) else 1
+                    assert int(flags[b, qb, kt]) == want, (b, qb, kt)
