@@ -298,7 +298,6 @@ __global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __
                     (pf_s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p0)));
                 const pf_s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (pf_s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p0 + 16 * VP)));
-                typedef short pf_s16x8 __attribute__((ext_vector_type(8)));
                 const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int r = 0; r < R; ++r) o[r][dt] = PfMma<T>::mma(a, pb[r][c], o[r][dt]);
