@@ -405,13 +405,53 @@ def e2e_cpu(torch, device):
             "generated": len(toks), "prefill_s": round(s["init_s"], 2), "gen_tok_per_s": round(s["gen_tok_per_s"], 4)}
 
 
+def prefill_attention(torch, device):
+    """The attention of config 5's prefill (batch 4, one chunk of 2048 positions, 32 heads x 128, 2 key / value groups): the
+    one-launch kernel (qlinear_prefill_attention) beside the GEMM route (two batched GEMMs around qlinear_masked_softmax); FLOPs
+    count only visible (query, key) pairs."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd import model as M
+    H, G, D, B, S = 32, 2, 128, 4, 2048
+    dt = torch.float16
+    gen = torch.Generator(device=device).manual_seed(5)
+    q = torch.randn(B, S, H * D, device=device, generator=gen).to(dt)
+    k = torch.randn(B, S, G, D, device=device, generator=gen).to(dt)
+    v = torch.randn(B, S, G, D, device=device, generator=gen).to(dt)
+    t = torch.arange(S, device=device)
+    mask = ((t[None, None, :] > t[None, :, None]).expand(B, S, S).float() * -1e10).contiguous()
+    flags = F_.attention_tile_flags(mask)
+    attn = M.ChatGLM2Attention(H * D, H, D, G, 0, dtype=dt)
+    flops = 4.0 * B * H * D * (S * (S + 1) // 2)
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    one = timed(lambda: F_.prefill_attention(q, k, v, mask, flags, S, H, G, D), 20)
+    two = timed(lambda: attn.core(dt, q.view(B, S, G, H // G, D), k, v, mask), 5)
+    a, b = F_.prefill_attention(q, k, v, mask, flags, S, H, G, D), attn.core(dt, q.view(B, S, G, H // G, D), k, v, mask)
+    return {"workload": "causal attention of one prefill layer, batch 4 x 2048 positions, fp16",
+            "one_launch_ms": round(one, 4), "one_launch_TFLOPs_visible_pairs": round(flops / one / 1e9, 1),
+            "frac_of_2.5PF_f16_mfma": round(flops / one / 1e9 / 2500.0, 4),
+            "gemm_route_ms": round(two, 4), "gemm_route_TFLOPs_visible_pairs": round(flops / two / 1e9, 1),
+            "rel_l2_between_routes": float((a.float() - b.float()).norm() / b.float().norm())}
+
+
 def run(torch, device):
     out = {}
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
                      ("prefill_gemm_M8192", prefill_gemm), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
-                     ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
+                     ("prefill_attention_b4_s2048", prefill_attention), ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)
         except Exception as e:      # keep going: extras are informative only

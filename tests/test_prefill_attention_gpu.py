@@ -52,6 +52,7 @@ CASES = [
     (1, 128, 320, 384, 192),        # second chunk against a prefix; T not a multiple of 64
     (2, 37, 42, 64, 5),             # ragged block of query rows
     (1, 1024, 2048, 2048, 1024),    # config 5's second chunk of one sequence
+    (1, 40, 4113, 4224, 4073),      # a short chunk behind a long prefix: 65 key tiles, ragged last tile, ragged query block
 ]
 
 
