@@ -218,6 +218,17 @@ int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* 
     return w4_fewrow(dtype, A, tiled, bias, C, M, N, K, lda, ldc, nullptr, 0, (hipStream_t)stream, true);
 }
 
+int qlinear_w4g32_fwd_tiled_residual(const void* A, const void* tiled, const void* bias, const void* residual, void* C, int64_t M,
+                                     int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, int dtype, void* stream) {
+    if (!A || !tiled || !C || !residual) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || K % 32 != 0 || lda < K || ldc < N || ldr < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !aligned(A, 16) || !aligned(C, 16) || !aligned(residual, 16) || lda % 8 != 0 || ldc % 8 != 0 || ldr % 8 != 0)
+        return QL_ERR_MISALIGNED;
+    if (N % 8 != 0 || !w4_gemm256_supported(M, N, K, lda, A, 2)) return QL_ERR_UNSUPPORTED;   // callers add the residual themselves
+    return w4_gemm256_residual(dtype, A, tiled, bias, residual, C, M, N, K, lda, ldc, ldr, (hipStream_t)stream);
+}
+
 int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                    int64_t lda, int64_t ldc, int dtype, void* stream) {
     if (!packed) return QL_ERR_NULL_POINTER;

@@ -250,6 +250,44 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {   // rounds each v
     return r;
 }
 
+// The same epilogue with the residual stream added (chatglm_q/model.py:243,245: hidden = hidden + sublayer(...)): every 8-column
+// row chunk of the rounded tile meets the same chunk of `resid` (row stride ldr) and leaves as round(y + resid) - the sublayer's
+// output is rounded to T first, as the reference materialises it.  16-byte aligned rows of C and resid (checked by the ABI).
+template <typename T, typename F>
+__device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restrict__ C, int64_t ldc, const T* __restrict__ resid,
+                                                       int64_t ldr, int m_base, int n0, int M, int N, const T* __restrict__ bias,
+                                                       int lane, F val) {
+    static_assert(sizeof(T) == 2, "16-bit outputs");
+    const int j = lane & 31, kb = lane >> 5;
+    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
+        float y = Act<T>::round(val(i));
+        if (bias) y = y + bj;
+        Act<T>::store(lds_wave + row * 32 + j, y);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h, row = q >> 2, c8 = (q & 3) * 8;
+        const int m = m_base + row, n = n0 + c8;
+        if (m >= M || n >= N) continue;
+        if (n + 8 <= N) {
+            float y[8], r[8];
+            unpack8<T>(*reinterpret_cast<const u32x4*>(lds_wave + row * 32 + c8), y);
+            unpack8<T>(*reinterpret_cast<const u32x4*>(resid + (int64_t)m * ldr + n), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = y[e] + r[e];
+            *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = pack8<T>(y);
+        } else {                                 // ragged last chunk of the matrix: element by element
+            for (int e = 0; e < N - n; ++e)
+                Act<T>::store(C + (int64_t)m * ldc + n + e, (float)lds_wave[row * 32 + c8 + e] + Act<T>::load(resid + (int64_t)m * ldr + n + e));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // The same epilogue with SiLU * gate (chatglm_q/model.py:200-201) on GATE-INTERLEAVED columns: column quad t of the weight copy is
 // (h[2t], h[2t+1], gate[2t], gate[2t+1]), so an 8-column row chunk of the tile holds two complete quads and becomes 4 outputs -
 // out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias as a second rounded operation) - stored as ONE 8-byte

@@ -106,7 +106,8 @@ __device__ __forceinline__ u32x4 w8_dequant_natural(u32 w0, u32 w1, float s) {
 template <typename T, bool W8 = false, bool GATE = false>
 __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                          int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
-                                                         const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+                                                         const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                         const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
     typedef Mma<T> MM;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2]; reused by the epilogue
 #ifdef QL_G256_STAMPS
@@ -375,6 +376,8 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
             for (int mt = 0; mt < 4; ++mt)
                 if constexpr (GATE)
                     store_tile_32x32_gated<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else if (resid)                        // kernel-uniform: the residual stream is added in the row-chunk pass
+                    store_tile_32x32_resid<T>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
                 else
                     store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
 #ifdef QL_G256_STAMPS
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 
 template <typename T, bool GATE = false>
 static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
-                          hipStream_t st) {
+                          hipStream_t st, const void* resid = nullptr, int64_t ldr = 0) {
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const u32x4* Wt = (const u32x4*)tiled;
     const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
@@ -415,7 +418,7 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
-        super ? sy : 0, (const T*)bias, (T*)C, ldc);
+        super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
     return finish_launch();
 }
 
@@ -474,6 +477,16 @@ int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, vo
     switch (dtype) {
     case QL_DTYPE_F16: return launch_gemm256<f16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
     case QL_DTYPE_BF16: return launch_gemm256<__bf16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+// C = round(round(A . dequant(W) (+ bias)) + resid): the residual add of the block in the GEMM's epilogue (16-byte aligned C / resid rows)
+int w4_gemm256_residual(int dtype, const void* A, const void* tiled, const void* bias, const void* resid, void* C, int64_t M, int64_t N,
+                        int64_t K, int64_t lda, int64_t ldc, int64_t ldr, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256<f16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st, resid, ldr);
+    case QL_DTYPE_BF16: return launch_gemm256<__bf16>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, st, resid, ldr);
     default: return QL_ERR_BAD_DTYPE;
     }
 }

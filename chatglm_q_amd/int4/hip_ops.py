@@ -420,6 +420,34 @@ def w4_forward_gated(a: Tensor, gated: Tensor, n_out: int, bias: Tensor | None, 
     return c.reshape(*a.shape[:-1], n_out // 2)
 
 
+def w4_forward_tiled_residual(a: Tensor, tiled: Tensor, n_out: int, bias: Tensor | None, residual: Tensor) -> Tensor | None:
+    """Prefill row counts: ``round(round(a @ dequant(W) (+ bias)) + residual)`` with the add in the 256 x 256-tile GEMM's epilogue
+    (``qlinear_w4g32_fwd_tiled_residual``; bit-equal to the projection followed by ``+``).  ``tiled``: part 2 of the derived layout.
+    None when that kernel does not serve the row count (the caller then adds the residual itself)."""
+    lib = _lib.get_lib()
+    K = a.shape[-1]
+    _check_row_operands("w4_forward_tiled_residual", a, K, bias=bias, residual=residual)
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    r2 = residual.reshape(-1, n_out)
+    if r2.shape[0] != M or r2.stride(1) != 1 or r2.stride(0) % 8:
+        if r2.shape[0] != M:
+            raise AssertionError("w4_forward_tiled_residual: residual rows != activation rows")
+        r2 = r2.contiguous()
+    if tiled.device != a.device or tiled.numel() < tiled_nbytes(n_out, K, a.dtype):
+        raise AssertionError("w4_forward_tiled_residual: derived buffer on another device or too small for (n_out, K)")
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w4g32_fwd_tiled_residual(a2.data_ptr(), tiled.data_ptr(), _lib.ptr(bias), r2.data_ptr(), c.data_ptr(), M, n_out, K,
+                                                  a2.stride(0), n_out, r2.stride(0), _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w4g32_fwd_tiled_residual")
+    return c.reshape(*a.shape[:-1], n_out)
+
+
 def w4_forward_residual(a: Tensor, packed: Tensor, n_out: int, bias: Tensor | None, residual: Tensor,
                         strict: bool | None = None, plan_out: list | None = None, guards=()) -> Tensor:
     """One-row forward added to the residual stream in the kernel's epilogue: round(y + residual), y = the layer's

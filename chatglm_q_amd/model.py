@@ -39,6 +39,9 @@ PREFILL_ATTENTION = os.environ.get("QLINEAR_PREFILL_ATTENTION", "1") not in ("0"
 # prefill row counts: w_in on its gate-interleaved copy with SiLU * gate in the 256 x 256-tile GEMM's epilogue (no (rows, 2 * hidden)
 # intermediate, no silu_mul launch); QLINEAR_GATED_PREFILL=0 keeps the two launches
 GATED_PREFILL = os.environ.get("QLINEAR_GATED_PREFILL", "1") not in ("0", "false", "False")
+# prefill row counts: `hidden + o_proj(...)` / `hidden + w_out(...)` with the add in the 256 x 256-tile GEMM's epilogue (the norm behind it
+# then reads one tensor instead of two); QLINEAR_RESIDUAL_PREFILL=0 keeps the add inside the norm launch
+RESIDUAL_PREFILL = os.environ.get("QLINEAR_RESIDUAL_PREFILL", "1") not in ("0", "false", "False")
 
 
 @dataclass
@@ -315,7 +318,12 @@ class ChatGLM2Model(nn.Module):
                     att = F_.prefill_attention(q.view(B, S, H * D), cache.k[i], cache.v[i], mask, tile_flags, T_kv, H, G, D)
                 else:
                     att = layer.attn.core(h.dtype, q.view(B, S, G, H // G, D), cache.k[i][:, :kv_len], cache.v[i][:, :kv_len], mask)
-            o = layer.attn.o_proj(att)
+            many = RESIDUAL_PREFILL and B * S >= 1024       # prefill row counts: residual adds inside the GEMMs' epilogues
+            hn = self._residual_many(layer.attn.o_proj, att, h) if many else None
+            if hn is not None:                         # h + o_proj(att) came out of the GEMM
+                h, o = hn, None
+            else:
+                o = layer.attn.o_proj(att)
             y = self._rows_fused(layer.ffn.w_in, h, o, layer.ffn_ln, gate_hidden=layer.ffn.hidden_dim) if few else None
             if y is not None:                          # h += o, RMSNorm, w_in and SiLU * gate: one launch
                 y, h = y
@@ -324,7 +332,10 @@ class ChatGLM2Model(nn.Module):
                     h, a_q, a_s, _ = F_.rmsnorm_quant(h, layer.ffn_ln.weight, layer.ffn_ln.eps, o)
                     y, u = None, layer.ffn.w_in.forward_quantized(a_q, a_s).view(B, S, -1)
                 else:
-                    h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
+                    if o is None:
+                        x = F_.rmsnorm(h, layer.ffn_ln.weight, layer.ffn_ln.eps)
+                    else:
+                        h, x = F_.add_rmsnorm(h, o, layer.ffn_ln.weight, layer.ffn_ln.eps)
                     y = self._gated_w_in(layer.ffn, x) if (S == 1 and 2 <= B <= 32) or (GATED_PREFILL and B * S >= 1024) else None   # SiLU * gate in w_in's epilogue
                     u = layer.ffn.w_in(x) if y is None else None
                 if y is None and prequant(layer.ffn.w_out):
@@ -333,14 +344,33 @@ class ChatGLM2Model(nn.Module):
                     continue
                 if y is None:
                     y = F_.silu_mul(u, layer.ffn.hidden_dim)
-            delta = layer.ffn.w_out(y)
+            hn = self._residual_many(layer.ffn.w_out, y, h) if many else None
+            if hn is not None:                         # h + w_out(y) came out of the GEMM: nothing pending
+                h, delta = hn, None
+            else:
+                delta = layer.ffn.w_out(y)
         if last_only:
-            h, delta = h[:, -1:], delta[:, -1:]
+            h, delta = h[:, -1:], None if delta is None else delta[:, -1:]
         out = self._rows_fused(self.lm_head, h, delta, self.final_ln, want_hout=False) if few else None
         if out is not None:
             return out[0]
-        _, x = F_.add_rmsnorm(h, delta, self.final_ln.weight, self.final_ln.eps)
+        if delta is None:
+            x = F_.rmsnorm(h, self.final_ln.weight, self.final_ln.eps)
+        else:
+            _, x = F_.add_rmsnorm(h, delta, self.final_ln.weight, self.final_ln.eps)
         return self.lm_head(x)
+
+    @staticmethod
+    def _residual_many(mod, x: Tensor, h: Tensor) -> Optional[Tensor]:
+        """Prefill row counts: ``h + mod(x)`` with the add in the int4g32 256 x 256-tile GEMM's epilogue (bit-equal to the two ops);
+        None when module / shape are not served that way."""
+        from .int4 import hip_ops as H4
+        from .int4.qlinear import DynamicQuantizeLinear as Q4
+        if not (isinstance(mod, Q4) and x.dtype in (torch.float16, torch.bfloat16) and mod._packed_supported() and not mod.act_quant
+                and mod.weight_scale.dtype == x.dtype and h.dtype == x.dtype and h.shape[-1] == mod.out_features):
+            return None
+        out = H4.w4_forward_tiled_residual(x, mod.tiled(), mod.out_features, mod.bias, h)
+        return None if out is None else out.view(h.shape)
 
     @staticmethod
     def _rows_fused(mod, h: Tensor, delta: Optional[Tensor], ln, gate_hidden: Optional[int] = None, want_hout: bool = True):

@@ -221,6 +221,12 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
  * The same on part 2 alone (qlinear_w4g32_tile of the gate-interleaved part 1): */
 int qlinear_w4g32_fwd_tiled_gated(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                   int64_t lda, int64_t ldc, int dtype, void* stream);
+/* Prefill row counts with the residual add of the block in the GEMM's epilogue (round 3): C = round(round(A . dequant(W) (+ bias)) +
+ * residual) - `hidden = hidden + sublayer(...)`, chatglm_q/model.py:243,245, with the sublayer output rounded first as the reference
+ * materialises it; bit-equal to qlinear_w4g32_fwd_tiled + an elementwise add.  residual (M, N) with row stride ldr; must not overlap C.
+ * QL_ERR_UNSUPPORTED unless the 256 x 256-tile kernel serves the row count (callers then add the residual themselves). */
+int qlinear_w4g32_fwd_tiled_residual(const void* A, const void* tiled, const void* bias, const void* residual, void* C, int64_t M,
+                                     int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, int dtype, void* stream);
 
 /* The same prologue (QL_PRO_ADDNORM, optionally | QL_EPI_SILU_GATE) for 2..4 contiguous rows (batched decode), on the 4x4x4-MFMA
  * kernel: A, delta (nullable), hout (nullable; written when delta is given) are (M, K), C is (M, N) or (M, N / 2) with the gate

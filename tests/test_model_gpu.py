@@ -342,6 +342,32 @@ def test_gemm256_gate_epilogue_equals_separate_ops(dtype, bias, M):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (8192 - 56, 13696, 4096)])
+def test_gemm256_residual_epilogue_equals_separate_ops(dtype, bias, shape):
+    """Prefill row counts: qlinear_w4g32_fwd_tiled_residual (hidden + sublayer(...) with the add in the 256 x 256-tile GEMM's
+    epilogue, chatglm_q/model.py:243,245) against the same GEMM followed by the elementwise add - bit for bit; row counts the
+    kernel does not serve report None."""
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    M, K, N = shape
+    g = torch.Generator(device=DEV).manual_seed(13)
+    layer = DynamicQuantizeLinear(K, N, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(1, M, K, device=DEV, generator=g).to(dtype)
+    h = torch.randn(1, M, N, device=DEV, generator=g).to(dtype)
+    got = H4.w4_forward_tiled_residual(x, layer.tiled(), N, layer.bias, h)
+    with torch.no_grad():
+        want = h + layer(x)
+    assert got is not None and got.shape == (1, M, N)
+    assert torch.equal(got, want)
+    assert H4.w4_forward_tiled_residual(x[:, :40], layer.tiled(), N, layer.bias, h[:, :40]) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("M", [3, 8, 32])
 def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     """qlinear_w4g32_fwd_packed_gated (few rows, SiLU * gate in the MFMA kernel's epilogue) against the projection
