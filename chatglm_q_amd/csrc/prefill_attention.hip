@@ -13,8 +13,10 @@
 //                                                 of the step), A = two ds_read_b64_tr_b16 of row-major value rows (pitch 288 B)
 // A wave owns R = 2 query positions x the group's 16 heads (every key / value fragment read from LDS feeds two MFMAs); a
 // workgroup of NWV waves owns 2 NWV consecutive positions of one (sequence, group) and stages each 64-key tile of K and V
-// once (global -> registers -> LDS, double buffered, one barrier per tile).  Rows of a block differ by at most 2 NWV - 1
-// positions, so a causal mask cuts whole key tiles for the whole block.
+// once (global -> registers -> LDS; two K buffers, three V buffers).  Rows of a block differ by at most 2 NWV - 1 positions, so a
+// causal mask cuts whole key tiles for the whole block.  Time is cut into slots of one barrier each and the two waves of a SIMD
+// (w, w + 4) run one slot apart: second product of the previous tile + first product of this one in one slot, softmax in the
+// next - one wave's MFMAs beside the other's VALU work (the slot loop at the end of the kernel has the buffer accounting).
 //
 // Mask: the reference's additive fp32 mask (B, S, T), applied exactly as the reference does - round(score) + mask in fp32 -
 // so a row whose keys are ALL blocked comes out as the uniform average, like the reference's.  `tile_flags` (optional,
@@ -23,7 +25,8 @@
 //       are exactly 0 in fp32 whatever the scores are (|score| <= 65504);  2 = every entry is 0: no mask loads;  1 = load it.
 // Rounding points (T = activation dtype): q / sqrt(d), the scores, the output - as the reference; P is rounded to T as
 // exp(s - running max) and normalised after the second product (the reference rounds exp(s - max) / sum: the same
-// relative error, not the same bits); the exp-sum uses the unrounded values.
+// relative error, not the same bits); the exp-sum is accumulated by the matrix pipe from those rounded values (an all-ones A
+// operand), i.e. the normaliser is the sum of exactly what the second product multiplies.
 #include "launch.h"
 #include "ql_common.h"
 #include <type_traits>
