@@ -30,16 +30,15 @@
 #include "launch.h"
 #include "ql_common.h"
 #include <type_traits>
-#include <cstdlib>
 
 // developer switches (tools/ab/build_pf_variant.sh; always 0 / 8 in the library): QL_PF_ABLATE bits strip parts of the tile body to
 // attribute time (results wrong): 1 no softmax arithmetic, 2 no second product, 4 no first product, 8 no K / V staging in the loop,
-// 16 no barrier in the loop.
+// 16 no barrier in the loop.  QL_PF_WAVES: waves per workgroup (8 or 4).
 #ifndef QL_PF_ABLATE
 #define QL_PF_ABLATE 0
 #endif
-#ifndef QL_PF_MODE
-#define QL_PF_MODE 0              // default kernel structure (see prefill_attention_kernel); QLINEAR_PREFILL_ATT_MODE overrides at run time
+#ifndef QL_PF_WAVES
+#define QL_PF_WAVES 8
 #endif
 
 // QL_PF_STAMPS (developer build): workgroup 0's waves stamp s_memtime (shader-clock ticks) at the start of every slot, after its
@@ -76,20 +75,14 @@ constexpr int kPfR = 2;                                       // query positions
 constexpr int kPfMaxTiles = 2048;                             // key tiles per row of flags kept in LDS (T <= 131 072)
 constexpr int kPfLds = kPfKeys * (2 * kPfKP + 3 * kPfVP) + kPfMaxTiles;   // two K tiles, three V tiles, the flags: 92 160 bytes
 
-// MODE 0: eight waves x 2 query positions, the waves of a SIMD one slot apart (ping-pong).  MODE 1: four waves x 4 positions (one wave
-// per SIMD with the whole register file: every key / value fragment read from LDS feeds FOUR MFMAs), one barrier per tile, and the
-// same pipeline folded into each wave's own instruction stream: first product of tile i, then the second product of tile i - 1
-// interleaved (by the compiler's scheduler) with the softmax of tile i.
-template <typename T, int MODE>
-__global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kc,
+template <typename T, int NWV>
+__global__ __launch_bounds__(NWV * 64) void prefill_attention_kernel(const T* __restrict__ Q, const T* __restrict__ Kc,
                                                                      const T* __restrict__ Vc, const float* __restrict__ mask,
                                                                      const uint8_t* __restrict__ flags, T* __restrict__ Out,
                                                                      int S, int Tkv, int H, int G, int cap, int nqb, int nkt,
                                                                      int64_t ldm, float sqrt_d) {
     static_assert(sizeof(T) == 2, "16-bit dtypes");
-    constexpr int NWV = MODE ? 4 : 8, R = MODE ? 4 : kPfR;
-    constexpr int D = 128, HP = 16, QB = R * NWV, NTH = NWV * 64, KP = kPfKP, VP = kPfVP;
-    static_assert(QB == kPfR * 8, "both modes share the tile-flag granularity");
+    constexpr int D = 128, HP = 16, R = kPfR, QB = R * NWV, NTH = NWV * 64, KP = kPfKP, VP = kPfVP;
     constexpr int CH = kPfKeys * 16 / NTH;                    // 16-byte chunks of a K (and of a V) tile staged per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char pf_smem[];
     unsigned char* const kimg = pf_smem;                      // [2][64][KP]
@@ -171,9 +164,7 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
     const u32x4 ones = u32x4{one2, one2, one2, one2};
     f32x4 o[R][8];                                            // O^T: lane (li, q) = head li, d = 16 dt + 4 q + e
     f32x4 s[R][4];                                            // S^T of the tile between the first product and its softmax
-    u32x4 pb[1][R][2];                                        // exp(S^T - max) as the B operands of the second product's two 32-key steps
-    float alpha_p[R];                                         // MODE 1: rescale of O pending until the previous tile's second product is in
-    bool keep_p = true;
+    u32x4 pb[R][2];                                           // exp(S^T - max) as the B operands of the second product's two 32-key steps
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         m[r] = -INFINITY;
@@ -202,9 +193,8 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
 
     // mask, running maximum, exponentials (rounded to T into pb), exp-sum, rescale of O.  Two copies: the general one (mask loads,
     // range checks) runs on the few tiles that need it - left to one body the compiler if-converts both into selects on every score
-    auto softmax = [&](auto general_tag, auto pb_tag, const int t0, const int fl) {
+    auto softmax = [&](auto general_tag, const int t0, const int fl) {
         constexpr bool GEN = decltype(general_tag)::value;
-        constexpr int PBI = decltype(pb_tag)::value;
         float mv[GEN ? R : 1][4][4];
         if constexpr (GEN) {
 #pragma unroll
@@ -228,7 +218,7 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    pb[PBI][r][c] = u32x4{pack2<T>(s[r][2 * c][0], s[r][2 * c][1]), pack2<T>(s[r][2 * c][2], s[r][2 * c][3]),
+                    pb[r][c] = u32x4{pack2<T>(s[r][2 * c][0], s[r][2 * c][1]), pack2<T>(s[r][2 * c][2], s[r][2 * c][3]),
                                      pack2<T>(s[r][2 * c + 1][0], s[r][2 * c + 1][1]), pack2<T>(s[r][2 * c + 1][2], s[r][2 * c + 1][3])};
         }
         typedef T T2 __attribute__((ext_vector_type(2)));
@@ -285,13 +275,10 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
                     else                                      // |x|, |mn| <= 65504: one fma, error <= 6e-8 |mn| in the exponent
                         ev[e] = __builtin_amdgcn_exp2f(__builtin_fmaf((float)xr[pt][e >> 1][e & 1], kLog2e, -mnl));
                 }
-                pb[PBI][r][pt >> 1][2 * (pt & 1)] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[0], ev[1]}, T2));
-                pb[PBI][r][pt >> 1][2 * (pt & 1) + 1] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[2], ev[3]}, T2));
+                pb[r][pt >> 1][2 * (pt & 1)] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[0], ev[1]}, T2));
+                pb[r][pt >> 1][2 * (pt & 1) + 1] = __builtin_bit_cast(u32, __builtin_convertvector(F2{ev[2], ev[3]}, T2));
             }
-            if constexpr (MODE == 1) {                        // O still waits for the previous tile's second product: rescale later
-                alpha_p[r] = alpha;
-                keep_p = keep_p && alpha == 1.0f;
-            } else if (!__all(alpha == 1.0f)) {               // wave-uniform: the maximum settles after the first tiles
+            if (!__all(alpha == 1.0f)) {                      // wave-uniform: the maximum settles after the first tiles
 #pragma unroll
                 for (int e = 0; e < 4; ++e) lacc[r][e] *= alpha;
 #pragma unroll
@@ -303,8 +290,7 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
     };
 
     // O^T += V^T P^T, 32 keys per MFMA step
-    auto second_product = [&](auto pb_tag, const int vbuf) {
-        constexpr int PBI = decltype(pb_tag)::value;
+    auto second_product = [&](const int vbuf) {
         const unsigned char* vb = vimg + vbuf * kPfKeys * VP;
 #pragma unroll
         for (int c = 0; c < ((QL_PF_ABLATE & 2) ? 0 : 2); ++c) {
@@ -317,18 +303,18 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
                     (pf_s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p0 + 16 * VP)));
                 const u32x4 a = __builtin_bit_cast(u32x4, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int r = 0; r < R; ++r) o[r][dt] = PfMma<T>::mma(a, pb[PBI][r][c], o[r][dt]);
+                for (int r = 0; r < R; ++r) o[r][dt] = PfMma<T>::mma(a, pb[r][c], o[r][dt]);
             }
             // the exp-sum on the matrix pipe too: an all-ones A operand gives every lane of head li the sum over the step's 32 keys
             // (of the ROUNDED probabilities - what the product above multiplies), with no cross-lane reduction and no VALU adds
 #pragma unroll
-            for (int r = 0; r < R; ++r) lacc[r] = PfMma<T>::mma(ones, pb[PBI][r][c], lacc[r]);
+            for (int r = 0; r < R; ++r) lacc[r] = PfMma<T>::mma(ones, pb[r][c], lacc[r]);
         }
         if constexpr ((QL_PF_ABLATE & 2) != 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) o[r][c][0] += __builtin_bit_cast(float, pb[PBI][r][c][0] ^ pb[PBI][r][c][1] ^ pb[PBI][r][c][2] ^ pb[PBI][r][c][3]);
+                for (int c = 0; c < 2; ++c) o[r][c][0] += __builtin_bit_cast(float, pb[r][c][0] ^ pb[r][c][1] ^ pb[r][c][2] ^ pb[r][c][3]);
         }
     };
 
@@ -349,89 +335,37 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
         ord_stage = 1;
     }
     __syncthreads();
-    if constexpr (MODE == 0) {
-        int kt_x = next_tile(-1), kt_soft = 0;
-        for (int p = 0; p < 2 * NT + 2; ++p) {
-            const bool staging = ord_stage < NT && !(QL_PF_ABLATE & 8);
-            QL_PF_STAMP(0);
-            if (!(p & 1) && staging) load_tile(kt_stage);         // in flight under two slots of arithmetic
-            const int pp = p - grp;
-            if (pp >= 0 && pp <= 2 * NT) {
-                const int ii = pp >> 1;
-                if (!(pp & 1)) {
-                    if (ii > 0) second_product(std::integral_constant<int, 0>{}, (ii - 1) % 3);
-                    if (ii < NT) {
-                        first_product(ii & 1);
-                        kt_soft = kt_x;
-                        kt_x = next_tile(kt_x);
-                    }
-                } else if (ii < NT) {
-                    const int t0 = kt_soft * kPfKeys;
-                    const int fl = !mask ? 2 : have_flags ? (int)frow[kt_soft] : 1;   // no mask at all: every tile is 'all zero'
-                    if (fl == 1 || t0 + kPfKeys > Tkv) softmax(std::true_type{}, std::integral_constant<int, 0>{}, t0, fl);
-                    else softmax(std::false_type{}, std::integral_constant<int, 0>{}, t0, fl);
+    int kt_x = next_tile(-1), kt_soft = 0;
+    for (int p = 0; p < 2 * NT + 2; ++p) {
+        const bool staging = ord_stage < NT && !(QL_PF_ABLATE & 8);
+        QL_PF_STAMP(0);
+        if (!(p & 1) && staging) load_tile(kt_stage);         // in flight under two slots of arithmetic
+        const int pp = p - grp;
+        if (pp >= 0 && pp <= 2 * NT) {
+            const int ii = pp >> 1;
+            if (!(pp & 1)) {
+                if (ii > 0) second_product((ii - 1) % 3);
+                if (ii < NT) {
+                    first_product(ii & 1);
+                    kt_soft = kt_x;
+                    kt_x = next_tile(kt_x);
                 }
+            } else if (ii < NT) {
+                const int t0 = kt_soft * kPfKeys;
+                const int fl = !mask ? 2 : have_flags ? (int)frow[kt_soft] : 1;   // no mask at all: every tile is 'all zero'
+                if (fl == 1 || t0 + kPfKeys > Tkv) softmax(std::true_type{}, t0, fl);
+                else softmax(std::false_type{}, t0, fl);
             }
-            QL_PF_STAMP(1);
-            if ((p & 1) && ord_stage < NT) {
-                if (!(QL_PF_ABLATE & 8)) store_tile(ord_stage & 1, ord_stage % 3);
-                kt_stage = next_tile(kt_stage);
-                ++ord_stage;
-            }
-            QL_PF_STAMP(2);
-            if (!(QL_PF_ABLATE & 16)) __syncthreads();
-            QL_PF_STAMP(3);
         }
-    } else {
-        // one barrier per tile; iteration i (0 .. NT): the rescale of O left pending by tile i - 1's softmax, the first product of
-        // tile i, then the second product of tile i - 1 in one instruction stream with the softmax of tile i.  Tile i + 1 is requested at the top and stored at the bottom: its K buffer was last read by the
-        // first product of tile i - 1 (previous iteration), its V buffer (three of them) by the second product of tile i - 2.
-        int kt_cur = next_tile(-1);
-        for (int i = 0; i <= NT; ++i) {
-            const bool staging = ord_stage < NT && !(QL_PF_ABLATE & 8);
-            const int p = i;                                  // (the stamp macro's slot index)
-            (void)p;
-            QL_PF_STAMP(0);
-            if (staging) load_tile(kt_stage);
-            if (i > 0 && !__all(keep_p)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lacc[r][e] *= alpha_p[r];
-#pragma unroll
-                    for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[r][dt][e] *= alpha_p[r];
-                }
-            }
-            keep_p = true;
-            if (i < NT) {
-                first_product(i & 1);
-                const int t0 = kt_cur * kPfKeys;
-                const int fl = !mask ? 2 : have_flags ? (int)frow[kt_cur] : 1;   // no mask at all: every tile is 'all zero'
-                // one register set of probabilities is enough: the MFMAs of the second product read theirs at issue, and the
-                // softmax writes the new ones last - the write-after-read order is the only constraint the scheduler has to keep
-                if (fl == 1 || t0 + kPfKeys > Tkv) {
-                    if (i > 0) second_product(std::integral_constant<int, 0>{}, (i - 1) % 3);
-                    softmax(std::true_type{}, std::integral_constant<int, 0>{}, t0, fl);
-                } else {
-                    if (i > 0) second_product(std::integral_constant<int, 0>{}, (i - 1) % 3);
-                    softmax(std::false_type{}, std::integral_constant<int, 0>{}, t0, fl);
-                }
-                kt_cur = next_tile(kt_cur);
-            } else if (i > 0) {
-                second_product(std::integral_constant<int, 0>{}, (i - 1) % 3);
-            }
-            QL_PF_STAMP(1);
-            if (ord_stage < NT) {
-                if (!(QL_PF_ABLATE & 8)) store_tile(ord_stage & 1, ord_stage % 3);
-                kt_stage = next_tile(kt_stage);
-                ++ord_stage;
-            }
-            QL_PF_STAMP(2);
-            if (!(QL_PF_ABLATE & 16)) __syncthreads();
-            QL_PF_STAMP(3);
+        QL_PF_STAMP(1);
+        if ((p & 1) && ord_stage < NT) {
+            if (!(QL_PF_ABLATE & 8)) store_tile(ord_stage & 1, ord_stage % 3);
+            kt_stage = next_tile(kt_stage);
+            ++ord_stage;
         }
+        QL_PF_STAMP(2);
+        if (!(QL_PF_ABLATE & 16)) __syncthreads();
+        QL_PF_STAMP(3);
     }
 
 #pragma unroll
@@ -448,24 +382,24 @@ __global__ __launch_bounds__((MODE ? 4 : 8) * 64) void prefill_attention_kernel(
 }
 
 void prefill_attention_tiles(int64_t* q_block, int64_t* k_tile) {
-    *q_block = kPfR * 8;
+    *q_block = kPfR * QL_PF_WAVES;
     *k_tile = kPfKeys;
 }
 
-template <typename T, int MODE>
+template <typename T>
 static int launch_prefill_attention(const void* Q, const void* Kc, const void* Vc, const float* mask, const uint8_t* flags, void* Out,
                                     int64_t B, int64_t S, int64_t Tkv, int64_t H, int64_t G, int64_t cap, int64_t ldm, hipStream_t st) {
-    constexpr int NWV = MODE ? 4 : 8, QB = kPfR * 8;
+    constexpr int NWV = QL_PF_WAVES, QB = kPfR * NWV;
     const int nqb = (int)((S + QB - 1) / QB), nkt = (int)((Tkv + kPfKeys - 1) / kPfKeys);
     if (nkt > kPfMaxTiles) return QL_ERR_UNSUPPORTED;
     static bool attr_set = false;                             // > 64 KB of dynamic LDS needs the opt-in, once per process
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attention_kernel<T, MODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attention_kernel<T, NWV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kPfLds) != hipSuccess)
             return (int)hipGetLastError();
         attr_set = true;
     }
-    prefill_attention_kernel<T, MODE><<<(unsigned)(nqb * B * G), NWV * 64, kPfLds, st>>>(
+    prefill_attention_kernel<T, NWV><<<(unsigned)(nqb * B * G), NWV * 64, kPfLds, st>>>(
         (const T*)Q, (const T*)Kc, (const T*)Vc, mask, flags, (T*)Out, (int)S, (int)Tkv, (int)H, (int)G, (int)cap, nqb, nkt, ldm,
         sqrtf(128.0f));
     return finish_launch();
@@ -473,13 +407,8 @@ static int launch_prefill_attention(const void* Q, const void* Kc, const void* V
 
 int prefill_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, const uint8_t* flags, void* Out,
                       int64_t B, int64_t S, int64_t Tkv, int64_t H, int64_t G, int64_t cap, int64_t ldm, hipStream_t st) {
-    static const int mode = [] { const char* e = getenv("QLINEAR_PREFILL_ATT_MODE"); return e ? atoi(e) : QL_PF_MODE; }();   // A/B switch
-    if (dtype == QL_DTYPE_F16)
-        return mode ? launch_prefill_attention<f16, 1>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st)
-                    : launch_prefill_attention<f16, 0>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st);
-    if (dtype == QL_DTYPE_BF16)
-        return mode ? launch_prefill_attention<__bf16, 1>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st)
-                    : launch_prefill_attention<__bf16, 0>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st);
+    if (dtype == QL_DTYPE_F16) return launch_prefill_attention<f16>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st);
+    if (dtype == QL_DTYPE_BF16) return launch_prefill_attention<__bf16>(Q, Kc, Vc, mask, flags, Out, B, S, Tkv, H, G, cap, ldm, st);
     return QL_ERR_UNSUPPORTED;
 }
 
