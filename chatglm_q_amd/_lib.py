@@ -131,6 +131,8 @@ EXPORTS = {
                                        c_int, c_void_p]),
     "qlinear_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_tiled_residual": (c_int, [c_void_p] * 5 + [c_int64] * 6 + [c_int, c_void_p]),
+    "qlinear_w8_fwd_tiled_gated": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_void_p]),
+    "qlinear_w8_fwd_tiled_residual": (c_int, [c_void_p] * 6 + [c_int64] * 6 + [c_int, c_void_p]),
     "qlinear_prefill_attention_tiles": (c_int, [c_void_p, c_void_p]),
     "qlinear_prefill_attention": (c_int, [c_void_p] * 6 + [c_int64] * 8 + [c_int, c_void_p]),
     "qlinear_rmsnorm_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

@@ -383,6 +383,27 @@ int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const 
                         (hipStream_t)stream);
 }
 
+int qlinear_w8_fwd_tiled_gated(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                               int64_t K, int64_t lda, int64_t ldc, int dtype, void* stream) {
+    if (!A || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || K % 16 != 0 || N % 4 != 0 || lda < K || ldc < N / 2) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype) || !aligned(C, 8) || ldc % 4 != 0) return QL_ERR_MISALIGNED;
+    if (N % 32 != 0 || !w4_gemm256_supported(M, N, K, lda, A, 2)) return QL_ERR_UNSUPPORTED;   // projection + qlinear_silu_mul instead
+    return w8_gemm256_gated(dtype, A, (const int8_t*)tiled, S, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
+int qlinear_w8_fwd_tiled_residual(const void* A, const void* tiled, const void* S, const void* bias, const void* residual, void* C,
+                                  int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, int dtype, void* stream) {
+    if (!A || !tiled || !S || !C || !residual) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || K % 16 != 0 || lda < K || ldc < N || ldr < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype) || !aligned(C, 16) || !aligned(residual, 16) || ldc % 8 != 0 || ldr % 8 != 0)
+        return QL_ERR_MISALIGNED;
+    if (N % 8 != 0 || !w4_gemm256_supported(M, N, K, lda, A, 2)) return QL_ERR_UNSUPPORTED;    // callers add the residual themselves
+    return w8_gemm256_residual(dtype, A, (const int8_t*)tiled, S, bias, residual, C, M, N, K, lda, ldc, ldr, (hipStream_t)stream);
+}
+
 int qlinear_w8_fwd_fused(int prologue, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t N,
                          int64_t K, int64_t ldw_n, const void* delta, const void* ln_weight, void* hout, float eps, int dtype,
                          void* stream) {

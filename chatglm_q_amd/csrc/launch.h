@@ -165,6 +165,10 @@ int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, vo
                int64_t ldc, hipStream_t st);
 int w4_gemm256_residual(int dtype, const void* A, const void* tiled, const void* bias, const void* resid, void* C, int64_t M, int64_t N,
                         int64_t K, int64_t lda, int64_t ldc, int64_t ldr, hipStream_t st);   // C = round(round(y) + resid)
+int w8_gemm256_gated(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                     int64_t lda, int64_t ldc, hipStream_t st);
+int w8_gemm256_residual(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, const void* resid, void* C, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, hipStream_t st);
 int w4_gemm256_gated(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                      int64_t ldc, hipStream_t st);   // gate-interleaved copy, SiLU * gate epilogue: C (M, N / 2)
 int w8_gemm256(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,

@@ -422,11 +422,11 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     return finish_launch();
 }
 
-template <typename T>
+template <typename T, bool GATE = false>
 static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int M, int N, int K, int64_t lda,
-                             int64_t ldc, hipStream_t st) {
+                             int64_t ldc, hipStream_t st, const void* resid = nullptr, int64_t ldr = 0) {
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, true, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kG256Lds) == hipSuccess;
     }();
     (void)attr_set;
@@ -434,10 +434,28 @@ static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, con
     static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
     const int sy = 4;
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
-    w4_gemm256_kernel<T, true><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
+    w4_gemm256_kernel<T, true, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K),
-        super ? sy : 0, (const T*)bias, (T*)C, ldc);
+        super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
     return finish_launch();
+}
+
+// int8 weight-only with the epilogues of the int4 kernel: SiLU * gate on a gate-interleaved copy (C (M, N / 2)), residual add
+int w8_gemm256_gated(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                     int64_t lda, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256_w8<f16, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    case QL_DTYPE_BF16: return launch_gemm256_w8<__bf16, true>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+int w8_gemm256_residual(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, const void* resid, void* C, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_gemm256_w8<f16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st, resid, ldr);
+    case QL_DTYPE_BF16: return launch_gemm256_w8<__bf16>(A, Wm, S, bias, C, (int)M, (int)N, (int)K, lda, ldc, st, resid, ldr);
+    default: return QL_ERR_BAD_DTYPE;
+    }
 }
 
 // int8 per-channel weights (tile-major copy) through the same kernel: C = A . (W^T * s[n]) with the reference's per-weight rounding

@@ -151,6 +151,60 @@ def w8_forward_tiled(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias
     return c.reshape(*a.shape[:-1], n_out)
 
 
+def _w8_tiled_epilogue_args(what: str, a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None):
+    lib = _lib.get_lib()
+    K = a.shape[-1]
+    from ..int4.hip_ops import _check_row_operands
+    _check_row_operands(what, a, K, w_scale=w_scale, bias=bias)
+    if w_scale.shape != (n_out,) or (bias is not None and bias.shape != (n_out,)):
+        raise AssertionError(f"{what}: scale / bias must have shape ({n_out},)")
+    if tiled.device != a.device or tiled.numel() != int(lib.qlinear_w8_tiled_bytes(n_out, K)):
+        raise AssertionError(f"{what}: tiled copy does not belong to a ({n_out}, {K}) weight on {a.device}")
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8:
+        a2 = a2.contiguous()
+    return lib, K, a2
+
+
+def w8_forward_tiled_gated(a: Tensor, gated_tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor | None:
+    """Prefill row counts through a gate-interleaved first MLP projection with SiLU * gate in the 256 x 256-tile GEMM's epilogue
+    (``qlinear_w8_fwd_tiled_gated``): (..., K) -> (..., n_out / 2); scale / bias in the same permuted order.  None when that kernel
+    does not serve the row count (the caller runs the projection and ``silu_mul`` separately)."""
+    lib, K, a2 = _w8_tiled_epilogue_args("w8_forward_tiled_gated", a, gated_tiled, n_out, w_scale, bias)
+    M = a2.shape[0]
+    c = torch.empty((M, n_out // 2), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd_tiled_gated(a2.data_ptr(), gated_tiled.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out,
+                                            K, a2.stride(0), n_out // 2, _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w8_fwd_tiled_gated")
+    return c.reshape(*a.shape[:-1], n_out // 2)
+
+
+def w8_forward_tiled_residual(a: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None, residual: Tensor) -> Tensor | None:
+    """Prefill row counts: ``round(round(a @ (W * scale).T (+ bias)) + residual)`` with the add in the 256 x 256-tile GEMM's epilogue
+    (``qlinear_w8_fwd_tiled_residual``).  None when that kernel does not serve the row count."""
+    lib, K, a2 = _w8_tiled_epilogue_args("w8_forward_tiled_residual", a, tiled, n_out, w_scale, bias)
+    M = a2.shape[0]
+    if residual.dtype != a.dtype or residual.device != a.device:
+        raise AssertionError("w8_forward_tiled_residual: residual dtype / device differ from the activations'")
+    r2 = residual.reshape(-1, n_out)
+    if r2.shape[0] != M:
+        raise AssertionError("w8_forward_tiled_residual: residual rows != activation rows")
+    if r2.stride(1) != 1 or r2.stride(0) % 8:
+        r2 = r2.contiguous()
+    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_w8_fwd_tiled_residual(a2.data_ptr(), tiled.data_ptr(), w_scale.data_ptr(), _lib.ptr(bias), r2.data_ptr(), c.data_ptr(),
+                                               M, n_out, K, a2.stride(0), n_out, r2.stride(0), _lib.dtype_code(a.dtype),
+                                               _lib.stream_ptr(a.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w8_fwd_tiled_residual")
+    return c.reshape(*a.shape[:-1], n_out)
+
+
 def w8_forward_fused(kind: int, a: Tensor, weight_nk: Tensor, w_scale: Tensor, bias: Tensor | None = None,
                      delta: Tensor | None = None, ln_weight: Tensor | None = None, hout: Tensor | None = None,
                      eps: float = 0.0, plan_out: list | None = None, guards=()) -> Tensor:

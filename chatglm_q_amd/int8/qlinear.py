@@ -69,6 +69,7 @@ class DynamicQuantizeLinear(nn.Module):
             self.register_buffer("bias", None)
         self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._gated_tiled, self._gated_tiled_key = None, None
         self._plans: dict = {}            # pre-bound launches (``_lib.make_plan``): forward() by input.numel() ...
         self._fast: dict = {}             # ... and the fused one-row launches of the decode step by call site
         self.act_quant = False
@@ -78,14 +79,15 @@ class DynamicQuantizeLinear(nn.Module):
         only after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
         self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
+        self._gated_tiled, self._gated_tiled_key = None, None
         self._plans, self._fast = {}, {}
         _lib.bump_layout_epoch()
         return self
 
     def release(self, *parts: str):
-        """Free derived copies a deployment no longer needs ("tiled", "gated"); rebuilt on demand."""
+        """Free derived copies a deployment no longer needs ("tiled", "gated", "gated_tiled"); rebuilt on demand."""
         for part in parts:
-            if part not in ("tiled", "gated"):
+            if part not in ("tiled", "gated", "gated_tiled"):
                 raise ValueError(f"unknown derived layout {part!r}")
             setattr(self, "_" + part, None)
             setattr(self, "_" + part + "_key", None)
@@ -98,7 +100,8 @@ class DynamicQuantizeLinear(nn.Module):
             if isinstance(t, tuple):
                 return sum(nb(x) for x in t)
             return 0 if t is None else t.numel() * t.element_size()
-        return {"tiled": nb(self._tiled), "gated": nb(self._gated), "canonical": nb(self.weight) + nb(self.weight_scale)}
+        return {"tiled": nb(self._tiled), "gated": nb(self._gated), "gated_tiled": nb(self._gated_tiled),
+                "canonical": nb(self.weight) + nb(self.weight_scale)}
 
     def __setattr__(self, name, value):
         super().__setattr__(name, value)
@@ -180,9 +183,22 @@ class DynamicQuantizeLinear(nn.Module):
             self._gated = (self.weight.index_select(0, perm).contiguous(), self.weight_scale.index_select(0, perm).contiguous(),
                            None if self.bias is None else self.bias.index_select(0, perm).contiguous())
             self._gated_key = key
+            self._gated_tiled, self._gated_tiled_key = None, None
             self._fast = {}
             _lib.bump_layout_epoch()
         return self._gated
+
+    @torch.no_grad()
+    def gated_tiled(self, hidden: int):
+        """Tile-major copy of the gate-interleaved weights (prefill row counts: qlinear_w8_fwd_tiled_gated) + the permuted scale and
+        bias; built on first use from ``gated()``, dropped with it."""
+        w, s, b = self.gated(hidden)
+        key = self._gated_key
+        if getattr(self, "_gated_tiled", None) is None or self._gated_tiled_key != key:
+            self._gated_tiled = hip_ops.tile_w8(w)
+            self._gated_tiled_key = key
+            _lib.bump_layout_epoch()
+        return self._gated_tiled, s, b
 
     @torch.no_grad()
     def apply_weights_(self, q_weight: Tensor, scale: Tensor, bias: Tensor = None):

@@ -365,11 +365,21 @@ class ChatGLM2Model(nn.Module):
         """Prefill row counts: ``h + mod(x)`` with the add in the int4g32 256 x 256-tile GEMM's epilogue (bit-equal to the two ops);
         None when module / shape are not served that way."""
         from .int4 import hip_ops as H4
+        from .int8 import hip_ops as H8
         from .int4.qlinear import DynamicQuantizeLinear as Q4
-        if not (isinstance(mod, Q4) and x.dtype in (torch.float16, torch.bfloat16) and mod._packed_supported() and not mod.act_quant
+        from .int8.qlinear import DynamicQuantizeLinear as Q8
+        if not (x.dtype in (torch.float16, torch.bfloat16) and isinstance(mod, (Q4, Q8)) and not mod.act_quant
                 and mod.weight_scale.dtype == x.dtype and h.dtype == x.dtype and h.shape[-1] == mod.out_features):
             return None
-        out = H4.w4_forward_tiled_residual(x, mod.tiled(), mod.out_features, mod.bias, h)
+        if isinstance(mod, Q4):
+            if not mod._packed_supported():
+                return None
+            out = H4.w4_forward_tiled_residual(x, mod.tiled(), mod.out_features, mod.bias, h)
+        else:
+            tiled = mod.prepare()._tiled
+            if tiled is None:
+                return None
+            out = H8.w8_forward_tiled_residual(x, tiled, mod.out_features, mod.weight_scale, mod.bias, h)
         return None if out is None else out.view(h.shape)
 
     @staticmethod
@@ -398,8 +408,15 @@ class ChatGLM2Model(nn.Module):
         when layer / shape are not served that way."""
         from .int4 import hip_ops as H4
         from .int4.qlinear import DynamicQuantizeLinear as Q4
+        from .int8.qlinear import DynamicQuantizeLinear as Q8
         from . import _lib
         w_in = ffn.w_in
+        if (isinstance(w_in, Q8) and x.dtype in (torch.float16, torch.bfloat16) and not w_in.act_quant and w_in.weight_scale.dtype == x.dtype
+                and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0 and w_in.in_features % 16 == 0
+                and x.numel() // x.shape[-1] >= 1024):     # int8 weight-only at prefill row counts: the same epilogue on the 256-tile GEMM
+            from .int8 import hip_ops as H8
+            tiled, s_perm, b_perm = w_in.gated_tiled(ffn.hidden_dim)
+            return H8.w8_forward_tiled_gated(x, tiled, w_in.out_features, s_perm, b_perm)
         if not (isinstance(w_in, Q4) and x.dtype in (torch.float16, torch.bfloat16) and w_in._packed_supported()
                 and not w_in.act_quant and w_in.weight_scale.dtype == x.dtype
                 and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0):

@@ -208,6 +208,15 @@ int qlinear_w8_fwd_tiled(const void* A, const void* tiled, const void* S, const 
  * aligned rows of A and M * lda * 2 < 2^31. */
 int qlinear_w8_fwd_tiled256(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                             int64_t K, int64_t lda, int64_t ldc, int dtype, void* stream);
+/* The int4 kernel's prefill epilogues for int8 weight-only (round 3): `tiled` = qlinear_w8_tile of the weights (for _gated: of the
+ * gate-interleaved row order (h_2t, h_2t+1, gate_2t, gate_2t+1), S and bias permuted alike; C is (M, N / 2), see
+ * qlinear_w4g32_fwd_tiled_gated); _residual: C = round(round(y) + residual), see qlinear_w4g32_fwd_tiled_residual.  Bit-equal to
+ * qlinear_w8_fwd_tiled followed by qlinear_silu_mul / an elementwise add.  QL_ERR_UNSUPPORTED unless the 256 x 256-tile kernel serves
+ * the row count. */
+int qlinear_w8_fwd_tiled_gated(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
+                               int64_t K, int64_t lda, int64_t ldc, int dtype, void* stream);
+int qlinear_w8_fwd_tiled_residual(const void* A, const void* tiled, const void* S, const void* bias, const void* residual, void* C,
+                                  int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, int64_t ldr, int dtype, void* stream);
 
 /* Few rows (batched decode: 2..32) through a first MLP projection with the SiLU * gate EPILOGUE: `packed` holds the
  * gate-interleaved column order (h_2t, h_2t+1, gate_2t, gate_2t+1), C gets N / 2 columns,

@@ -368,6 +368,44 @@ def test_gemm256_residual_epilogue_equals_separate_ops(dtype, bias, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("bias", [False, True])
+def test_int8_gemm256_gate_and_residual_epilogues_equal_separate_ops(dtype, bias):
+    """int8 weight-only at prefill row counts: qlinear_w8_fwd_tiled_gated (SiLU * gate on the gate-interleaved copy) and
+    qlinear_w8_fwd_tiled_residual against the module's own GEMM followed by silu_mul / the elementwise add - bit for bit
+    (chatglm_q/model.py:199-201,243-245 on chatglm_q/int8/qlinear.py:90-93)."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int8 import hip_ops as H8
+    from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear as Q8
+    g = torch.Generator(device=DEV).manual_seed(17)
+    K, hidden, M = 4096, 13696, 4096
+    layer = Q8(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(-128, 128, layer.weight.shape, dtype=torch.int8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(2 * hidden, device=DEV, generator=g) * 0.001 + 0.0002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(1, M, K, device=DEV, generator=g).to(dtype)
+    tiled, s_perm, b_perm = layer.gated_tiled(hidden)
+    got = H8.w8_forward_tiled_gated(x, tiled, 2 * hidden, s_perm, b_perm)
+    with torch.no_grad():
+        want = F_.silu_mul(layer(x), hidden)
+    assert got is not None and got.shape == (1, M, hidden)
+    assert torch.equal(got, want)
+    out = Q8(hidden, K, bias=bias, dtype=dtype, device=DEV)
+    out.weight.copy_(torch.randint(-128, 128, out.weight.shape, dtype=torch.int8, device=DEV, generator=g))
+    out.weight_scale.copy_((torch.rand(K, device=DEV, generator=g) * 0.001 + 0.0002).to(dtype))
+    if bias:
+        out.bias.copy_((torch.randn(K, device=DEV, generator=g) * 0.1).to(dtype))
+    M2 = 8192 - 24
+    y = torch.randn(1, M2, hidden, device=DEV, generator=g).to(dtype)
+    h = torch.randn(1, M2, K, device=DEV, generator=g).to(dtype)
+    got = H8.w8_forward_tiled_residual(y, out.prepare()._tiled, K, out.weight_scale, out.bias, h)
+    with torch.no_grad():
+        want = h + out(y)
+    assert got is not None and torch.equal(got, want)
+    assert H8.w8_forward_tiled_residual(y[:, :40], out.prepare()._tiled, K, out.weight_scale, out.bias, h[:, :40]) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
 @pytest.mark.parametrize("M", [3, 8, 32])
 def test_fewrow_gate_epilogue_equals_separate_ops(dtype, bias, M):
     """qlinear_w4g32_fwd_packed_gated (few rows, SiLU * gate in the MFMA kernel's epilogue) against the projection
