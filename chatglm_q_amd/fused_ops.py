@@ -223,10 +223,8 @@ def attention_tile_flags(mask: Tensor) -> Tensor:
         row_ok = torch.nn.functional.pad(row_ok, (0, nq * QB - S), value=True)
     skip = blocked.view(B, nq, QB, nk, KB).all(dim=4).all(dim=2) & row_ok.view(B, nq, QB).all(dim=2)[:, :, None]
     clear = zero.view(B, nq, QB, nk, KB).all(dim=4).all(dim=2)
-    flags = torch.ones((B, nq, nk), dtype=torch.uint8, device=mask.device)
-    flags[clear] = 2
-    flags[skip] = 0
-    return flags.contiguous()
+    # (torch.where, not masked assignment: no host synchronisation, capturable)
+    return torch.where(skip, 0, torch.where(clear, 2, 1)).to(torch.uint8).contiguous()
 
 
 def prefill_attention_supported(q_dtype, H: int, G: int, D: int) -> bool:
