@@ -115,7 +115,9 @@ class DecodeSession:
         self.pad_cols[:, self.length:self.length + S] = ~valid
         positions = self.n_tokens[:, None] + torch.cumsum(valid.long(), dim=1)       # 1-based among real tokens
         positions = torch.where(valid, positions, torch.zeros_like(positions))       # cumsum of a left pad is 0
-        chunk = chunk or S
+        # default: the whole prompt in one pass while that is at most 8192 rows per QLinear call (where the prefill GEMMs are at their
+        # best and the (batch, chunk, keys) mask stays small), otherwise chunks of 8192 // batch positions
+        chunk = chunk or (S if B * S <= 8192 else max(256, 8192 // B))
         t = torch.arange(self.capacity, device=self.device)
         logits = None
         for s0 in range(0, S, chunk):
