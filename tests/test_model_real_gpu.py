@@ -130,3 +130,20 @@ def test_config5_sampled_positions_inside_chunks(real_gpu):
                 want = f32(f"big/chunk{ci}_logits")
                 sel = valid[:, c0 + rows_s].cpu().numpy()                      # pad query rows are undefined by design
                 assert _err(f"config5 chunk {ci} sampled rows", got[sel], want[sel]) < TOL
+
+
+def test_default_prefill_chunking_bounds_a_pass_at_8192_rows(real_gpu):
+    """DecodeSession.prefill without a chunk length: the whole prompt while batch x positions <= 8192, chunks of 8192 // batch
+    positions beyond that - here 4 x 2300 = a pass of 2048 and one of 252 positions (the second one attends over a 2048-row
+    prefix through the one-launch attention) - against explicit chunks of 512."""
+    model, cfg = real_gpu
+    g = torch.Generator().manual_seed(23)
+    ids = torch.randint(0, cfg.vocab_size, (4, 2300), generator=g)
+    a = DecodeSession(model, 4, 2304, use_graph=False)
+    before = _lib.launch_count()
+    la = a.prefill(ids)
+    assert a.length == 2300 and _lib.launch_count() > before
+    b = DecodeSession(model, 4, 2304, use_graph=False)
+    lb = b.prefill(ids, chunk=512)
+    assert _err("default chunking vs chunks of 512, last logits", t2n(la), t2n(lb)) < TOL
+    assert _err("default chunking vs chunks of 512, cache rows", t2n(a.cache.k[1][:, :2300]), t2n(b.cache.k[1][:, :2300])) < TOL
