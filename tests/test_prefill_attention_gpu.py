@@ -139,3 +139,26 @@ def test_abi_rejects_other_geometries():
     st = lib.qlinear_prefill_attention(None, kc.data_ptr(), kc.data_ptr(), None, None, x.data_ptr(), 1, 16, 16, 32, 2, 128, 16, 0,
                                        _lib.dtype_code(torch.float16), _lib.stream_ptr(x.device))
     assert st == -1
+
+
+def test_random_shapes_and_pads_against_reference_sequence():
+    """Seeded sweep: random batch / chunk / prefix lengths, random left pads per sequence, with and without tile flags."""
+    import random
+    from chatglm_q_amd import fused_ops as F_
+    rng = random.Random(2024)
+    for case in range(14):
+        B = rng.choice([1, 2, 3])
+        S = rng.randint(1, 200)
+        prefix = rng.choice([0, 0, rng.randint(1, 300)])
+        T = prefix + S
+        cap = T + rng.randint(0, 70)
+        q, k, v = make(B, S, T, cap, torch.float16, seed=100 + case)
+        pad_cols = torch.zeros(B, cap, dtype=torch.bool, device="cuda")
+        for b in range(B):
+            pad_cols[b, : rng.choice([0, 0, rng.randint(1, max(1, T // 2))])] = True
+        mask = causal_mask(B, S, T, prefix, pad_cols)
+        flags = F_.attention_tile_flags(mask) if case % 2 == 0 else None
+        got = F_.prefill_attention(q, k, v, mask, flags, T, H, G, D)
+        want = reference(q, k, v, mask, T)
+        assert torch.isfinite(got.float()).all(), (case, B, S, T)
+        assert rel_l2(got, want) < 1.5e-3, (case, B, S, T, rel_l2(got, want))
