@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # QLINEAR_LIB_PATH: developer override (tools/: ablation builds of the same library); the package default is the in-tree build
 LIB_PATH = os.environ.get("QLINEAR_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
@@ -56,6 +56,9 @@ EXPORTS = {
     "qlinear_abi_version": (c_int, []),
     "qlinear_status_string": (c_char_p, [c_int]),
     "qlinear_launch_count": (c_uint64, []),
+    "qlinear_last_dispatch": (c_uint64, []),
+    "qlinear_dispatch_reset": (None, []),
+    "qlinear_dispatch_reload": (None, []),
     "qlinear_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "qlinear_w4g32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
@@ -72,6 +75,8 @@ EXPORTS = {
                                         c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w4g32_fwd_tiled256": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                            c_int, c_void_p]),
+    "qlinear_gemm256_serves": (c_int, [c_int64, c_int64, c_int64]),
+    "qlinear_tiled_dispatch": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p]),
     "qlinear_w4g32_fwd_tiled_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                          c_int64, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -2,6 +2,7 @@
 // Contract: include/qlinear_hip.h.  Nothing here allocates, synchronises or touches the default
 // stream; every launch goes to the caller's stream.
 #include <atomic>
+#include <cstring>
 
 #include "launch.h"
 #include "../../include/qlinear_hip.h"
@@ -9,11 +10,48 @@
 namespace ql {
 
 static std::atomic<uint64_t> g_launches{0};
+static thread_local uint64_t t_dispatch_log = 0;       // newest launch in the low byte (qlinear_last_dispatch)
 
-int finish_launch() {
+int finish_launch(int kernel_family) {
     g_launches.fetch_add(1, std::memory_order_relaxed);
+    t_dispatch_log = (t_dispatch_log << 8) | (uint64_t)(kernel_family & 0xFF);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? QL_OK : (int)e;
+}
+
+// QLINEAR_DISPATCH (tune.h): the one environment variable the product library reads
+static unsigned parse_dispatch_env() {
+    const char* e = getenv("QLINEAR_DISPATCH");
+    unsigned v = 0x80000000u;                          // "parsed" marker
+    if (!e) return v;
+    if (strstr(e, "no256")) v |= QL_D_NO256;
+    if (strstr(e, "nopeel")) v |= QL_D_NOPEEL;
+    if (strstr(e, "nofewrow")) v |= QL_D_NOFEWROW;
+    if (strstr(e, "norows4")) v |= QL_D_NOROWS4;
+    if (strstr(e, "nogroupattn")) v |= QL_D_NOGROUPATTN;
+    return v;
+}
+static std::atomic<unsigned> g_dispatch{0};
+unsigned dispatch_flags() {
+    unsigned v = g_dispatch.load(std::memory_order_relaxed);
+    if (!v) {
+        v = parse_dispatch_env();
+        g_dispatch.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// CU count of the current device: the idempotent per-device property cache the ABI allows.  256 (the MI355X this
+// library is written for) when no device answers, so that the host-side planning functions stay usable without a GPU.
+int cu_count() {
+    static std::atomic<int> cache[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -51,6 +89,10 @@ const char* qlinear_status_string(int status) {
 }
 
 uint64_t qlinear_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
+uint64_t qlinear_last_dispatch(void) { return t_dispatch_log; }
+void qlinear_dispatch_reset(void) { t_dispatch_log = 0; }
+void qlinear_dispatch_reload(void) { g_dispatch.store(parse_dispatch_env(), std::memory_order_relaxed); }
 
 size_t qlinear_workspace_bytes(int op, int64_t M, int64_t N, int64_t K, int64_t group) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -153,6 +195,29 @@ int qlinear_w4g32_fwd_tiled256(const void* A, const void* tiled, const void* bia
     if (!aligned(tiled, 16) || !act_vec_ok(A, lda, dtype)) return QL_ERR_MISALIGNED;
     if (!w4_gemm256_can_run(M, N, K, lda, A, esize(dtype))) return QL_ERR_UNSUPPORTED;
     return w4_gemm256(dtype, A, tiled, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+}
+
+int qlinear_gemm256_serves(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return w4_gemm256_supported(M, N, K, K, nullptr, 2) ? 1 : 0;
+}
+
+int qlinear_tiled_dispatch(int weight_bits, int64_t M, int64_t N, int64_t K, int64_t* rows_first) {
+    if (M <= 0 || N <= 0 || K <= 0 || (weight_bits != 4 && weight_bits != 8)) return 0;
+    int64_t first = M;
+    int family;
+    if (weight_bits == 4) {
+        if (w4_fewrow_supported(M, N, K)) family = QL_K_W4_FEWROW;
+        else {
+            const int64_t m256 = w4_gemm256_rows(M, N, K, K, nullptr, 2);
+            family = m256 > 0 ? QL_K_W4_GEMM256 : QL_K_W4_GEMM128;
+            if (m256 > 0) first = m256;
+        }
+    } else {
+        family = M <= 32 ? QL_K_W8_FEWROW : (w4_gemm256_supported(M, N, K, K, nullptr, 2) ? QL_K_W8_GEMM256 : QL_K_W8_GEMM128);
+    }
+    if (rows_first) *rows_first = first;
+    return family;
 }
 
 int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,

@@ -1096,22 +1096,23 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
     const float sq = sqrtf((float)D);
     const int nwin = split_ws ? (int)((capacity + kAttnWindow - 1) / kAttnWindow) : 1;
     if constexpr (ROPE && sizeof(T) == 2) {
-        // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_ATTENTION_MFMA=0: per-head kernels)
-        const char* mfma_env = getenv("QLINEAR_ATTENTION_MFMA");
+        // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_DISPATCH=nogroupattn: per-head kernels)
         const bool one_window = capacity <= kAttnWindow;
-        if (D == 128 && H == 16 * G && H < 65536 && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(mfma_env && atoi(mfma_env) == 0)) {
+        if (D == 128 && H == 16 * G && H < 65536 && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(dispatch_flags() & QL_D_NOGROUPATTN)) {
             // prefetch workgroups: about one per CU (they only issue loads); none without a descriptor, none when the
             // attention itself fills the chip (windows of a long context, large batches: measured slower)
             const int att_blocks = (int)(B * G);
             const int hg = (int)H | ((int)G << 16);
             const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < 256 ? ((pf.blocks + 7) & ~7) : 256) : 0;
             dim3 gridg((unsigned)(att_blocks + npf), (unsigned)(one_window ? 1 : nwin));
-            static const int waves = [] { const char* e = getenv("QLINEAR_ATTENTION_WAVES"); return e ? atoi(e) : 8; }();
-            if (waves == 4)
+            // 8 waves x 32 positions: 6.3 us against 6.6 for 4 x 64 (the kernel is one dependent chain; LABNOTES r2)
+#ifdef QL_DEV_TUNING
+            if (QL_TUNE("QLINEAR_ATTENTION_WAVES", 8) == 4)
                 decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
                                                                          (T*)Out, one_window ? nullptr : split_ws, pf);
             else
+#endif
                 decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
                                                                          (int)capacity, (int)ldq, (const T*)table, mask, sq,
                                                                          (T*)Out, one_window ? nullptr : split_ws, pf);

@@ -2,14 +2,18 @@
 #pragma once
 #include <cstdlib>
 #include <hip/hip_runtime.h>
+
+#include "tune.h"
 #include <stddef.h>
 #include <stdint.h>
 
 namespace ql {
 
-// Every kernel launch funnels through this: bumps the launch counter and turns the launch status
-// into the ABI's return convention (0 OK, >0 hipError_t).
-int finish_launch();
+// Every kernel launch funnels through this: bumps the launch counter, notes WHICH kernel family ran (QL_K_*,
+// include/qlinear_hip.h: qlinear_last_dispatch) and turns the launch status into the ABI's return convention
+// (0 OK, >0 hipError_t).
+int finish_launch(int kernel_family = 1 /* QL_K_OTHER */);
+int cu_count();   // of the current device (cached per device, abi.hip)
 
 // activation prologue / gate epilogue of the one-row fused GEMVs (w4_packed.hip, w8_kernels.hip)
 enum { PRO_NONE = 0, PRO_SILU = 1, PRO_ADDNORM = 2, PRO_NORM = 3 };   // PRO_NORM: ADDNORM without delta / hout (internal)
@@ -128,13 +132,12 @@ int w8_gemv(int dtype, const void* A, const int8_t* W, const void* S, const void
 // (few rows: the launch is bound by the weight stream and needs memory-level parallelism, not MFMA rate), K is
 // split over blockIdx.z into fp32 slabs in the workspace and a second launch sums them.  `per` = K steps
 // (64 k each) per slab.  No or too small a workspace degrades to ksplit = 1.
-// QLINEAR_GEMM_MT / QLINEAR_GEMM_KSPLIT override (tuning sweeps).
+// Developer build: QLINEAR_GEMM_MT / QLINEAR_GEMM_KSPLIT override (tune.h).
 struct GemmPlan {
     int mt, ksplit, per;
 };
 inline GemmPlan gemm_plan(int64_t M, int64_t N, int64_t ksteps, size_t ws_bytes) {
-    static const int forced_mt = [] { const char* e = getenv("QLINEAR_GEMM_MT"); return e ? atoi(e) : 0; }();
-    static const int forced_ks = [] { const char* e = getenv("QLINEAR_GEMM_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int forced_mt = QL_TUNE("QLINEAR_GEMM_MT", 0), forced_ks = QL_TUNE("QLINEAR_GEMM_KSPLIT", 0);
     const int64_t nb = (N + 127) / 128;
     int mt = 1;
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4 || forced_mt == 8) mt = forced_mt;
@@ -161,6 +164,7 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
 // w4_gemm256.hip: many rows (prefill) on 256 x 256 tiles, weights dequantised once per block into LDS, A by LDS-DMA
 bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
+int64_t w4_gemm256_rows(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);   // w4_gemm.hip: 0 / peel / M
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                int64_t ldc, hipStream_t st);
 int w4_gemm256_residual(int dtype, const void* A, const void* tiled, const void* bias, const void* resid, void* C, int64_t M, int64_t N,

@@ -252,7 +252,7 @@ struct FewRowPlan {
 constexpr int kFewRowWaves = 4;
 // global K split: aim at >= ~2048 waves (8 per CU), at least 2 K steps per wave
 static FewRowPlan fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
-    static const int forced = [] { const char* e = getenv("QLINEAR_FEWROW_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int forced = QL_TUNE("QLINEAR_FEWROW_KSPLIT", 0);
     const int nt = fewrow_nt(N);
     const int64_t ksteps = (K / 32 + 1) / 2, nb = (N + 32 * nt - 1) / (32 * nt);
     int64_t ks = forced > 0 ? forced : (2048 + nb * kFewRowWaves - 1) / (nb * kFewRowWaves);
@@ -265,10 +265,9 @@ static FewRowPlan fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) 
 
 // Measured against w4_packed_gemm (one 32-row tile + split-K over workgroups, fragments fetched per column), ChatGLM2-6B
 // shapes, fp16, us at 8 rows: 4096->4608 9.5 vs 12.8, 4096->4096 8.7 vs 11.6, 4096->27392 21.0 vs 27.9,
-// 13696->4096 14.3 vs 20.6 (the GEMV at ONE row: 5.3 / 4.7 / 14.1 / 10.2).  QLINEAR_FEWROW=0 disables it.
+// 13696->4096 14.3 vs 20.6 (the GEMV at ONE row: 5.3 / 4.7 / 14.1 / 10.2).  QLINEAR_DISPATCH=nofewrow disables it.
 bool w4_fewrow_supported(int64_t M, int64_t N, int64_t K) {
-    static const bool on = [] { const char* e = getenv("QLINEAR_FEWROW"); return !e || atoi(e) != 0; }();
-    return on && M <= 32 && K >= 512;       // two row tiles (33..64 rows) measured no better than the tiled GEMM
+    return !(dispatch_flags() & QL_D_NOFEWROW) && M <= 32 && K >= 512;       // two row tiles (33..64 rows) measured no better than the tiled GEMM
 }
 
 size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -292,11 +291,11 @@ static int launch_fewrow_nt(const void* A, const void* tiled, const void* bias, 
     static_assert((KW - 1) * MT * NT * 16 * 64 * 4 <= KW * 8192 * MT, "reduction scratch fits in the A buffers");
     w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
                                                             (const T*)bias, (T*)C, ldc, part, gate ? 1 : 0);
-    const int rc = finish_launch();
+    const int rc = finish_launch(QL_K_W4_FEWROW);
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
     splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
 template <typename T>

@@ -317,36 +317,44 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
     w4_packed_gemm_kernel<T, MT, NT, NW, QL_GEMM_DEPTH><<<grid, NW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
         xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5), (const T*)bias, (T*)C, ldc, part);
-    const int rc = finish_launch();
+    const int rc = finish_launch(QL_K_W4_GEMM128);
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
     splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
+
+// Prefill-sized row counts go to the 256 x 256-tile kernel (w4_gemm256.hip), which pays in whole rounds of cu_count() workgroups.
+// When the last round would be less than 40 % full (qkv_proj at 8192 rows: 576 workgroups = 2.25 rounds at the price of 3), only
+// the row tiles that fill the whole rounds go to it and the remaining rows to the 128-row-tile kernel as a second launch (same
+// dequantised weights and fp32 sums; the two kernels add in different orders, so a row's last bit may depend on which one served
+// it).  Returns the rows of the 256-tile launch: 0 = none, M = all, in between = peel.  QLINEAR_DISPATCH=nopeel: never peel.
+int64_t w4_gemm256_rows(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize) {
+    if (!w4_gemm256_supported(M, N, K, lda, A, esize)) return 0;
+    const int64_t nbx = (N + 255) / 256, nby = (M + 255) / 256, blocks = nbx * nby;
+    const int64_t cus = cu_count(), full = blocks / cus, tail = blocks - full * cus;
+    const int64_t nby_main = full * cus / nbx, m_main = nby_main * 256;
+    if ((dispatch_flags() & QL_D_NOPEEL) || full < 1 || tail == 0 || tail * 10 > cus * 4 || nby_main < 1 || m_main >= M) return M;
+    return m_main;
+}
 
 template <typename T>
 static int launch_gemm_any(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool can_recurse = true) {
-    if (can_recurse && w4_gemm256_supported(M, N, K, lda, A, sizeof(T))) {    // prefill-sized row counts: 256 x 256 tiles (w4_gemm256.hip)
-        // That kernel pays in whole rounds of 256 workgroups.  When the last round would be less than 40 % full (qkv_proj at 8192 rows:
-        // 576 workgroups = 2.25 rounds at the price of 3), the row tiles that fill the whole rounds go to it and the remaining rows to
-        // the 128-row-tile kernel below as a second launch (same dequantised weights and fp32 sums; the two kernels add in different
-        // orders, so a row's last bit may depend on which one served it).  QLINEAR_GEMM_PEEL=0: one launch (A/B measurements).
-        static const int no_peel = [] { const char* e = getenv("QLINEAR_GEMM_PEEL"); return e && atoi(e) == 0; }();
-        const int64_t nbx = (N + 255) / 256, nby = (M + 255) / 256, blocks = nbx * nby;
-        const int64_t full = blocks / 256, tail = blocks - full * 256;
-        const int64_t nby_main = full * 256 / nbx, m_main = nby_main * 256;
-        if (no_peel || full < 1 || tail == 0 || tail * 10 > 256 * 4 || nby_main < 1 || m_main >= M)
-            return w4_gemm256(Act<T>::code, A, tiled, bias, C, M, N, K, lda, ldc, st);
-        const int rc = w4_gemm256(Act<T>::code, A, tiled, bias, C, m_main, N, K, lda, ldc, st);
-        if (rc != 0) return rc;
-        return launch_gemm_any<T>((const T*)A + m_main * lda, tiled, bias, (T*)C + m_main * ldc, M - m_main, N, K, lda, ldc, ws, ws_bytes, st,
-                                  false);
+    if (can_recurse) {
+        const int64_t m_main = w4_gemm256_rows(M, N, K, lda, A, sizeof(T));      // rows the 256 x 256-tile kernel takes (0: none)
+        if (m_main >= M) return w4_gemm256(Act<T>::code, A, tiled, bias, C, M, N, K, lda, ldc, st);
+        if (m_main > 0) {                                                          // "peel": the rest as a second launch below
+            const int rc = w4_gemm256(Act<T>::code, A, tiled, bias, C, m_main, N, K, lda, ldc, st);
+            if (rc != 0) return rc;
+            return launch_gemm_any<T>((const T*)A + m_main * lda, tiled, bias, (T*)C + m_main * ldc, M - m_main, N, K, lda, ldc, ws, ws_bytes,
+                                      st, false);
+        }
     }
     const GemmPlan plan = gemm_plan(M, N, (K / 32 + 1) / 2, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
-    static const int forced_nt = [] { const char* e = getenv("QLINEAR_GEMM_NT"); return e ? atoi(e) : 0; }();
-    static const int forced_nw = [] { const char* e = getenv("QLINEAR_GEMM_NW"); return e ? atoi(e) : 0; }();   // 4: two 4-wave blocks per CU (measurement)
+    const int forced_nt = QL_TUNE("QLINEAR_GEMM_NT", 0);
+    const int forced_nw = QL_TUNE("QLINEAR_GEMM_NW", 0);   // 4: two 4-wave blocks per CU (measurement)
     if (forced_nt == 2 && plan.mt == 4)       // 64 columns per wave: every A fragment feeds two MFMAs (experiment)
         return launch_gemm<T, 4, 2, 4>(A, tiled, bias, C, (int)M, (int)N, (int)K, lda, ldc, plan, (float*)ws, st);
     if (forced_nt == 2 && plan.mt == 2)

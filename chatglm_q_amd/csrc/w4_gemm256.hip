@@ -412,14 +412,13 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     }();
     (void)attr_set;
     const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
-    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
-    static const int sy_env = [] { const char* e = getenv("QLINEAR_GEMM_SY"); return e ? atoi(e) : 0; }();            // tuning sweeps
-    const int sy = sy_env > 0 ? sy_env : 4;            // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
+    const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);      // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
-    return finish_launch();
+    return finish_launch(QL_K_W4_GEMM256);
 }
 
 template <typename T, bool GATE = false>
@@ -431,13 +430,13 @@ static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, con
     }();
     (void)attr_set;
     const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
-    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
-    const int sy = 4;
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
+    const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w4_gemm256_kernel<T, true, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
-    return finish_launch();
+    return finish_launch(QL_K_W8_GEMM256);
 }
 
 // int8 weight-only with the epilogues of the int4 kernel: SiLU * gate on a gate-interleaved copy (C (M, N / 2)), residual add
@@ -471,17 +470,16 @@ int w8_gemm256(int dtype, const void* A, const int8_t* Wm, const void* S, const 
 // rows / shapes the 256 x 256 kernel takes (the launcher in w4_gemm.hip asks): whole 64-deep K tiles, 16-byte aligned rows,
 // 32-bit byte offsets into A, and enough 256-row tiles to fill the chip
 bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize) {
-    static const int off = [] { const char* e = getenv("QLINEAR_GEMM_256"); return e && atoi(e) == 0; }();         // A/B switch
-    if (off || esize != 2 || K % 64 != 0 || K < 128 || (lda * (int64_t)esize) % 16 != 0 || ((uintptr_t)A & 15) != 0) return false;
+    if ((dispatch_flags() & QL_D_NO256) || esize != 2 || K % 64 != 0 || K < 128 || (lda * (int64_t)esize) % 16 != 0 || ((uintptr_t)A & 15) != 0) return false;
     if (M * lda * (int64_t)esize >= ((int64_t)1 << 31)) return false;
     const int64_t blocks = ((N + 255) / 256) * ((M + 255) / 256);
-    static const int min_blocks = [] { const char* e = getenv("QLINEAR_GEMM_256_MIN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    const int min_blocks = QL_TUNE("QLINEAR_GEMM_256_MIN_BLOCKS", 0);   // tuning sweeps (developer build)
     if (min_blocks > 0) return M >= 256 && blocks >= min_blocks;
-    // one block per CU at a time (128 KB of LDS): the grid pays in whole rounds of 256 blocks.  Measured against the 128-row-tile
+    // one block per CU at a time (128 KB of LDS): the grid pays in whole rounds of cu_count() (256) blocks.  Measured against the 128-row-tile
     // kernel (tools/prefill_gemm_ab.py, M = 1024 .. 8192 x the four layer shapes): ahead from one full round on when the last
     // round is at least ~70 % full (256 blocks +11 %, 428 +13 %, 576 +3.5 %, 856 +3 %), behind below that (288 blocks -9 %, 128 -25 %)
-    const int64_t rounds = (blocks + 255) / 256;
-    return blocks >= 256 && blocks * 10 >= rounds * 256 * 7;
+    const int64_t cus = cu_count(), rounds = (blocks + cus - 1) / cus;
+    return blocks >= cus && blocks * 10 >= rounds * cus * 7;
 }
 
 // what the kernel itself needs (the dispatch heuristic above is a speed choice on top of this)

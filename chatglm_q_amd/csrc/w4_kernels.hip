@@ -200,7 +200,7 @@ static int launch_w4_generic(const void* A, const uint8_t* Wq, const void* S, co
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)M);
     w4_generic_kernel<T><<<grid, 256, 0, st>>>((const T*)A, Wq, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N,
                                                (int)K, (int)group, lda, ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W4_GENERIC);
 }
 
 template <typename T, int MB>
@@ -210,11 +210,11 @@ static int launch_w4_canon_mb(const T* A, const uint8_t* Wq, const T* S, const T
     const int ksplit = (G + 15) / 16;
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)ksplit, (unsigned)((M + MB - 1) / MB));
     w4_canon_kernel<T, MB><<<grid, 256, 0, st>>>(A, Wq, S, bias, C, ws, M, N, K, G, lda, ldc, ksplit);
-    int rc = finish_launch();
+    int rc = finish_launch(QL_K_W4_CANON);
     if (rc != 0 || ksplit == 1) return rc;
     const int64_t total = (int64_t)M * N;
     splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ws, bias, C, M, N, ldc, ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
 size_t w4_canon_workspace_bytes(int64_t M, int64_t N, int64_t K) {

@@ -747,25 +747,17 @@ struct PackedArgs {
 };
 
 #ifdef QL_DEV_VARIANTS
-static int dev_variant() {
-    static const int v = [] { const char* e = getenv("QL_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
+static int dev_variant() { return QL_TUNE("QL_VARIANT", 0); }
 #endif
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // K slices per block: as many as keep every lane of a wave busy (>= 64 groups per slice) while the
-// grid is still small (fewer than ~4 blocks per CU); QLINEAR_W4_KSPLIT overrides for measurements.
+// grid is still small (fewer than ~4 blocks per CU); developer build: QLINEAR_W4_KSPLIT overrides for measurements.
 // Every block stages its MB activation rows (MB * K values) into LDS.  Once that tile is large enough to limit the
 // blocks per CU (> 40 KB: w_out with 2 rows, 55 KB) more, smaller blocks only multiply the staging traffic (1024
 // blocks x 55 KB = 56 MB against 28 MB of weights: 20.4 us instead of 13.9), so the split is halved until the staged
 // bytes no longer exceed the weight bytes.  Small tiles keep the finer split (qkv_proj, 4 rows: 11.5 vs 14.1 us).
 static int choose_ksplit(int64_t quads, int64_t G, int mb = 1) {
-    static const int forced = env_int("QLINEAR_W4_KSPLIT", 0);
+    const int forced = QL_TUNE("QLINEAR_W4_KSPLIT", 0);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     int ks = 1;
     while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 1024) ks *= 2;
@@ -817,7 +809,7 @@ static int launch_16(const PackedArgs& p) {
     w4_packed_gemv_16_kernel<T, MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const T*)p.A, Wt, Sp, nullptr, nullptr, p.N, p.K, p.M,
                                                                                (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, nullptr, 0.f, 0,
                                                                                (const T*)p.resid);
-    return finish_launch();
+    return finish_launch(QL_K_W4_GEMV);
 }
 
 template <typename T, int MB, int KS, bool STRICT>
@@ -859,7 +851,7 @@ static int launch_generic_mb(const PackedArgs& p) {
     dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
     w4_packed_gemv_kernel<T, MB><<<grid, 256, 0, p.st>>>((const T*)p.A, Wt, Sp, (const T*)p.bias, (T*)p.C, p.M, p.N,
                                                          p.K, (int)G, p.lda, p.ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W4_GEMV);
 }
 
 // one-row forward with an activation prologue (decode step)
@@ -875,7 +867,7 @@ static int launch_16_pro(const PackedArgs& p, const Prologue& pro) {
     w4_packed_gemv_16_kernel<T, 1, ACH, KS, STRICT, 0, PRO><<<grid, 256, lds, p.st>>>(
         (const T*)p.A, Wt, Sp, pro.delta, pro.ln_weight, p.N, p.K, 1, (int)p.lda, (const T*)p.bias, (T*)p.C, p.ldc, pro.hout, pro.eps,
         pro.gate_epilogue);
-    return finish_launch();
+    return finish_launch(QL_K_W4_GEMV);
 }
 
 template <typename T, int PRO, bool STRICT>
@@ -895,6 +887,7 @@ static int launch_16_pro_any(const PackedArgs& p, const Prologue& pro) {
 #undef QL_PRO
 }
 
+#ifdef QL_DEV_EXPERIMENTS      // libqlinear_hip_dev.so only (include/qlinear_hip_dev.h): measured 27.5 vs 23.0 us, profiles/r02_mlp_pair.txt
 // ---------------------------------------------------------------------------------------------
 // The MLP of a decode step in ONE launch (experiment): blocks [0, nA) run the first projection (RMSNorm
 // prologue, SiLU * gate epilogue on the gate-interleaved copy) and publish its (1, hidden) row; the remaining blocks run
@@ -959,6 +952,8 @@ int w4_mlp_pair(int dtype, const void* x, const void* ln_weight, float eps, cons
     if (dtype == QL_DTYPE_BF16) return launch_mlp_pair<__bf16>(x, ln_weight, eps, packed_a, bias_a, Na, Ka, packed_b, bias_b, Nb, Kb, resid, mid, out, ws, st);
     return QL_ERR_BAD_DTYPE;
 }
+
+#endif  // QL_DEV_EXPERIMENTS
 
 template <typename T, bool STRICT>
 static int w4_packed_fused_t(int kind, const PackedArgs& p, const Prologue& pro) {
@@ -1038,8 +1033,9 @@ int w4_packed_residual(int dtype, bool strict, const void* A, const void* packed
 // staged rows stay small (K <= 8192: w_out's 13696-deep rows are the case that loses).  QLINEAR_ROWS4_MIN / _MAX move the
 // row range (MAX = 0 turns the kernel off).
 bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict) {
-    static const int r4_min = env_int("QLINEAR_ROWS4_MIN", 2), r4_max = env_int("QLINEAR_ROWS4_MAX", 4);
-    return !strict && M >= r4_min && M <= r4_max && (M <= 2 || M * K * 2 <= 64 * 1024) && w4_rows4_supported(dtype, M, N, K, lda);
+    // 2..4 rows: measured against the GEMV (2 rows) and the few-row kernel (3, 4 rows), profiles/r02_rows_2_to_4.txt
+    const int r4_min = QL_TUNE("QLINEAR_ROWS4_MIN", 2), r4_max = QL_TUNE("QLINEAR_ROWS4_MAX", 4);
+    return !strict && !(dispatch_flags() & QL_D_NOROWS4) && M >= r4_min && M <= r4_max && (M <= 2 || M * K * 2 <= 64 * 1024) && w4_rows4_supported(dtype, M, N, K, lda);
 }
 
 int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
@@ -1056,7 +1052,7 @@ int w4_rows4_fused(int dtype, bool gate, const void* A, const void* packed, cons
 }
 
 bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
-    static const int forced = [] { const char* e = getenv("QLINEAR_GEMV_MAX_ROWS"); return e ? atoi(e) : -1; }();
+    const int forced = QL_TUNE("QLINEAR_GEMV_MAX_ROWS", -1);
     if (forced >= 0) return M > forced;
     (void)N;
     (void)K;

@@ -352,7 +352,7 @@ static int launch_rows4_ks(const void* A, const void* packed, const void* bias, 
     w4_rows4_kernel<T, KS, RING, NQ, NW, MR, PRO><<<(unsigned)((quads + per_block - 1) / per_block), NW * 64, lds, st>>>(
         (const T*)A, Wt, Sp, N, K, M, (int)lda, (const T*)bias, (T*)C, ldc, gate ? 1 : 0, (const T*)pro.delta, (const T*)pro.ln_weight,
         (T*)pro.hout, pro.eps);
-    return finish_launch();
+    return finish_launch(QL_K_W4_ROWS4);
 }
 
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda) {
@@ -380,7 +380,7 @@ int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* b
     QL_R4K(T_, 1, 0)
     // one quad per wave; two (QLINEAR_ROWS4_NQ=2: shared activation fragments, half the blocks) measured slower on every
     // layer shape but w_out at one row (2 rows: 7.2 / 5.8 / 18.4 / 13.3 us against 6.5 / 5.8 / 17.1 / 11.8)
-    static const int nq = [] { const char* e = getenv("QLINEAR_ROWS4_NQ"); return e && atoi(e) == 2 ? 2 : 1; }();
+    const int nq = QL_TUNE("QLINEAR_ROWS4_NQ", 1) == 2 ? 2 : 1;
     if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
     if (ln_weight && (K > 8192 || QL_ROWS4_WAVES != 8)) return QL_ERR_UNSUPPORTED;
     if (dtype == QL_DTYPE_F16) { QL_R4(f16) }

@@ -486,7 +486,7 @@ static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* pa
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
-    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = NG == 1 ? 8 : 4;
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;    // ql_common.h: xcd_tile_super
     w4a8_kernel<T, MT, DEPTH, NG, COLG><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
@@ -498,8 +498,7 @@ static int launch_w4a8_mt(const int8_t* Aq, const float* a_scale, const void* pa
 template <typename T>
 static int launch_w4a8(const int8_t* Aq, const float* a_scale, const void* packed, const void* bias, void* C, int64_t M,
                        int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W4A8_MT"); return e ? atoi(e) : 0; }();
-    static const int forced_ng = [] { const char* e = getenv("QLINEAR_W4A8_NG"); return e ? atoi(e) : 0; }();
+    const int forced_mt = QL_TUNE("QLINEAR_W4A8_MT", 0), forced_ng = QL_TUNE("QLINEAR_W4A8_NG", 0);
     const int64_t nb = (N + 127) / 128;
     int mt = 1;
     for (int t = 4; t > 1; t >>= 1)
@@ -508,7 +507,7 @@ static int launch_w4a8(const int8_t* Aq, const float* a_scale, const void* packe
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
     int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
     if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
-    static const int colg = [] { const char* e = getenv("QLINEAR_W4A8_COLG"); return e ? atoi(e) : 0; }();
+    const int colg = QL_TUNE("QLINEAR_W4A8_COLG", 0);
     if (mt == 4 && colg == 1) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 2, true>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
     if (mt == 4 && ng == 1) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 1>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);
     if (mt == 4) return launch_w4a8_mt<T, 4, QL_W4A8_DEPTH4, 2>(Aq, a_scale, packed, bias, C, M, N, K, ldc, st);

@@ -295,11 +295,11 @@ static int launch_w8_gemm(const void* A, const int8_t* W, const void* S, const v
     dim3 grid((unsigned)(nbx * nby), 1, (unsigned)plan.ksplit);
     w8_gemm_kernel<T, MT, NW, 3, SK, TILED><<<grid, NW * 64, 0, st>>>((const T*)A, W, (const T*)S, M, N, K, (int)ldw, (int)lda, plan.per,
         xcd_order(nbx, nby, (double)M * K * 2, (double)N * K), (const T*)bias, (T*)C, ldc, part);
-    const int rc = finish_launch();
+    const int rc = finish_launch(QL_K_W8_GEMM128);
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
     splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
 template <typename T>
@@ -354,8 +354,7 @@ static int launch_w8_gemm_tiled(const void* A, const int8_t* Wm, const void* S, 
 
 int w8_gemm_tiled(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    static const int off256 = [] { const char* e = getenv("QLINEAR_W8_256"); return e && atoi(e) == 0; }();         // A/B switch
-    if (!off256 && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && w4_gemm256_supported(M, N, K, lda, A, 2))
+    if ((dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && w4_gemm256_supported(M, N, K, lda, A, 2))
         return w8_gemm256(dtype, A, Wm, S, bias, C, M, N, K, lda, ldc, st);     // prefill row counts: 256 x 256 tiles (w4_gemm256.hip)
     switch (dtype) {
     case QL_DTYPE_F16: return launch_w8_gemm_tiled<f16>(A, Wm, S, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st);
@@ -565,11 +564,11 @@ static int launch_w8_fewrow(const void* A, const int8_t* Wm, const void* S, cons
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)plan.ksplit);
     w8_fewrow_kernel<T, KW><<<grid, KW * 64, (size_t)KW * 8192, st>>>((const T*)A, Wm, (const T*)S, M, N, K, lda, plan.per,
                                                                       (const T*)bias, (T*)C, ldc, part);
-    const int rc = finish_launch();
+    const int rc = finish_launch(QL_K_W8_FEWROW);
     if (rc != 0 || !part) return rc;
     const int64_t total = (int64_t)M * N;
     splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, (const T*)bias, (T*)C, M, N, ldc, plan.ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
 // rows >= 3 on the tile-major copy: few-row kernel up to 32 rows, tiled GEMM above

@@ -745,7 +745,7 @@ static int launch_w8_generic(const void* A, const int8_t* W, const void* S, cons
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)M);
     w8_generic_kernel<T><<<grid, 256, 0, st>>>((const T*)A, W, (const T*)S, (const T*)bias, (T*)C, (int)M, (int)N,
                                                (int)K, ldw_k, ldw_n, lda, ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W8_GENERIC);
 }
 
 struct W8Args {
@@ -767,7 +767,7 @@ static int launch_w8_gemv_generic(const W8Args& p) {
     dim3 grid((unsigned)((quads + 3) / 4), (unsigned)((p.M + MB - 1) / MB));
     w8_gemv_kernel<T, MB><<<grid, 256, 0, p.st>>>((const T*)p.A, p.W, (const T*)p.S, (const T*)p.bias, (T*)p.C, p.M,
                                                   p.N, p.K, p.ldw, p.lda, p.ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W8_GEMV);
 }
 
 template <int MB, int ACH, int KS, bool STRICT>
@@ -781,7 +781,7 @@ static int launch_w8_gemv_f16(const W8Args& p) {
     w8_gemv_f16_kernel<MB, ACH, KS, STRICT><<<grid, 256, lds, p.st>>>((const f16*)p.A, p.W, nullptr, nullptr, p.N, p.K, p.M, (int)p.ldw,
                                                           (int)p.lda, (const f16*)p.S, (const f16*)p.bias, (f16*)p.C, p.ldc,
                                                           nullptr, 0.f, 0, (const f16*)p.resid);
-    return finish_launch();
+    return finish_launch(QL_K_W8_GEMV);
 }
 
 template <int ACH, int KS, int PRO = PRO_ADDNORM>
@@ -796,7 +796,7 @@ static int launch_w8_gemv_fused(const W8Args& p, const Prologue& pro) {
                                                                                 p.K, 1, (int)p.ldw, (int)p.lda, (const f16*)p.S,
                                                                                 (const f16*)p.bias, (f16*)p.C, p.ldc, pro.hout,
                                                                                 pro.eps, pro.gate_epilogue);
-    return finish_launch();
+    return finish_launch(QL_K_W8_GEMV);
 }
 
 template <int MB, bool STRICT>
@@ -804,7 +804,7 @@ static int launch_w8_gemv_f16_st(const W8Args& p) {
     const int64_t pieces = (int64_t)MB * ((p.K & ~15) / 8);
     const bool lds_ok = (size_t)MB * p.K * sizeof(f16) <= 64 * 1024 && pieces > 0;
     // split K two ways inside the block while the plain grid is small and every lane keeps >= 1 chunk
-    static const int forced = [] { const char* e = getenv("QLINEAR_W8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int forced = QL_TUNE("QLINEAR_W8_KSPLIT", 0);
     const int64_t quads = (p.N + 3) / 4;
     const bool split = forced ? forced == 2 : ((p.K >> 4) >= 128 && quads / 2 < 1024);
     if (split) {
@@ -825,7 +825,7 @@ static int launch_w8_gemv_f16_mb(const W8Args& p) {
 
 // how the one-row fp16 kernel walks the weights (Prefetch, launch.h): 4 / KS channel quads of ldw bytes per workgroup
 void w8_gemv_blocks(int64_t N, int64_t K, int64_t ldw, int64_t* w_block_bytes, int64_t* blocks) {
-    static const int forced = [] { const char* e = getenv("QLINEAR_W8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int forced = QL_TUNE("QLINEAR_W8_KSPLIT", 0);
     const int64_t quads = (N + 3) / 4;
     const bool split = forced ? forced == 2 : ((K >> 4) >= 128 && quads / 2 < 1024);
     const int qw = split ? 2 : 4;
@@ -875,8 +875,7 @@ struct W8A8Plan {
 // rows per block: large tiles once they still give >= ~1 block per CU, smaller ones to fill the chip; when even
 // those leave most CUs idle, split K (exact: the slabs are int32)
 static W8A8Plan w8a8_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
-    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W8A8_MT"); return e ? atoi(e) : 0; }();
-    static const int forced_ks = [] { const char* e = getenv("QLINEAR_W8A8_KSPLIT"); return e ? atoi(e) : 0; }();
+    const int forced_mt = QL_TUNE("QLINEAR_W8A8_MT", 0), forced_ks = QL_TUNE("QLINEAR_W8A8_KSPLIT", 0);
     const int64_t nb = (N + 127) / 128, ksteps = (K + 127) / 128;
     int mt = (M > 64 && nb * ((M + 127) / 128) >= 256) ? 4 : M > 32 ? 2 : 1;
     if (forced_mt == 1 || forced_mt == 2 || forced_mt == 4) mt = forced_mt;
@@ -900,19 +899,19 @@ static int launch_w8a8_mt(const int8_t* Aq, const float* a_scale, const int8_t* 
                           hipStream_t st) {
     int* part = plan.ksplit > 1 ? ws : nullptr;
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 32 * MT - 1) / (32 * MT)), (unsigned)plan.ksplit);
-    static const int forced_depth = [] { const char* e = getenv("QLINEAR_W8A8_DEPTH"); return e ? atoi(e) : 0; }();
+    const int forced_depth = QL_TUNE("QLINEAR_W8A8_DEPTH", 0);
     if (forced_depth ? forced_depth == 4 : (int64_t)grid.x * grid.y * grid.z <= 256)
         w8a8_mfma_kernel<T, MT, 4><<<grid, 256, 0, st>>>(Aq, W, (int)M, (int)N, (int)K, plan.per, a_scale, (const T*)S,
                                                          (const T*)bias, (T*)C, ldc, part);
     else
         w8a8_mfma_kernel<T, MT, 2><<<grid, 256, 0, st>>>(Aq, W, (int)M, (int)N, (int)K, plan.per, a_scale, (const T*)S,
                                                          (const T*)bias, (T*)C, ldc, part);
-    const int rc = finish_launch();
+    const int rc = finish_launch(QL_K_W8A8_ROWMAJOR);
     if (rc != 0 || !part) return rc;
     const int64_t total = M * N;
     w8a8_splitk_reduce_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, a_scale, (const T*)S, (const T*)bias,
                                                                                  (T*)C, (int)M, (int)N, ldc, plan.ksplit);
-    return finish_launch();
+    return finish_launch(QL_K_SPLITK_REDUCE);
 }
 
 template <typename T>

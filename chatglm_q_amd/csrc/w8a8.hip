@@ -190,11 +190,11 @@ static int launch_act_quant_mode(const void* A, int8_t* Aq, float* a_scale, int6
             else if (nvec <= 1024) QL_AQ(4);
             else QL_AQ(8);
 #undef QL_AQ
-            return finish_launch();
+            return finish_launch(QL_K_ACT_QUANT);
         }
     }
     act_quant_rows_generic_kernel<T, MODE><<<(unsigned)M, 256, 0, st>>>((const T*)A, Aq, a_scale, (int)K, lda, rowmax, (int)M);
-    return finish_launch();
+    return finish_launch(QL_K_ACT_QUANT);
 }
 
 template <typename T>
@@ -717,22 +717,21 @@ static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const in
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
     }();
     (void)attr_set;
-    static const int rotate = [] { const char* e = getenv("QLINEAR_W8A8_ROTATE"); return e ? atoi(e) : 0; }();   // experiment switch (1: rotation on; measured 17.5 vs 17.2 us in the unrolled form)
-    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
+    const int rotate = QL_TUNE("QLINEAR_W8A8_ROTATE", 0);       // K-phase rotation of the column tiles: 17.5 vs 17.2 us in the unrolled form (LABNOTES r3)
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;   // super-tile raster (ql_common.h): profiles/r02_w8a8_l2_pmc.txt
     const int sy = NG == 1 ? 8 : 4;                    // blocks in flight per XCD: 64 (two per CU) or 32
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w8a8_tiled_kernel<T, MT, S, DEPTH, NG, COLG, NITER, ADMA><<<(unsigned)(nbx * nby), NG * 256, kLds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), rotate, super ? sy : 0,
         a_scale, (const T*)Sc,
         (const T*)bias, (T*)C, ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W8A8_TILED);
 }
 
 template <typename T>
 static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
                              int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    static const int forced_mt = [] { const char* e = getenv("QLINEAR_W8A8_MT"); return e ? atoi(e) : 0; }();
-    static const int forced_ng = [] { const char* e = getenv("QLINEAR_W8A8_NG"); return e ? atoi(e) : 0; }();   // tuning sweeps
+    const int forced_mt = QL_TUNE("QLINEAR_W8A8_MT", 0), forced_ng = QL_TUNE("QLINEAR_W8A8_NG", 0);   // tuning sweeps (developer build)
     const int64_t nb = (N + 127) / 128;
     // tallest row tile that still gives every CU a block
     int mt = 1;
@@ -743,16 +742,20 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
     // two independent 4-wave blocks per CU once there are at least two 128-row tiles per CU
     int ng = (mt == 4 && nb * ((M + 127) / 128) >= 512) ? 1 : 2;
     if (forced_ng == 1 || forced_ng == 2) ng = forced_ng;
-    static const int colg = [] { const char* e = getenv("QLINEAR_W8A8_COLG"); return e ? atoi(e) : 0; }();
-    if (mt == 4 && colg == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+#ifdef QL_DEV_TUNING     // column-group variant (two 128-column groups per block): measured behind the K-parity groups, LABNOTES r2
+    if (mt == 4 && QL_TUNE("QLINEAR_W8A8_COLG", 0) == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+#endif
     if (mt == 4 && ng == 1) return launch_w8a8_tiled_mt<T, 4, 1, 2, 1>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     if (mt == 4) return launch_w8a8_tiled_mt<T, 4, 1, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-    static const int no_unroll = [] { const char* e = getenv("QLINEAR_W8A8_UNROLL"); return e && atoi(e) == 0; }();   // A/B switch
-    static const int no_adma = [] { const char* e = getenv("QLINEAR_W8A8_ADMA"); return e && atoi(e) == 0; }();       // A/B switch
-    if (mt == 2 && K == 4096 && !no_unroll && !no_adma && M * K < (int64_t)1 << 31)   // ... with A by LDS-DMA, hand-counted VM queue
+    // config 3's shape: 8 iterations of 256 bytes per K-parity group fully unrolled, A by LDS-DMA, hand-counted VM queue
+    // (18.7 -> 17.1 us, profiles/r03_w8a8_kernel_stats.csv; developer build: QLINEAR_W8A8_UNROLL=0 / QLINEAR_W8A8_ADMA=0 for the A/B)
+    const bool unroll = QL_TUNE("QLINEAR_W8A8_UNROLL", 1) != 0, adma = QL_TUNE("QLINEAR_W8A8_ADMA", 1) != 0;
+    if (mt == 2 && K == 4096 && unroll && adma && M * K < (int64_t)1 << 31)
         return launch_w8a8_tiled_mt<T, 2, 2, 2, 2, false, 8, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
-    if (mt == 2 && K == 4096 && !no_unroll)            // 8 iterations of 256 bytes per K-parity group, fully unrolled (config 3)
+#ifdef QL_DEV_TUNING
+    if (mt == 2 && K == 4096 && unroll)                // the register-staged unrolled form
         return launch_w8a8_tiled_mt<T, 2, 2, 2, 2, false, 8>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+#endif
     if (mt == 2) return launch_w8a8_tiled_mt<T, 2, 2, 2, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     return launch_w8a8_tiled_mt<T, 1, 2, 3, 2>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 }

@@ -189,13 +189,13 @@ static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm,
     }();
     (void)attr_set;
     const int nbx = (int)((N + 255) / 256), nby = (int)((M + 255) / 256);
-    static const int no_super = [] { const char* e = getenv("QLINEAR_GEMM_SUPER"); return e && atoi(e) == 0; }();   // A/B switch
-    const int sy = 4;
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
+    const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
     w8a8_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kI256Lds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), super ? sy : 0, a_scale,
         (const T*)S, (const T*)bias, (T*)C, ldc);
-    return finish_launch();
+    return finish_launch(QL_K_W8A8_GEMM256);
 }
 
 // what the kernel needs: 16-bit outputs, whole 128-byte K tiles (two at least), 32-bit byte offsets into Aq
@@ -205,13 +205,12 @@ bool w8a8_gemm256_can_run(int dtype, int64_t M, int64_t N, int64_t K, const void
 }
 // ... and when the launcher of w8a8.hip takes it: the grid pays in whole rounds of 256 blocks (one block per CU at a time)
 bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq) {
-    static const int off = [] { const char* e = getenv("QLINEAR_W8A8_256"); return e && atoi(e) == 0; }();            // A/B switch
-    static const int min_blocks = [] { const char* e = getenv("QLINEAR_W8A8_256_MIN_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning sweeps
-    if (off || !w8a8_gemm256_can_run(dtype, M, N, K, Aq)) return false;
+    const int min_blocks = QL_TUNE("QLINEAR_W8A8_256_MIN_BLOCKS", 0);   // tuning sweeps (developer build)
+    if ((dispatch_flags() & QL_D_NO256) || !w8a8_gemm256_can_run(dtype, M, N, K, Aq)) return false;
     const int64_t blocks = ((N + 255) / 256) * ((M + 255) / 256);
     if (min_blocks > 0) return blocks >= min_blocks;
-    const int64_t rounds = (blocks + 255) / 256;
-    return blocks >= 256 && blocks * 10 >= rounds * 256 * 7;
+    const int64_t cus = cu_count(), rounds = (blocks + cus - 1) / cus;
+    return blocks >= cus && blocks * 10 >= rounds * cus * 7;
 }
 
 int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,

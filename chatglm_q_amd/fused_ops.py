@@ -122,7 +122,12 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
     return out
 
 
-GROUP_ATTENTION = os.environ.get("QLINEAR_ATTENTION_MFMA", "1") != "0"
+def group_attention() -> bool:
+    """False when QLINEAR_DISPATCH (include/qlinear_hip.h) turns the grouped MFMA decode attention off."""
+    return "nogroupattn" not in os.environ.get("QLINEAR_DISPATCH", "")
+
+
+
 PREFETCH_NEXT = os.environ.get("QLINEAR_ATTENTION_PREFETCH", "1") != "0"   # spare workgroups warm the next linear's weights
 SPLIT_ATTENTION_FROM = int(os.environ.get("QLINEAR_SPLIT_ATTENTION_FROM", "448"))   # cache capacity from which windows are split
 
@@ -151,7 +156,7 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
                          f"got {tuple(mask.shape)} {mask.dtype}")
     if split is None:
         # 16 heads per key/value group (16-bit, D = 128): the group kernel takes one 256-position window per block
-        group_kernel = qkv.dtype != torch.float32 and d_head == 128 and n_head == 16 * n_groups and GROUP_ATTENTION
+        group_kernel = qkv.dtype != torch.float32 and d_head == 128 and n_head == 16 * n_groups and group_attention()
         split = capacity > 256 if group_kernel else capacity >= SPLIT_ATTENTION_FROM
     pos_c = pos.contiguous()
     with torch.cuda.device(qkv.device):

@@ -41,7 +41,10 @@
 extern "C" {
 #endif
 
-#define QLINEAR_ABI_VERSION 1
+/* 2 (round 4): qlinear_w4g32_fwd_packed_residual gained `flags` in front of `stream` (round 3); qlinear_last_dispatch /
+ * qlinear_dispatch_reset / qlinear_dispatch_reload / qlinear_gemm256_serves / qlinear_tiled_dispatch added; the experimental entry points (one-launch MLP pair / persistent MLP
+ * engine / W4A8) moved to include/qlinear_hip_dev.h and libqlinear_hip_dev.so. */
+#define QLINEAR_ABI_VERSION 2
 
 /* activation dtypes */
 #define QL_DTYPE_F32 0
@@ -86,6 +89,39 @@ const char* qlinear_status_string(int status);
 /* Number of kernel launches this process has issued through the library (monotonic, relaxed).
  * Lets a caller prove that a result came from the HIP path and not from any fallback. */
 uint64_t qlinear_launch_count(void);
+
+/* Debug query: WHICH kernel families the calling thread's library calls launched since qlinear_dispatch_reset(): one byte per
+ * launch, newest in the low byte, up to 8 launches (older ones fall off).  tests/test_dispatch_sweep_gpu.py asserts with it that
+ * the kernel really changes where the dispatch tables say it does.  Thread-local, no synchronisation, no effect on results. */
+#define QL_K_OTHER 1            /* repacks, norms, attention, embeddings, quantisers, ... */
+#define QL_K_W4_GEMV 2          /* w4_packed.hip: 1..2 rows (4 per pass), part 1 */
+#define QL_K_W4_ROWS4 3         /* w4_rows4.hip: 2..4 rows on v_mfma_f32_4x4x4, part 1 */
+#define QL_K_W4_FEWROW 4        /* w4_fewrow.hip: 3..32 rows, part 2 */
+#define QL_K_W4_GEMM128 5       /* w4_gemm.hip: 32..128-row tiles, part 2 (+ QL_K_SPLITK_REDUCE for few rows) */
+#define QL_K_W4_GEMM256 6       /* w4_gemm256.hip: 256 x 256 tiles, part 2 */
+#define QL_K_W4_CANON 7         /* w4_kernels.hip: canonical layout, split-K */
+#define QL_K_W4_GENERIC 8       /* w4_kernels.hip: any group size / alignment */
+#define QL_K_SPLITK_REDUCE 9
+#define QL_K_W8_GEMV 10         /* w8_kernels.hip: up to 4 rows per pass on the (N, K) buffer */
+#define QL_K_W8_FEWROW 11       /* w8_gemm.hip: 3..32 rows, tile-major copy */
+#define QL_K_W8_GEMM128 12      /* w8_gemm.hip: 32..128-row tiles (row-major or tile-major weights) */
+#define QL_K_W8_GEMM256 13      /* w4_gemm256.hip<W8>: 256 x 256 tiles, tile-major copy */
+#define QL_K_W8_GENERIC 14
+#define QL_K_W8A8_ROWMAJOR 15   /* w8_kernels.hip: round 1's i8 x i8 kernel on the (N, K) buffer */
+#define QL_K_W8A8_TILED 16      /* w8a8.hip: 64 / 128-row tiles, tile-major copy */
+#define QL_K_W8A8_GEMM256 17    /* w8a8_gemm256.hip */
+#define QL_K_ACT_QUANT 18
+#define QL_K_W4_STREAMK_FIXUP 19 /* w4_gemm256.hip: sums the fp32 partial tiles of a stream-K tail */
+uint64_t qlinear_last_dispatch(void);
+void qlinear_dispatch_reset(void);
+void qlinear_dispatch_reload(void);   /* parse QLINEAR_DISPATCH again (it is read once, at the first dispatch decision) */
+
+/* Environment variables read by THIS library (chatglm_q_amd/csrc/tune.h): exactly one,
+ *   QLINEAR_DISPATCH = comma list of kernel families the dispatch must not use: no256, nopeel, nofewrow, norows4, nogroupattn
+ * (every family has a slower fallback computing the same function; for A/B measurements and triage).  The host package reads
+ * QLINEAR_LIB_PATH (another build of this library) and QLINEAR_STRICT (0 / 1 / auto: the per-weight rounding policy, see
+ * QL_FLAG_STRICT_ROUNDING) - chatglm_q_amd/_lib.py.  Every other tuning value is a compile-time constant with its measurement
+ * cited at its use; the developer build (make dev, -DQL_DEV_TUNING) turns them back into environment variables. */
 
 /* Bytes of scratch the op wants for this shape (0 = none).  The caller allocates it (e.g. from
  * torch's caching allocator so stream semantics hold) and passes it to the op.  It is REQUIRED by
@@ -158,6 +194,16 @@ int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, 
  * 16-byte aligned rows of A and M * lda * 2 < 2^31.  fp16 / bf16. */
 int qlinear_w4g32_fwd_tiled256(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                                int64_t group, int64_t lda, int64_t ldc, int dtype, void* stream);
+/* 1 when the dispatch of qlinear_w4g32_fwd_tiled / qlinear_w8_fwd_tiled (and the _gated / _residual entry points, which exist on
+ * that kernel only) takes the 256 x 256-tile kernel for M contiguous, 16-byte aligned rows of K 16-bit activations: K % 64 == 0,
+ * K >= 128 and a grid that fills the chip in whole rounds (at least one block per CU, last round >= 70 % full).  Lets a caller
+ * decide BEFORE it builds a gate-interleaved tile-major copy whether the gated entry point will serve the row count. */
+int qlinear_gemm256_serves(int64_t M, int64_t N, int64_t K);
+/* Host-only: what qlinear_w4g32_fwd_tiled (weight_bits = 4) / qlinear_w8_fwd_tiled (8) launches for M contiguous 16-bit rows:
+ * returns the QL_K_* family of the first launch; *rows_first (nullable) = the rows it serves - fewer than M only for
+ * QL_K_W4_GEMM256, when the rows of a thinly filled last round go to QL_K_W4_GEMM128 as a second launch ("peel").  The dispatch
+ * table as a function, for tests and tools; 0 for bad arguments. */
+int qlinear_tiled_dispatch(int weight_bits, int64_t M, int64_t N, int64_t K, int64_t* rows_first);
 
 /* One-row (decode) forward on the derived layout with an activation PROLOGUE fused into the staging of the
  * activation row, so that the small op in front of the QLinear call costs no launch of its own (SURVEY.md 8f
@@ -397,7 +443,7 @@ int qlinear_decode_attention(const void* Q, const void* Kcache, const void* Vcac
  * then not rounded to the activation dtype before P.V (same function within fp tolerance).  Without it one block per
  * (sequence, head) walks the whole cache with the reference's rounding points (capacity <= ~15 k).
  * H == 16 G, D == 128, fp16 / bf16, ldqkv % 8 == 0: one block per (sequence, group, window) on the matrix cores
- * (a single launch up to capacity 256, split_workspace needed above; QLINEAR_ATTENTION_MFMA=0 turns it off). */
+ * (a single launch up to capacity 256, split_workspace needed above; QLINEAR_DISPATCH=nogroupattn turns it off). */
 size_t qlinear_decode_attention_split_bytes(int64_t B, int64_t H, int64_t D, int64_t capacity);
 int qlinear_decode_attention_rope(const void* QKV, const void* table, const int64_t* pos, const int64_t* widx, void* Kcache,
                                   void* Vcache, const float* mask, void* Out, int64_t B, int64_t H, int64_t G, int64_t D,

@@ -47,7 +47,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert _lib.get_lib().qlinear_abi_version() == 1
+    assert _lib.get_lib().qlinear_abi_version() == 2
     assert _lib.get_lib().qlinear_status_string(0) == b"ok"
     assert b"group" in _lib.get_lib().qlinear_status_string(-4)
     # host-only queries (no GPU needed)

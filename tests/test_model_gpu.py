@@ -297,13 +297,17 @@ def test_group_attention_on_matrix_cores_equals_per_head(dtype, geom, monkeypatc
     if n > 4:
         mask[:, :, 3] = -1e10                                # a hole, as left padding makes
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("QLINEAR_ATTENTION_MFMA", flag)
+    from chatglm_q_amd import _lib
+    for flag in ("nogroupattn", ""):
+        monkeypatch.setenv("QLINEAR_DISPATCH", flag)
+        _lib.get_lib().qlinear_dispatch_reload()
         g2 = torch.Generator(device=DEV).manual_seed(12)
         k = torch.randn(B, cap, Gq, D, device=DEV, generator=g2).to(dtype)
         v = torch.randn(B, cap, Gq, D, device=DEV, generator=g2).to(dtype)
         outs.append((F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, Gq, D, split=cap > 256), k, v))
         torch.cuda.synchronize()
+    monkeypatch.delenv("QLINEAR_DISPATCH")
+    _lib.get_lib().qlinear_dispatch_reload()
     (o0, k0, v0), (o1, k1, v1) = outs
     assert torch.isfinite(o1.float()).all()
     assert torch.equal(k0, k1) and torch.equal(v0, v1)
