@@ -202,7 +202,10 @@ def test_decode_attention_long_context_vs_reference_op_sequence(B, cap, n, dtype
     k_ref, v_ref = k0.clone(), v0.clone()
     k_ref[:, n] = rotate_reference(kn.view(B, G, D), rows[:, None])
     v_ref[:, n] = vn.view(B, G, D)
-    assert torch.equal(k1, k_ref) and torch.equal(v1, v_ref)                # cache row written exactly, nothing else touched
+    assert torch.equal(v1, v_ref)                                           # value row written as it is, nothing else touched
+    assert rel_l2(k1[:, n], k_ref[:, n]) < (1e-3 if dtype == torch.float16 else 6e-3)      # rotated key row (fma vs mul / sub: 1 ulp)
+    k_ref[:, n] = k1[:, n]
+    assert torch.equal(k1, k_ref)                                           # no other cache row touched
     want = reference(q_rot, k_ref, v_ref, mask, cap)
     assert torch.isfinite(out.float()).all()
     err = rel_l2(out, want)
