@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # QLINEAR_LIB_PATH: developer override (tools/: ablation builds of the same library); the package default is the in-tree build
 LIB_PATH = os.environ.get("QLINEAR_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "csrc", "libqlinear_hip_dev.so")    # product + experiments + tuning knobs as environment variables
 ABI_VERSION = 2
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -99,10 +100,6 @@ EXPORTS = {
     "qlinear_w8a8_fwd_tiled": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
     "qlinear_w8a8_fwd_tiled256": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
     "qlinear_w8a8_linear_tiled": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "qlinear_w4a8_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
-    "qlinear_w4a8_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
-    "qlinear_w4a8_fwd": (c_int, [c_void_p] * 5 + [c_int64] * 4 + [c_int, c_void_p]),
-    "qlinear_w4a8_linear": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_qembedding_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
@@ -119,13 +116,6 @@ EXPORTS = {
     "qlinear_w4g32_fwd_packed_gated": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_void_p]),
     "qlinear_w4g32_fwd_rows_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_float, c_int, c_void_p]),
-    "qlinear_w4g32_mlp_pair_workspace_bytes": (c_size_t, []),
-    "qlinear_w4g32_mlp_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "qlinear_w4g32_mlp_engine_workspace_bytes": (c_size_t, [c_int64]),
-    "qlinear_w4g32_mlp_engine_supported": (c_int, [c_int64, c_int64, c_int64]),
-    "qlinear_w4g32_mlp_engine": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
-                                         c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "qlinear_w4g32_fwd_packed_residual": (c_int, [c_void_p] * 5 + [c_int64, c_int64, c_int, c_int, c_void_p]),
     "qlinear_w8_fwd_residual": (c_int, [c_void_p] * 6 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_decode_attention_rope_prefetch": (c_int, [c_void_p] * 8 + [c_int64] * 6 + [c_int, c_void_p, c_size_t, c_void_p, c_int,
@@ -143,6 +133,21 @@ EXPORTS = {
     "qlinear_rmsnorm_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int64, c_float, c_int, c_void_p]),
     "qlinear_silu_mul_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
+}
+
+# entry points of libqlinear_hip_dev.so only (include/qlinear_hip_dev.h): recorded experiments, chatglm_q_amd/dev/
+DEV_EXPORTS = {
+    "qlinear_w4a8_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "qlinear_w4a8_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4a8_fwd": (c_int, [c_void_p] * 5 + [c_int64] * 4 + [c_int, c_void_p]),
+    "qlinear_w4a8_linear": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "qlinear_w4g32_mlp_pair_workspace_bytes": (c_size_t, []),
+    "qlinear_w4g32_mlp_pair": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "qlinear_w4g32_mlp_engine_workspace_bytes": (c_size_t, [c_int64]),
+    "qlinear_w4g32_mlp_engine_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "qlinear_w4g32_mlp_engine": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 
 
@@ -202,6 +207,33 @@ def get_lib():
     return _lib
 
 
+_dev_lib = None
+
+
+def dev_available() -> bool:
+    """True when the developer library (``make -C chatglm_q_amd/csrc dev``) is built."""
+    return os.path.exists(DEV_LIB_PATH)
+
+
+def get_dev_lib():
+    """libqlinear_hip_dev.so: everything the product library exports plus ``DEV_EXPORTS`` (chatglm_q_amd/dev/)."""
+    global _dev_lib
+    if _dev_lib is None:
+        try:
+            lib = ctypes.CDLL(DEV_LIB_PATH)
+            for name, (res, args) in {**EXPORTS, **DEV_EXPORTS}.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            if lib.qlinear_abi_version() != ABI_VERSION:
+                raise OSError(f"{DEV_LIB_PATH}: ABI version {lib.qlinear_abi_version()}, expected {ABI_VERSION}")
+        except (OSError, AttributeError) as e:
+            raise QLinearLibraryMissing(f"libqlinear_hip_dev.so is not available ({e}); build it with "
+                                        f"`make -C {os.path.join(_HERE, 'csrc')} dev`") from None
+        _dev_lib = lib
+    return _dev_lib
+
+
 def check(status: int, what: str):
     if status == 0:
         return
@@ -243,7 +275,7 @@ def _version_of(t):
 
 
 def make_plan(name: str, values, a_slot: int, c_slot: int, st_slot: int, rows: int, in_cols: int, n_cols: int, dtype, device,
-              guards, ws_slot: int | None = None, ws_bytes: int = 0, keep=(), extras=()):
+              guards, ws_slot: int | None = None, ws_bytes: int = 0, keep=(), extras=(), dev: bool = False):
     """Closure ``run(input, *extra_tensors) -> Tensor | None`` around the C entry point ``name``.  ``values``: one Python
     value per argument (``EXPORTS[name]``), with None in the variable slots; ``guards``: the tensors whose identity and
     version the plan depends on (canonical buffers, bias, norm weights); ``keep``: tensors whose ADDRESSES are baked into
@@ -251,8 +283,8 @@ def make_plan(name: str, values, a_slot: int, c_slot: int, st_slot: int, rows: i
     (residual, delta, hout), each passed to ``run`` as a tensor or None."""
     if _raw_stream is None or _cur_device is None:
         return None
-    lib = get_lib()
-    res, argtypes = EXPORTS[name]
+    lib = get_dev_lib() if dev else get_lib()
+    res, argtypes = (DEV_EXPORTS if dev else EXPORTS)[name]
     fn = lib._FuncPtr((name, lib))      # a private pointer object: no argtypes, arguments arrive as ctypes objects
     fn.restype = res
     tmpl = tuple(t(v) for t, v in zip(argtypes, values))

@@ -30,64 +30,80 @@ __device__ unsigned long long ql_i256_stamps[8192 * 2 * 4];
 constexpr int kI256Tile = 256 * 128;               // one operand tile: 256 rows (columns) x 128 bytes of K
 constexpr int kI256Lds = 4 * kI256Tile;            // A[2] | W[2]
 
-template <typename T>
-__global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M, int N, int K,
-                                                           int nbx, int super_rows, const float* __restrict__ a_scale,
-                                                           const T* __restrict__ Sc, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+// NW = 8: 2 (M) x 4 (N) waves, wave tile 128 x 64, two waves per SIMD (round 3).
+// NW = 4: 2 x 2 waves, wave tile 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers), ONE wave per SIMD - the geometry of the
+//         vendor's i8 kernel on this chip (rocprof: MT256x256x128, 256 threads; profiles/r04_vendor_gemm_diff.txt): half the
+//         fragment reads per MFMA (8 per 16 instead of 6 per 8), a 4-wave barrier, no second wave competing for the SIMD's issue.
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M, int N, int K,
+                                                               int nbx, int super_rows, const float* __restrict__ a_scale,
+                                                               const T* __restrict__ Sc, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+    static_assert(NW == 8 || NW == 4, "8 waves (2 x 4) or 4 waves (2 x 2)");
+    constexpr int NWN = NW / 2;                        // waves side by side in N
+    constexpr int NT = 8 / NWN;                        // 32-column MFMA tiles per wave
+    constexpr int PW = 32 / NW;                        // A pieces (and W units) a wave stages per K tile
+    constexpr int CTW = 8 / NW;                        // W column tiles a wave stages (4 units each)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | W[2]; reused by the epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / NWN, wc = wave % NWN;
     const int j = lane & 31, kb = lane >> 5;
     const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
     const int m0 = tile.y * 256, n0 = tile.x * 256;
     const int ktiles = K >> 7, ksteps64 = K >> 6;
 
-    // ---- this wave's share of the staging work: A pieces 4 wave .. 4 wave + 3 (8 rows each), W column tile `wave` ---------------
-    unsigned a_off[4];
+    // ---- this wave's share of the staging work: A pieces PW wave .. PW wave + PW - 1 (8 rows each), W column tiles CTW wave .. ----
+    unsigned a_off[PW];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
+    for (int n = 0; n < PW; ++n) {
+        const int q = 64 * (PW * wave + n) + lane, r = q >> 3, cp = q & 7;
         const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
         a_off[n] = (unsigned)row * (unsigned)K + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
     }
     const int ctiles = (N + 31) >> 5;
-    const int ct_raw = tile.x * 8 + wave;
-    const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;          // clamped: loads stay in bounds, stores are masked
     const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)Aq);
-    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wm + (unsigned long long)ct * (unsigned long long)ksteps64 * 2048ull);
+    unsigned long long w_base[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+        const int ct_raw = tile.x * 8 + CTW * wave + c;
+        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;      // clamped: loads stay in bounds, stores are masked
+        w_base[c] = sgpr64((unsigned long long)(uintptr_t)Wm + (unsigned long long)ct * (unsigned long long)ksteps64 * 2048ull);
+    }
     const unsigned w_voff = (unsigned)lane * 16u;
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
-    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;                          // + buffer * tile + n * 1024
-    const unsigned w_dma = lds0 + (unsigned)(2 * kI256Tile) + (unsigned)(4 * wave) * 1024u;
+    const unsigned a_dma = lds0 + (unsigned)(PW * wave) * 1024u;                         // + buffer * tile + n * 1024
+    const unsigned w_dma = lds0 + (unsigned)(2 * kI256Tile) + (unsigned)(CTW * 4 * wave) * 1024u;
     char* w_lds = smem + 2 * kI256Tile;
     // fragment read offsets: sub-step s = (unit u, half h) of the K tile reads chunk 4 u + 2 kb + h of row 128 wr + 32 mt + j
-    // (the K assignment of the tile-major weights, w8a8.hip) and unit (column tile 2 wc + nt, s) of the W tile
+    // (the K assignment of the tile-major weights, w8a8.hip) and unit (column tile NT wc + nt, s) of the W tile
     int a_rd[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * (s >> 1) + 2 * kb + (s & 1)) ^ ((j >> 1) & 7))) * 16;
-    const int w_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
+    const int w_rd = ((NT * wc) * 4 * 64 + lane) * 16;             // + nt * 4096 + s * 1024
 
-    i32x16 acc[4][2];
+    i32x16 acc[4][NT];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0;
 
-    auto issue_piece = [&](int kt, int buf, int q) {   // q = 0..3: A pieces, 4..7: the column tile's four W units
+    auto issue_piece = [&](int kt, int buf, int q) {   // q = 0 .. PW - 1: A pieces, PW .. 2 PW - 1: W units
 #if QL_I256_ABLATE & 2                              // energy ablation: no requests in the loop (tiles 0 / 1 stay in LDS)
         if (kt >= 2) return;
 #endif
         const int k = kt < ktiles ? kt : ktiles - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
-        if (q < 4) glds16(a_dma + (unsigned)(buf * kI256Tile + q * 1024), a_off[q], sgpr64(a_base + (unsigned long long)k * 128ull));
-        else glds16(w_dma + (unsigned)(buf * kI256Tile + (q - 4) * 1024), w_voff, sgpr64(w_base + (unsigned long long)(4 * k + (q - 4)) * 1024ull));
+        if (q < PW) glds16(a_dma + (unsigned)(buf * kI256Tile + q * 1024), a_off[q], sgpr64(a_base + (unsigned long long)k * 128ull));
+        else {
+            const int u = q - PW;                      // unit u & 3 of the wave's column tile u >> 2
+            glds16(w_dma + (unsigned)(buf * kI256Tile + u * 1024), w_voff, sgpr64(w_base[u >> 2] + (unsigned long long)(4 * k + (u & 3)) * 1024ull));
+        }
     };
-    i32x4 fa[2][4], fb[2][2];
-    auto read_frags = [&](int buf, int s, i32x4 (&xa)[4], i32x4 (&xb)[2]) {
+    i32x4 fa[2][4], fb[2][NT];
+    auto read_frags = [&](int buf, int s, i32x4 (&xa)[4], i32x4 (&xb)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const i32x4*>(w_lds + buf * kI256Tile + w_rd + nt * 4096 + s * 1024);
+        for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const i32x4*>(w_lds + buf * kI256Tile + w_rd + nt * 4096 + s * 1024);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
 #if QL_I256_ABLATE & 1                              // energy ablation (results wrong): half the A fragment reads, the other half reused
@@ -99,20 +115,20 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restr
 
     // ---- prologue: tiles 0 and 1 requested; tile 0 landed ------------------------------------------------------------------------
 #pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(0, 0, q);
+    for (int q = 0; q < 2 * PW; ++q) issue_piece(0, 0, q);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(1, 1, q);
-    vm_wait_imm<8>();
+    for (int q = 0; q < 2 * PW; ++q) issue_piece(1, 1, q);
+    vm_wait_imm<2 * PW>();
     __syncthreads();
     read_frags(0, 0, fa[0], fb[0]);
 
     // ---- K loop (w4_gemm256.hip): sub-steps 0..2, barrier (tile kt + 1 complete, tile kt's last fragments in registers), then the
-    // eight requests of tile kt + 2 one behind each MFMA of sub-step 3, with the first fragment reads of tile kt + 1 in front
+    // requests of tile kt + 2 one behind each MFMA of sub-step 3, with the first fragment reads of tile kt + 1 in front
     auto mma_sub = [&](int s) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt], 0, 0, 0);
     };
     auto k_tile = [&](int kt, auto curc) {
         constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
@@ -127,13 +143,14 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restr
         __syncthreads();
         read_frags(nxt, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
-        static_for<8>([&](auto qc) {
-            constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
+        static_for<4 * NT>([&](auto qc) {              // 4 NT MFMAs, 2 PW = 64 / NW = 4 NT requests: one behind each
+            constexpr int q = decltype(qc)::value, mt = q / NT, nt = q % NT;
             acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[1][mt], fb[1][nt], acc[mt][nt], 0, 0, 0);
             issue_piece(kt + 2, cur, q);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    static_assert(4 * NT == 2 * PW, "one request per MFMA of the last sub-step");
 #ifdef QL_I256_STAMPS
     const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -144,47 +161,54 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(const int8_t* __restr
     }
     if (kt < ktiles) k_tile(kt, std::integral_constant<int, 0>{});
 #ifdef QL_I256_STAMPS
-    if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_i256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 3] = __builtin_amdgcn_s_memtime() - t_loop0;
+    if (lane == 0 && (wave % NWN) == 0 && blockIdx.x < 8192) ql_i256_stamps[((size_t)blockIdx.x * 2 + wr) * 4 + 3] = __builtin_amdgcn_s_memtime() - t_loop0;
 #endif
     vm_wait_imm<0>();                                  // the queue is empty before LDS is reused
     __syncthreads();                                   // ... and every wave is past its last fragment read
 
     // ---- epilogue: rank-1 scales, rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global ----------------
-    const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
+    // (row tile outermost: its 16 activation scales are fetched once and live in 16 registers - with the column tile outermost
+    // hipcc kept all 64 of them and spilled 252 bytes per lane, rocprof scratch column, round 3)
+    const int mw = m0 + 128 * wr, nw = n0 + (256 / NWN) * wc;
     const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
+    float ws[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int n = nw + 32 * nt + j;
-        const float ws = Act<T>::load(Sc + (n < N ? n : N - 1));
+        ws[nt] = Act<T>::load(Sc + (n < N ? n : N - 1));
+    }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            float asc[16];
+    for (int mt = 0; mt < 4; ++mt) {
+        float asc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
-                asc[i] = a_scale[m < M ? m : M - 1];
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+            asc[i] = a_scale[m < M ? m : M - 1];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nw + 32 * nt + j;
             if (wide) {
                 store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane,
-                                    [&](int i) { return (float)acc[mt][nt][i] * (asc[i] * ws); });
+                                    [&](int i) { return (float)acc[mt][nt][i] * (asc[i] * ws[nt]); });
             } else if (n < N) {
                 const T* bn = bias ? bias + n : nullptr;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
-                    if (m < M) store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][nt][i] * (asc[i] * ws), bn);
+                    if (m < M) store_out<T>(C + (int64_t)m * ldc + n, (float)acc[mt][nt][i] * (asc[i] * ws[nt]), bn);
                 }
             }
         }
     }
 }
 
-template <typename T>
-static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
-                       int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+template <typename T, int NW>
+static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                          int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kI256Lds) == hipSuccess;
     }();
     (void)attr_set;
@@ -192,10 +216,23 @@ static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm,
     const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
-    w8a8_gemm256_kernel<T><<<(unsigned)(nbx * nby), 512, kI256Lds, st>>>(
+    w8a8_gemm256_kernel<T, NW><<<(unsigned)(nbx * nby), NW * 64, kI256Lds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), super ? sy : 0, a_scale,
         (const T*)S, (const T*)bias, (T*)C, ldc);
     return finish_launch(QL_K_W8A8_GEMM256);
+}
+
+#ifndef QL_I256_NW
+#define QL_I256_NW 4
+#endif
+template <typename T>
+static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                       int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+#ifdef QL_DEV_TUNING
+    if (QL_TUNE("QLINEAR_I256_NW", QL_I256_NW) != QL_I256_NW)
+        return launch_i256_nw<T, 12 - QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+#endif
+    return launch_i256_nw<T, QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 }
 
 // what the kernel needs: 16-bit outputs, whole 128-byte K tiles (two at least), 32-bit byte offsets into Aq

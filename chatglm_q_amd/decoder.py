@@ -48,6 +48,9 @@ def filtered_distribution(logits: Tensor, top_k: int = 100, top_p: float = 0.8, 
     return probs / probs.sum(dim=-1, keepdim=True), indices
 
 
+# hook of the developer experiments (chatglm_q_amd/dev/experiments.py); None in the product
+POST_GENERATE_CHECK = None
+
 class DecodeSession:
     """One sequence batch on one device: preallocated cache, eager (chunked) prefill, graph-replayed decode."""
 
@@ -244,10 +247,9 @@ class DecodeSession:
             self.tok.copy_(token.to(self.device))
         if self.graph is not None and self._captured_greedy == greedy:
             from . import _lib
-            if self._graph_epoch != _lib.layout_epoch():        # a derived layout was rebuilt / dropped since the capture
-                self.graph = None
-                self.capture(greedy)
-            self.graph.replay()
+            if self._graph_epoch != _lib.layout_epoch():        # a derived layout was rebuilt / dropped since the capture:
+                self.capture(greedy)                            # capture() compares the fingerprint and keeps the graph when
+            self.graph.replay()                                 # only modules of OTHER models / sessions moved
         else:
             self._step_body(greedy)
         self.length += 1
@@ -298,11 +300,8 @@ class ChatGLMDecoder:
                                       sync_every_token)
         finally:
             sess.busy = False
-            from . import model as _M
-            if _M.MLP_PAIR:                                     # experiment switch: a consumer that gave up waiting set the error word
-                from .int4 import hip_ops as _h4
-                if _h4.mlp_pair_timed_out(sess.device):
-                    raise RuntimeError("QLINEAR_MLP_PAIR: a workgroup timed out waiting inside the one-launch MLP; this generation's tokens are invalid")
+            if POST_GENERATE_CHECK is not None:                 # set by chatglm_q_amd.dev.experiments: error words of one-launch MLPs
+                POST_GENERATE_CHECK(sess)
 
     def _generate(self, sess: DecodeSession, prefix, budget: int, top_k: int, top_p: float, temperature: float, greedy: bool,
                   ignore_eos: bool, prefill_chunk: Optional[int], sync_every_token: bool):

@@ -241,65 +241,6 @@ def w4_forward(a: Tensor, b: Tensor, b_scale: Tensor, bias: Tensor | None = None
     return c.reshape(out_shape)
 
 
-def w4a8_supported(a: Tensor, b: Tensor, b_scale: Tensor) -> bool:
-    """Shapes / dtypes served by the int8-activation path (qlinear_w4a8_*): fp16 / bf16, group 32."""
-    return (a.is_cuda and a.dtype in (torch.float16, torch.bfloat16) and b_scale.dtype == a.dtype and b.dtype == torch.uint8
-            and b_scale.shape[0] * 32 == b.shape[0] * 2 and b.is_contiguous() and b_scale.is_contiguous())
-
-
-def pack_w4a8(b: Tensor, b_scale: Tensor) -> Tensor:
-    """Derived "a8" layout of canonical int4g32 buffers for the int8-activation GEMM (``qlinear_w4a8_pack``): a cache like
-    ``repack_w4g32``'s, never part of a state_dict."""
-    lib = _lib.get_lib()
-    K, N = b.shape[0] * 2, b.shape[1]
-    nbytes = int(lib.qlinear_w4a8_packed_bytes(N, K, 32, _lib.dtype_code(b_scale.dtype)))
-    if nbytes == 0:
-        raise ValueError(f"no W4A8 layout for N={N}, K={K}, dtype={b_scale.dtype} (group 32, fp16 / bf16)")
-    out = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
-    with torch.cuda.device(b.device):
-        st = lib.qlinear_w4a8_pack(b.contiguous().data_ptr(), b_scale.contiguous().data_ptr(), out.data_ptr(), N, K, 32,
-                                   _lib.dtype_code(b_scale.dtype), _lib.stream_ptr(b.device))
-    _lib.check(st, "qlinear_w4a8_pack")
-    return out
-
-
-def w4a8_forward(a: Tensor, packed_a8: Tensor, n_out: int, bias: Tensor | None = None, per_tensor: bool = False) -> Tensor:
-    """int8-quantised activations x int4g32 weights on the i8 matrix cores (``qlinear_w4a8_linear``: activation
-    quantiser + GEMM in one library call).  NOT bit-compatible with the weight-only path: see include/qlinear_hip.h."""
-    lib = _lib.get_lib()
-    a2 = _rows(a)
-    M, K = a2.shape
-    _check_row_operands("w4a8_forward", a, K, bias=bias)
-    if packed_a8.device != a.device or packed_a8.numel() != int(lib.qlinear_w4a8_packed_bytes(n_out, K, 32, _lib.dtype_code(a.dtype))):
-        raise AssertionError(f"w4a8_forward: packed buffer does not belong to a ({K}, {n_out}) {a.dtype} weight on {a.device}")
-    c = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
-    if M:
-        if bias is not None:
-            bias = bias.contiguous()
-        with torch.cuda.device(a.device):
-            ws_bytes = int(lib.qlinear_workspace_bytes(_lib.OP_W4A8_LINEAR, M, n_out, K, 32))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
-            st = lib.qlinear_w4a8_linear(a2.data_ptr(), packed_a8.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out, K,
-                                         a2.stride(0) if M > 1 else K, n_out, _lib.dtype_code(a.dtype),
-                                         _lib.FLAG_ACT_PER_TENSOR if per_tensor else 0, ws.data_ptr(), ws_bytes,
-                                         _lib.stream_ptr(a.device))
-        _lib.check(st, "qlinear_w4a8_linear")
-    return c.reshape(*a.shape[:-1], n_out)
-
-
-def w4a8_gemm(a_q: Tensor, a_s: Tensor, packed_a8: Tensor, n_out: int, dtype: torch.dtype, bias: Tensor | None = None) -> Tensor:
-    """Second step alone (``qlinear_w4a8_fwd``): pre-quantised int8 rows (M, K) and their fp32 scales."""
-    lib = _lib.get_lib()
-    M, K = a_q.shape
-    c = torch.empty((M, n_out), device=a_q.device, dtype=dtype)
-    if M:
-        with torch.cuda.device(a_q.device):
-            st = lib.qlinear_w4a8_fwd(a_q.data_ptr(), a_s.data_ptr(), packed_a8.data_ptr(), _lib.ptr(bias), c.data_ptr(), M, n_out,
-                                      K, n_out, _lib.dtype_code(dtype), _lib.stream_ptr(a_q.device))
-        _lib.check(st, "qlinear_w4a8_fwd")
-    return c
-
-
 def w4_grad_input_supported(grad_out: Tensor, b: Tensor, b_scale: Tensor) -> bool:
     """Shapes / dtypes served by qlinear_w4g32_bwd_input (everything else takes the dense torch formula)."""
     K, N = b.shape[0] * 2, b.shape[1]
@@ -505,108 +446,6 @@ def w4_forward_rows_fused(kind: int, a: Tensor, packed: Tensor, n_out: int, bias
         return None
     _lib.check(st, "qlinear_w4g32_fwd_rows_fused")
     return c.reshape(*a.shape[:-1], cols), (hout.reshape(a.shape) if hout is not None else None)
-
-
-def mlp_engine_supported(n_in: int, K: int, n_out: int) -> bool:
-    """True when ``qlinear_w4g32_mlp_engine`` serves a (K -> n_in -> n_out) gated MLP (one persistent launch)."""
-    return bool(_lib.get_lib().qlinear_w4g32_mlp_engine_supported(n_in, K, n_out))
-
-
-def mlp_engine_workspace(n_in: int, device) -> Tensor:
-    """Zeroed workspace of the persistent MLP launch (launch epoch, error word, hand-off granules): one per decode session /
-    stream, reused by every layer's launch of that session (the launches of a stream are ordered)."""
-    nbytes = int(_lib.get_lib().qlinear_w4g32_mlp_engine_workspace_bytes(n_in))
-    ws = torch.zeros(nbytes + 64, dtype=torch.uint8, device=device)
-    off = (-ws.data_ptr()) % 64
-    return ws[off: off + nbytes]
-
-
-def mlp_engine_error(ws: Tensor) -> int:
-    """Host-synchronous read of the workspace's error word: non-zero when a bounded wait of an earlier launch gave up."""
-    return int(ws[8:12].view(torch.int32).item())
-
-
-def w4_mlp_engine(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, bias_in: Tensor | None, n_in: int,
-                  packed_out: Tensor, bias_out: Tensor | None, n_out: int, ws: Tensor, strict: bool | None = None,
-                  plan_out: list | None = None, guards=()) -> Tensor | None:
-    """The MLP of a one-row decode step in ONE persistent launch (``qlinear_w4g32_mlp_engine``): ``round(w_out(silu(h) * gate)
-    + x)`` with ``(h | gate) = w_in(rmsnorm(x) * ln_weight)``; bit-equal to ``w4_forward_fused(PRO_ADDNORM | EPI_SILU_GATE)``
-    followed by ``w4_forward_residual(residual=x)``.  None when the library does not serve the shape that way."""
-    lib = _lib.get_lib()
-    K = x.shape[-1]
-    if x.numel() != K:
-        raise ValueError("the MLP engine serves exactly one row")
-    _check_row_operands("w4_mlp_engine", x, K, ln_weight=ln_weight, bias_in=bias_in, bias_out=bias_out)
-    if n_out != K or not mlp_engine_supported(n_in, K, n_out):
-        return None
-    if gated_packed.numel() < gemv_nbytes(n_in, K, x.dtype) or packed_out.numel() < gemv_nbytes(n_out, n_in // 2, x.dtype):
-        raise AssertionError("w4_mlp_engine: derived buffers too small for the two projections")
-    if ws.device != x.device or ws.data_ptr() % 64 or ws.numel() < int(lib.qlinear_w4g32_mlp_engine_workspace_bytes(n_in)):
-        raise AssertionError("w4_mlp_engine: workspace on another device, misaligned or too small")
-    flags = _lib.FLAG_STRICT_ROUNDING if (_lib.strict_for(x.dtype) if strict is None else strict) else 0
-    x = x.contiguous()
-    out = torch.empty((*x.shape[:-1], n_out), device=x.device, dtype=x.dtype)
-    code = _lib.dtype_code(x.dtype)
-    with torch.cuda.device(x.device):
-        st = lib.qlinear_w4g32_mlp_engine(x.data_ptr(), ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
-                                          packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, out.data_ptr(), ws.data_ptr(), code, flags,
-                                          _lib.stream_ptr(x.device))
-    if st == _lib.ERR_UNSUPPORTED:
-        return None
-    _lib.check(st, "qlinear_w4g32_mlp_engine")
-    if plan_out is not None:
-        plan_out.append(_lib.make_plan(
-            "qlinear_w4g32_mlp_engine", (None, ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
-                                         packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, None, ws.data_ptr(), code, flags, None),
-            0, 10, 14, 1, K, n_out, x.dtype, x.device, (*guards, ln_weight, bias_in, bias_out),
-            keep=(gated_packed, packed_out, bias_in, bias_out, ln_weight, ws)))
-    return out
-
-
-_PAIR_WS: dict = {}
-
-
-def w4_mlp_pair(x: Tensor, ln_weight: Tensor, eps: float, gated_packed: Tensor, bias_in: Tensor | None, n_in: int,
-                packed_out: Tensor, bias_out: Tensor | None, n_out: int, residual: Tensor) -> Tensor | None:
-    """EXPERIMENT (``qlinear_w4g32_mlp_pair``): the MLP of a one-row decode step in ONE launch - RMSNorm + w_in + SiLU * gate
-    and w_out + residual, the second projection's workgroups waiting inside the launch for the first one's row.  Bit-equal
-    to ``w4_forward_fused(PRO_ADDNORM | EPI_SILU_GATE)`` followed by ``w4_forward_residual``.  None when the library does
-    not serve the shape (the caller then issues the two launches)."""
-    lib = _lib.get_lib()
-    K = x.shape[-1]
-    if x.numel() != K or residual.numel() != n_out:
-        raise ValueError("the MLP pair serves exactly one row")
-    _check_row_operands("w4_mlp_pair", x, K, ln_weight=ln_weight, bias_in=bias_in, bias_out=bias_out, residual=residual)
-    if gated_packed.numel() < gemv_nbytes(n_in, K, x.dtype) or packed_out.numel() < gemv_nbytes(n_out, n_in // 2, x.dtype):
-        raise AssertionError("w4_mlp_pair: derived buffers too small for the two projections")
-    ws_key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)   # two launches in flight on two streams must not share counters
-    ws = _PAIR_WS.get(ws_key)
-    if ws is None:                                        # arrival counters: zeroed once, reset by the kernel itself
-        ws = _PAIR_WS[ws_key] = torch.zeros(int(lib.qlinear_w4g32_mlp_pair_workspace_bytes()) + 64, dtype=torch.uint8, device=x.device)
-    off = (-ws.data_ptr()) % 64
-    x = x.contiguous()
-    residual = residual.contiguous()
-    mid = torch.empty(n_in // 2, device=x.device, dtype=x.dtype)
-    out = torch.empty((*x.shape[:-1], n_out), device=x.device, dtype=x.dtype)
-    with torch.cuda.device(x.device):
-        st = lib.qlinear_w4g32_mlp_pair(x.data_ptr(), ln_weight.data_ptr(), float(eps), gated_packed.data_ptr(), _lib.ptr(bias_in), n_in,
-                                        packed_out.data_ptr(), _lib.ptr(bias_out), n_out, K, residual.data_ptr(), mid.data_ptr(),
-                                        out.data_ptr(), ws.data_ptr() + off, _lib.dtype_code(x.dtype), _lib.stream_ptr(x.device))
-    if st == _lib.ERR_UNSUPPORTED:
-        return None
-    _lib.check(st, "qlinear_w4g32_mlp_pair")
-    return out
-
-
-def mlp_pair_timed_out(device) -> bool:
-    """True when a consumer workgroup of an earlier ``w4_mlp_pair`` launch gave up waiting (host-synchronous read of the
-    error word; the results of that launch are then garbage)."""
-    hit = False
-    for (dev, _stream), ws in list(_PAIR_WS.items()):
-        if dev == torch.device(device):
-            off = (-ws.data_ptr()) % 64
-            hit |= bool(ws[off + 4 * 16 * 65: off + 4 * 16 * 65 + 4].view(torch.int32).item())
-    return hit
 
 
 def dynamic_quant_matmul_s4(a: Tensor, b: Tensor, b_scale: Tensor, allow_tf32: bool | None = None) -> Tensor:

@@ -127,7 +127,8 @@ class DynamicQuantizeLinear(nn.Module):
         self._plans: dict = {}
         self._fast: dict = {}
         # opt-in int8-activation path (W4A8, i8 MFMA): False | True (row-wise scales) | "per_tensor".  NOT bit-compatible
-        # with the weight-only path (activation quantisation error ~1e-2 relative): include/qlinear_hip.h
+        # with the weight-only path (activation quantisation error ~1e-2 relative) and, since round 4, a developer experiment:
+        # it needs libqlinear_hip_dev.so (include/qlinear_hip_dev.h; measured behind the weight-only GEMM at every shape)
         self.act_quant = False
 
     # -- derived layout -----------------------------------------------------------------------
@@ -266,13 +267,11 @@ class DynamicQuantizeLinear(nn.Module):
                 if self.bias is not None:
                     out = out + self.bias      # not in place: the Function's output may be a view
                 return out
-            if self.act_quant and hip_ops.w4a8_supported(input, self.weight, self.weight_scale) and self.group_size == 32:
-                key = self._canonical_key()
-                if self._a8 is None or self._a8_key != key:
-                    self._a8, self._a8_key = hip_ops.pack_w4a8(self.weight, self.weight_scale), key
-                    _lib.bump_layout_epoch()
-                return hip_ops.w4a8_forward(input, self._a8, self.out_features, self.bias,
-                                            per_tensor=self.act_quant == "per_tensor")
+            if self.act_quant:            # W4A8: a recorded experiment, served by the developer library only (chatglm_q_amd/dev/)
+                from ..dev import experiments
+                out = experiments.w4a8_module_forward(self, input)
+                if out is not None:
+                    return out
             rows = input.numel() // max(input.shape[-1], 1)
             packed = tiled = None
             half = input.dtype in (torch.float16, torch.bfloat16)

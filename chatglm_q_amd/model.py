@@ -22,26 +22,17 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 
-# QLINEAR_FUSED_DECODE=0 keeps every op around the QLinear calls in plain torch (A/B measurements)
-FUSED_DECODE_OPS = os.environ.get("QLINEAR_FUSED_DECODE", "1") not in ("0", "false", "False")
-# batched decode at 2..4 rows: residual add + RMSNorm inside the projections' launches (qlinear_w4g32_fwd_rows_fused)
-ROWS_FUSED_MAX = int(os.environ.get("QLINEAR_ROWS_FUSED_MAX", "2"))      # largest batch that takes it (0 / 1: off)
-# experiment: the two MLP projections of a one-row int4 decode step in ONE launch (qlinear_w4g32_mlp_pair)
-MLP_PAIR = os.environ.get("QLINEAR_MLP_PAIR", "0") not in ("0", "false", "False")
-# the MLP of a one-row int4 decode step as ONE persistent launch (qlinear_w4g32_mlp_engine: LDS-DMA loader wave + consumer waves
-# per CU)
-MLP_ENGINE = os.environ.get("QLINEAR_MLP_ENGINE", "0") not in ("0", "false", "False")
-# int8-activation modules (act_quant): RMSNorm / SiLU * gate emit the int8 rows + scales themselves (quantising producers)
-PREQUANT = os.environ.get("QLINEAR_PREQUANT", "1") not in ("0", "false", "False")
-# many-position attention (prefill chunks) as one launch per layer (qlinear_prefill_attention) instead of two batched GEMMs around
-# the masked-softmax launch; QLINEAR_PREFILL_ATTENTION=0 keeps the GEMM route (A/B measurements)
-PREFILL_ATTENTION = os.environ.get("QLINEAR_PREFILL_ATTENTION", "1") not in ("0", "false", "False")
-# prefill row counts: w_in on its gate-interleaved copy with SiLU * gate in the 256 x 256-tile GEMM's epilogue (no (rows, 2 * hidden)
-# intermediate, no silu_mul launch); QLINEAR_GATED_PREFILL=0 keeps the two launches
-GATED_PREFILL = os.environ.get("QLINEAR_GATED_PREFILL", "1") not in ("0", "false", "False")
-# prefill row counts: `hidden + o_proj(...)` / `hidden + w_out(...)` with the add in the 256 x 256-tile GEMM's epilogue (the norm behind it
-# then reads one tensor instead of two); QLINEAR_RESIDUAL_PREFILL=0 keeps the add inside the norm launch
-RESIDUAL_PREFILL = os.environ.get("QLINEAR_RESIDUAL_PREFILL", "1") not in ("0", "false", "False")
+# Route switches of the decode / prefill graph.  Plain module attributes (no environment variables): every one has a fallback that
+# computes the same function, the tests flip them with monkeypatch to compare the two routes, tools/ set them for A/B timings.
+FUSED_DECODE_OPS = True     # False: every op around the QLinear calls in plain torch
+ROWS_FUSED_MAX = 2          # batched decode at 2..ROWS_FUSED_MAX rows: residual add + RMSNorm inside the projections' launches
+PREQUANT = True             # int8-activation modules: RMSNorm / SiLU * gate emit the int8 rows + scales themselves
+PREFILL_ATTENTION = True    # many-position attention as one launch per layer (False: two batched GEMMs around masked_softmax)
+GATED_PREFILL = True        # prefill: w_in on its gate-interleaved copy, SiLU * gate in the 256 x 256-tile GEMM's epilogue
+RESIDUAL_PREFILL = True     # prefill: `hidden + o_proj(...)` / `hidden + w_out(...)` with the add in the GEMM's epilogue
+# developer experiments (chatglm_q_amd/dev/experiments.py: enable_mlp_engine / enable_mlp_pair) plug a one-launch MLP in here:
+# callable (model, cache, ffn, ffn_ln, h) -> new hidden state or None.  None in the product.
+MLP_HOOK = None
 
 
 @dataclass
@@ -115,7 +106,6 @@ class KVCache:
         self.capacity = capacity
         self.length = 0            # host-side count of valid positions (not used inside captured graphs)
         self.att_plans: dict = {}  # layer -> (layout epoch, operand addresses, pre-bound attention launch); model._step_one_row
-        self.engine_ws = None      # workspace of the persistent MLP launch (hand-off granules, launch epoch): one per session
 
     def as_tuples(self):
         """Reference-shaped view: tuple of (k, v) each (batch, length, groups, 1, d_head)."""
@@ -507,26 +497,6 @@ class ChatGLM2Model(nn.Module):
                 mod._fast["resid"] = plan_out[0]
             return out
 
-        def mlp_engine(ff, ln, x):
-            w_in, w_out = ff.w_in, ff.w_out
-            plan = w_in._fast.get("engine")
-            if plan is not None and plan[0] is cache:
-                out = plan[1](x)
-                if out is not None:
-                    return out
-            if cache.engine_ws is None:
-                if not H4.mlp_engine_supported(w_in.out_features, w_in.in_features, w_out.out_features):
-                    return None
-                cache.engine_ws = H4.mlp_engine_workspace(w_in.out_features, x.device)
-            gp, gb = w_in.gated_packed(ff.hidden_dim)
-            plan_out = []
-            out = H4.w4_mlp_engine(x, ln.weight, ln.eps, gp, gb, w_in.out_features, w_out.prepare()._packed, w_out.bias,
-                                   w_out.out_features, cache.engine_ws, plan_out=plan_out,
-                                   guards=(w_in.weight, w_in.weight_scale, w_out.weight, w_out.weight_scale))
-            if out is not None and plan_out and plan_out[0] is not None:
-                w_in._fast["engine"] = (cache, plan_out[0])     # the plan bakes this session's workspace in
-            return out
-
         epoch = _lib.layout_epoch()
         att_key = (position_ids.data_ptr(), write_index.data_ptr(), mask.data_ptr(), cache.capacity)
         for i, layer in enumerate(self._layer_sites()):
@@ -548,13 +518,7 @@ class ChatGLM2Model(nn.Module):
                     cache.att_plans[i] = (_lib.layout_epoch(), att_key, plan_out[0])
                 epoch = _lib.layout_epoch()                 # prepare() above may have built a layout
             h = residual_linear(at.o_proj, att, h)
-            hn = None
-            if kind == "int4" and MLP_ENGINE:                  # both MLP projections in one persistent launch
-                hn = mlp_engine(ff, ffn_ln, h)
-            if kind == "int4" and MLP_PAIR and not _lib.strict_for(h.dtype):   # round-2 experiment (chained grids), exact-dequant only
-                gp, gb = ff.w_in.gated_packed(ff.hidden_dim)
-                hn = H4.w4_mlp_pair(h, ffn_ln.weight, ffn_ln.eps, gp, gb, ff.w_in.out_features,
-                                    ff.w_out.prepare()._packed, ff.w_out.bias, ff.w_out.out_features, h)
+            hn = MLP_HOOK(self, cache, ff, ffn_ln, h) if (MLP_HOOK is not None and kind == "int4") else None
             if hn is None:
                 y = norm_linear(ff.w_in, h, ffn_ln, gate_hidden=ff.hidden_dim)
                 hn = residual_linear(ff.w_out, y, h)

@@ -290,37 +290,6 @@ int qlinear_w4g32_fwd_tiled_residual(const void* A, const void* tiled, const voi
 int qlinear_w4g32_fwd_rows_fused(int prologue, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                                  int64_t K, const void* delta, const void* ln_weight, void* hout, float eps, int dtype, void* stream);
 
-/* EXPERIMENT (one launch instead of two): the MLP of a one-row decode step,
- *   Out = round(w_out(round(silu(h) * gate)) + residual),  (h | gate) = w_in(rmsnorm(X) * ln_weight),
- * i.e. qlinear_w4g32_fwd_packed_fused(QL_PRO_ADDNORM | QL_EPI_SILU_GATE) followed by qlinear_w4g32_fwd_packed_residual, bit
- * for bit, with the second projection's workgroups in the SAME launch behind the first one's: they request their weights
- * at once and wait (bounded) for the (1, N_in / 2) row `mid` through arrival counters in `workspace`
- * (qlinear_w4g32_mlp_pair_workspace_bytes() bytes, 64-byte aligned, zeroed ONCE by the caller; the kernel resets it).
- * packed_in: gate-interleaved part 1 of the (K, N_in) projection; packed_out: part 1 of the (N_in / 2, N_out) projection.
- * QL_ERR_UNSUPPORTED for shapes other than the ChatGLM2-6B layer's kernel configuration: use the two calls. */
-size_t qlinear_w4g32_mlp_pair_workspace_bytes(void);
-int qlinear_w4g32_mlp_pair(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
-                           const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, const void* residual, void* mid,
-                           void* Out, void* workspace, int dtype, void* stream);
-
-/* The MLP of a one-row decode step as ONE PERSISTENT launch (w4_engine.hip):
- *   Out = round(w_out(round(silu(h) * gate)) + X),  (h | gate) = w_in(rmsnorm(X) * ln_weight)       chatglm_q/model.py:199-201,244-245
- * bit for bit what qlinear_w4g32_fwd_packed_fused(QL_PRO_ADDNORM | QL_EPI_SILU_GATE) followed by
- * qlinear_w4g32_fwd_packed_residual(residual = X) compute (flags: 0 or QL_FLAG_STRICT_ROUNDING, as there).  One workgroup per CU:
- * a loader wave streams both projections' packed weights through an LDS ring with LDS-DMA and never waits for an activation,
- * seven consumer waves compute the two-launch kernels' per-wave sums out of LDS, the (1, N_in / 2) row between the projections
- * travels as 8-byte {data, tag} granules in `workspace`.
- * workspace: qlinear_w4g32_mlp_engine_workspace_bytes(N_in) bytes, 64-byte aligned, zeroed ONCE by the caller and then owned by
- *   launches of ONE stream (the launch epoch lives in it; word 2 is an error code: non-zero = a bounded wait gave up and the
- *   results of that launch are garbage).  X and Out must not alias.  fp16 / bf16, group 32.
- * packed_in: gate-interleaved part 1 of the (K, N_in) projection; packed_out: part 1 of the (N_in / 2, N_out) one; N_out == K.
- * QL_ERR_UNSUPPORTED when qlinear_w4g32_mlp_engine_supported is 0 (K slice of a task longer than 128 groups, LDS): two launches. */
-size_t qlinear_w4g32_mlp_engine_workspace_bytes(int64_t N_in);
-int qlinear_w4g32_mlp_engine_supported(int64_t N_in, int64_t K, int64_t N_out);
-int qlinear_w4g32_mlp_engine(const void* X, const void* ln_weight, float eps, const void* packed_in, const void* bias_in, int64_t N_in,
-                             const void* packed_out, const void* bias_out, int64_t N_out, int64_t K, void* Out, void* workspace, int dtype,
-                             int flags, void* stream);
-
 /* One-row forward on the derived layout whose output is added to the residual stream in the EPILOGUE:
  * C[n] = round(y[n] + residual[n]), y = round(sum) (+ bias, rounded) - chatglm_q/model.py:243,245
  * (hidden = hidden + attention(...), hidden = hidden + ffn(...)).  The next projection's QL_PRO_ADDNORM prologue then
@@ -384,25 +353,6 @@ int qlinear_w8a8_fwd_tiled256(const int8_t* Aq, const float* a_scale, const void
 int qlinear_w8a8_linear_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M,
                               int64_t N, int64_t K, int64_t lda, int64_t ldc, int dtype, int flags, void* workspace,
                               size_t workspace_bytes, void* stream);
-
-/* ---- int4 g32 weights x int8-quantised activations (W4A8: SURVEY.md 8d config 5, BASELINE configs[4]) ------------
- * C[m,n] = round(a_scale[m] * sum_g s[g,n] * (sum_{k in group g} Aq[m,k] * (nibble[k,n] - 8))) (+ bias):
- * the activation side of the int8 path (row-wise / per-tensor symmetric quantisation, chatglm_q/int8/quantizer.py:11-19,
- * chatglm_q/int8/qlinear.py:60-70) with the int4 weight decode (chatglm_q/int4/triton_ops.py:71-73).  One 32-deep
- * v_mfma_i32_32x32x32_i8 = one group; its exact int32 result is scaled into an fp32 accumulator.  The integer stage is
- * exact; the result differs from the weight-only (W4A16) path by the activation quantisation error (~1e-2 relative) -
- * an opt-in accuracy / throughput trade, not a parity claim against the Triton reference.
- * packed_a8: a third derived layout of the canonical buffers (qlinear_w4a8_pack; group 32, K % 32 == 0, fp16 / bf16),
- * nibbles ordered so that two bit operations per dword give the MFMA's int8 operand (chatglm_q_amd/csrc/w4a8.hip). */
-size_t qlinear_w4a8_packed_bytes(int64_t N, int64_t K, int64_t group, int dtype);
-int qlinear_w4a8_pack(const uint8_t* Wq, const void* S, void* packed_a8, int64_t N, int64_t K, int64_t group, int dtype,
-                      void* stream);
-int qlinear_w4a8_fwd(const int8_t* Aq, const float* a_scale, const void* packed_a8, const void* bias, void* C, int64_t M,
-                     int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
-/* quantise A (flags: 0 row-wise, QL_FLAG_ACT_PER_TENSOR) into the workspace, then qlinear_w4a8_fwd: one call, two launches;
- * workspace as for qlinear_w8a8_linear_tiled (QL_OP_W4A8_LINEAR). */
-int qlinear_w4a8_linear(const void* A, const void* packed_a8, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
-                        int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- quantised embedding gathers ("next" row N3) -------------------------------------------
  * ids: (count) int64 token ids.  int4: Wq (V/2, D) packs along the vocabulary axis, S (V/group, D).

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "dev: recorded experiment served by libqlinear_hip_dev.so (still runs under -m gpu)")
 
 
 import pytest  # noqa: E402

@@ -1,0 +1,173 @@
+"""Recorded experiments of libqlinear_hip_dev.so (include/qlinear_hip_dev.h, chatglm_q_amd/dev/experiments.py): the chained-grid MLP
+pair (round 2), the persistent MLP engine (round 3) and W4A8 (rounds 2 - 3, SURVEY row A10 as added by the judge).  They lost
+to the product path and left the product library in round 4; their parity tests stay - marker ``dev`` - and still run under
+``-m gpu`` (build() compiles the developer library too)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.dev]
+
+from oracle import qlinear_oracle as O  # noqa: E402
+from chatglm_q_amd import _lib  # noqa: E402
+from chatglm_q_amd import model as M  # noqa: E402
+from chatglm_q_amd.decoder import ChatGLMDecoder  # noqa: E402
+from chatglm_q_amd.dev import experiments as X  # noqa: E402
+from chatglm_q_amd.int4 import hip_ops as h4  # noqa: E402
+from chatglm_q_amd.int4 import hip_ops as H4  # noqa: E402
+from chatglm_q_amd.int4 import qlinear as q4  # noqa: E402
+from test_host_fast_gpu import _tiny  # noqa: E402
+from test_parity_gpu import TDT, _rand_w4, t2n  # noqa: E402
+
+DEV = "cuda:0"
+W4A8_SHAPES = [(512, 4096, 4096, "f16"), (70, 1024, 200, "f16"), (33, 512, 96, "bf16"), (1, 4096, 256, "f16"),
+               (130, 13696, 136, "f16"), (2048, 1024, 512, "bf16"), (513, 4160, 264, "f16"), (40, 64, 40, "f16"),
+               (96, 32, 32, "f16"), (1000, 1088, 1000, "bf16"), (300, 96, 130, "f16")]
+
+
+def dev_launches():
+    return int(_lib.get_dev_lib().qlinear_launch_count())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("shape,bias", [((4096, 13696), False), ((4096, 13696), True), ((256, 384), True), ((1024, 2752), False)])
+def test_mlp_engine_one_persistent_launch_equals_two(shape, bias, strict, dtype):
+    """qlinear_w4g32_mlp_engine (w4_engine.hip: LDS-DMA loader waves + consumer waves per CU, granule hand-off of the row between
+    the projections) against the two fused launches it replaces - bit for bit, in both arithmetic modes, over repeated launches
+    on one workspace (the launch epoch advances in device memory), real layer size and small sizes (K slices of the first
+    projection, fewer quads than CUs); no bounded wait gave up."""
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    K, hidden = shape
+    if not X.mlp_engine_supported(2 * hidden, K, K):
+        pytest.skip("shape not served by the engine on this device")
+    g = torch.Generator(device=DEV).manual_seed(K + hidden)
+    w_in = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    w_out = DynamicQuantizeLinear(hidden, K, bias=bias, dtype=dtype, device=DEV)
+    for l in (w_in, w_out):
+        l.weight.copy_(torch.randint(0, 256, l.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        l.weight_scale.copy_((torch.rand(l.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        if bias:
+            l.bias.copy_((torch.randn(l.bias.shape, device=DEV, generator=g) * 0.1).to(dtype))
+    ln = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+    gp, gb = w_in.gated_packed(hidden)
+    po = w_out.prepare()._packed
+    ws = X.mlp_engine_workspace(2 * hidden, DEV)
+    for rep in range(5):
+        x = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        y = h4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, x, gp, 2 * hidden, gb, None, ln, None, 1e-5, strict=strict)
+        want = h4.w4_forward_residual(y, po, K, w_out.bias, x, strict=strict)
+        before = dev_launches()
+        got = X.w4_mlp_engine(x, ln, 1e-5, gp, gb, 2 * hidden, po, w_out.bias, K, ws, strict=strict)
+        assert got is not None and dev_launches() == before + 1
+        torch.cuda.synchronize()
+        assert X.mlp_engine_error(ws) == 0
+        assert torch.equal(got, want), (rep, int((got != want).sum()))
+
+
+def test_decode_with_the_mlp_engine_equals_the_five_launch_step(monkeypatch):
+    """enable_mlp_engine(): the decode step with the persistent MLP launch (4 launches per layer) produces the token stream of
+    the 5-launch step, eager and from the HIP graph."""
+    model, cfg = _tiny()
+    if not X.mlp_engine_supported(2 * cfg.inner_hidden_size, cfg.hidden_size, cfg.hidden_size):
+        pytest.skip("tiny MLP not served by the engine")
+    prefix = [3, 17, 200, 5, 77]
+    kw = dict(max_generated_tokens=10, greedy=True, ignore_eos=True)
+    want = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
+    X.enable_mlp_engine()
+    try:
+        before = _lib.launch_count()
+        eager = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
+        n_eager = _lib.launch_count() - before
+        graph = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=True, **kw))
+        assert eager == want and graph == want
+    finally:
+        X.disable_mlp_experiments()
+    before = _lib.launch_count()
+    list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
+    assert n_eager < _lib.launch_count() - before               # one launch less per layer and step
+
+
+@pytest.mark.usefixtures("exact_dequant_policy")
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_mlp_pair_one_launch_equals_two(dtype, bias):
+    """qlinear_w4g32_mlp_pair (experiment: both MLP projections of a one-row decode step in ONE launch, the second one's
+    workgroups waiting inside the launch for the first one's row) against the two fused launches it replaces: bit for bit,
+    over repeated launches (the arrival counters reset themselves), and no consumer gave up waiting."""
+    from chatglm_q_amd.int4 import hip_ops as H4
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
+    g = torch.Generator(device=DEV).manual_seed(91)
+    K, hidden = 4096, 13696
+    w_in = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    w_out = DynamicQuantizeLinear(hidden, K, bias=bias, dtype=dtype, device=DEV)
+    for l in (w_in, w_out):
+        l.weight.copy_(torch.randint(0, 256, l.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+        l.weight_scale.copy_((torch.rand(l.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+        if bias:
+            l.bias.copy_((torch.randn(l.bias.shape, device=DEV, generator=g) * 0.1).to(dtype))
+    ln = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
+    gp, gb = w_in.gated_packed(hidden)
+    po = w_out.prepare()._packed
+    for rep in range(4):
+        h = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
+        y = H4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gp, 2 * hidden, gb, None, ln, None, 1e-5)
+        want = H4.w4_forward_residual(y, po, K, w_out.bias, h)
+        got = X.w4_mlp_pair(h, ln, 1e-5, gp, gb, 2 * hidden, po, w_out.bias, K, h)
+        assert got is not None and torch.equal(got, want)
+    torch.cuda.synchronize()
+    assert not X.mlp_pair_timed_out(DEV)
+    # other shapes are not served: the caller keeps its two launches
+    small = DynamicQuantizeLinear(256, 512, bias=False, dtype=dtype, device=DEV)
+    small.weight.fill_(0x88)
+    small.weight_scale.fill_(0.01)
+    s_out = DynamicQuantizeLinear(256, 256, bias=False, dtype=dtype, device=DEV)
+    s_out.weight.fill_(0x88)
+    s_out.weight_scale.fill_(0.01)
+    x = torch.randn(1, 1, 256, device=DEV, generator=g).to(dtype)
+    assert X.w4_mlp_pair(x, ln[:256].contiguous(), 1e-5, small.gated_packed(256)[0], None, 512, s_out.prepare()._packed, None, 256, x) is None
+
+
+@pytest.mark.parametrize("M,K,N,dt", W4A8_SHAPES)
+def test_w4a8_vs_oracle(M, K, N, dt):
+    """Two-level parity as for W8A8: (i) the integer stage - quantize_int8 rows composed with the nibble
+    decode, one exact int32 sum per 32-deep group - bit-exact (unit scales, operands bounded so the fp32 fold is exact);
+    (ii) against the oracle's W4A8 formula to fp32 roundoff / one output rounding; the distance to the weight-only W4A16
+    result is REPORTED (activation quantisation error), not claimed.  K = 13696 (428 groups), odd group counts (3, 33,
+    65, 130), ragged M / N, every tile height."""
+    qw, sc = _rand_w4(K, N, dt, seed=K * 7 + N)
+    g = torch.Generator().manual_seed(M + 17)
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt])
+    qd, sd = qw.to(DEV), sc.to(DEV)
+    a8 = X.pack_w4a8(qd, sd)
+    ref = O.w4a8_matmul(t2n(a), qw.numpy(), t2n(sc), t2n(bias), dtype=dt)
+    before = dev_launches()
+    out = X.w4a8_forward(a.to(DEV), a8, N, bias.to(DEV))
+    assert dev_launches() - before == 2                                  # activation quantiser + GEMM
+    err = O.rel_l2(t2n(out), ref)
+    assert err <= {"f16": 3e-4, "bf16": 2e-3}[dt], err
+    # (i) exact integer stage: unit group scales, unit row scales, small operands -> every fp32 partial sum is an integer < 2^24
+    small_a = torch.randint(-15, 16, (M, K), dtype=torch.int8, generator=g)
+    ones = torch.ones_like(sc)
+    a8_1 = X.pack_w4a8(qd, ones.to(DEV))
+    got = X.w4a8_gemm(small_a.to(DEV), torch.ones(M, device=DEV), a8_1, N, TDT[dt]).float().cpu().numpy()
+    want = O.w4a8_group_acc_i32(small_a.numpy(), qw.numpy()).sum(axis=0).astype(np.float64)
+    want_r = O.round_to(want, dt).astype(np.float64)                 # the output cast is the only rounding
+    assert np.array_equal(got.astype(np.float64), want_r)
+    # (ii) reported: distance to the weight-only result on the same inputs
+    ref16 = O.w4_matmul(t2n(a), qw.numpy(), t2n(sc), t2n(bias), dtype=dt)
+    q_err = O.rel_l2(t2n(out), ref16)
+    print(f"[w4a8] {M}x{K}x{N} {dt}: vs oracle W4A8 {err:.2e}; vs W4A16 (activation quantisation error) {q_err:.2e}")
+    assert q_err < 5e-2
+    # the module route (opt-in), row-wise and per-tensor
+    layer = q4.DynamicQuantizeLinear(K, N, bias=True, dtype=TDT[dt])
+    layer.apply_weights_(qw, sc, bias)
+    layer = layer.to(DEV)
+    layer.act_quant = True
+    with torch.no_grad():
+        assert torch.equal(layer(a.to(DEV)), out)
+    layer.act_quant = "per_tensor"
+    ref_t = O.w4a8_matmul(t2n(a), qw.numpy(), t2n(sc), t2n(bias), dtype=dt, per_tensor=True)
+    with torch.no_grad():
+        assert O.rel_l2(t2n(layer(a.to(DEV))), ref_t) <= {"f16": 3e-4, "bf16": 2e-3}[dt]

@@ -53,13 +53,15 @@ def table(bits, M, N, K):
 
 @functools.lru_cache(maxsize=None)
 def m_values(bits, N, K):
-    """BASE_M + every M where the table switches (few-row limit, 256-tile rule, peel on / off), with F - 255, F - 1, F + 1, F + 255."""
+    """BASE_M + every M = F where the table switches, with F - 1 and F + 1; where the kernel FAMILY switches (few-row limit,
+    256-tile rule) also F - 255 and F + 255 (the peel of w_in goes on and off 23 times below 8192 rows: F - 1, F, F + 1 there)."""
     ms, prev = set(BASE_M), None
     for M in range(1, M_MAX + 1):
         fam, first = table(bits, M, N, K)
         cur = (fam, first < M)
         if prev is not None and cur != prev:
-            ms.update(m for m in (M - 255, M - 1, M, M + 1, M + 255) if 1 <= m <= M_MAX)
+            near = (M - 255, M - 1, M, M + 1, M + 255) if cur[0] != prev[0] else (M - 1, M, M + 1)
+            ms.update(m for m in near if 1 <= m <= M_MAX)
         prev = cur
     return tuple(sorted(ms))
 

@@ -47,6 +47,15 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
+    # the developer library exports the product surface + the experiments of include/qlinear_hip_dev.h, and only it does
+    dev_header = open(os.path.join(ROOT, "include", "qlinear_hip_dev.h")).read()
+    dev_declared = set(re.findall(r"^(?:int|size_t)\s+(qlinear_\w+)\s*\(", dev_header, re.M))
+    assert dev_declared == set(_lib.DEV_EXPORTS), dev_declared ^ set(_lib.DEV_EXPORTS)
+    dev = ctypes.CDLL(_lib.DEV_LIB_PATH)
+    for name in declared | dev_declared:
+        assert getattr(dev, name) is not None
+    for name in dev_declared:
+        assert not hasattr(lib, name), name
     assert _lib.get_lib().qlinear_abi_version() == 2
     assert _lib.get_lib().qlinear_status_string(0) == b"ok"
     assert b"group" in _lib.get_lib().qlinear_status_string(-4)

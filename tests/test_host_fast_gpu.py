@@ -261,63 +261,6 @@ def test_release_frees_and_rebuilds_derived_layouts():
         layer.release("nonsense")
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("strict", [False, True])
-@pytest.mark.parametrize("shape,bias", [((4096, 13696), False), ((4096, 13696), True), ((256, 384), True), ((1024, 2752), False)])
-def test_mlp_engine_one_persistent_launch_equals_two(shape, bias, strict, dtype):
-    """qlinear_w4g32_mlp_engine (w4_engine.hip: LDS-DMA loader waves + consumer waves per CU, granule hand-off of the row between
-    the projections) against the two fused launches it replaces - bit for bit, in both arithmetic modes, over repeated launches
-    on one workspace (the launch epoch advances in device memory), real layer size and small sizes (K slices of the first
-    projection, fewer quads than CUs); no bounded wait gave up."""
-    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
-    K, hidden = shape
-    if not h4.mlp_engine_supported(2 * hidden, K, K):
-        pytest.skip("shape not served by the engine on this device")
-    g = torch.Generator(device=DEV).manual_seed(K + hidden)
-    w_in = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
-    w_out = DynamicQuantizeLinear(hidden, K, bias=bias, dtype=dtype, device=DEV)
-    for l in (w_in, w_out):
-        l.weight.copy_(torch.randint(0, 256, l.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
-        l.weight_scale.copy_((torch.rand(l.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
-        if bias:
-            l.bias.copy_((torch.randn(l.bias.shape, device=DEV, generator=g) * 0.1).to(dtype))
-    ln = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
-    gp, gb = w_in.gated_packed(hidden)
-    po = w_out.prepare()._packed
-    ws = h4.mlp_engine_workspace(2 * hidden, DEV)
-    for rep in range(5):
-        x = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
-        y = h4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, x, gp, 2 * hidden, gb, None, ln, None, 1e-5, strict=strict)
-        want = h4.w4_forward_residual(y, po, K, w_out.bias, x, strict=strict)
-        before = _lib.launch_count()
-        got = h4.w4_mlp_engine(x, ln, 1e-5, gp, gb, 2 * hidden, po, w_out.bias, K, ws, strict=strict)
-        assert got is not None and _lib.launch_count() == before + 1
-        torch.cuda.synchronize()
-        assert h4.mlp_engine_error(ws) == 0
-        assert torch.equal(got, want), (rep, int((got != want).sum()))
-
-
-def test_decode_with_the_mlp_engine_equals_the_five_launch_step(monkeypatch):
-    """QLINEAR_MLP_ENGINE: the decode step with the persistent MLP launch (4 launches per layer) produces the token stream of
-    the 5-launch step, eager and from the HIP graph."""
-    model, cfg = _tiny()
-    if not h4.mlp_engine_supported(2 * cfg.inner_hidden_size, cfg.hidden_size, cfg.hidden_size):
-        pytest.skip("tiny MLP not served by the engine")
-    prefix = [3, 17, 200, 5, 77]
-    kw = dict(max_generated_tokens=10, greedy=True, ignore_eos=True)
-    want = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
-    monkeypatch.setattr(M, "MLP_ENGINE", True)
-    before = _lib.launch_count()
-    eager = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
-    n_eager = _lib.launch_count() - before
-    graph = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=True, **kw))
-    assert eager == want and graph == want
-    monkeypatch.setattr(M, "MLP_ENGINE", False)
-    before = _lib.launch_count()
-    list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
-    assert n_eager < _lib.launch_count() - before               # one launch less per layer and step
-
-
 def test_decode_only_session_frees_prefill_layouts_and_decodes_the_same():
     model, cfg = _tiny()
     ids = torch.randint(0, 320, (1, 40), device=DEV)

@@ -631,46 +631,6 @@ def test_int8_model_one_row_step_matches_unfused_graph():
 
 @pytest.mark.usefixtures("exact_dequant_policy")
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("bias", [False, True])
-def test_mlp_pair_one_launch_equals_two(dtype, bias):
-    """qlinear_w4g32_mlp_pair (experiment: both MLP projections of a one-row decode step in ONE launch, the second one's
-    workgroups waiting inside the launch for the first one's row) against the two fused launches it replaces: bit for bit,
-    over repeated launches (the arrival counters reset themselves), and no consumer gave up waiting."""
-    from chatglm_q_amd.int4 import hip_ops as H4
-    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
-    g = torch.Generator(device=DEV).manual_seed(91)
-    K, hidden = 4096, 13696
-    w_in = DynamicQuantizeLinear(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
-    w_out = DynamicQuantizeLinear(hidden, K, bias=bias, dtype=dtype, device=DEV)
-    for l in (w_in, w_out):
-        l.weight.copy_(torch.randint(0, 256, l.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
-        l.weight_scale.copy_((torch.rand(l.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
-        if bias:
-            l.bias.copy_((torch.randn(l.bias.shape, device=DEV, generator=g) * 0.1).to(dtype))
-    ln = (1 + 0.1 * torch.randn(K, device=DEV, generator=g)).to(dtype)
-    gp, gb = w_in.gated_packed(hidden)
-    po = w_out.prepare()._packed
-    for rep in range(4):
-        h = torch.randn(1, 1, K, device=DEV, generator=g).to(dtype)
-        y = H4.w4_forward_fused(_lib.PRO_ADDNORM | _lib.EPI_SILU_GATE, h, gp, 2 * hidden, gb, None, ln, None, 1e-5)
-        want = H4.w4_forward_residual(y, po, K, w_out.bias, h)
-        got = H4.w4_mlp_pair(h, ln, 1e-5, gp, gb, 2 * hidden, po, w_out.bias, K, h)
-        assert got is not None and torch.equal(got, want)
-    torch.cuda.synchronize()
-    assert not H4.mlp_pair_timed_out(DEV)
-    # other shapes are not served: the caller keeps its two launches
-    small = DynamicQuantizeLinear(256, 512, bias=False, dtype=dtype, device=DEV)
-    small.weight.fill_(0x88)
-    small.weight_scale.fill_(0.01)
-    s_out = DynamicQuantizeLinear(256, 256, bias=False, dtype=dtype, device=DEV)
-    s_out.weight.fill_(0x88)
-    s_out.weight_scale.fill_(0.01)
-    x = torch.randn(1, 1, 256, device=DEV, generator=g).to(dtype)
-    assert H4.w4_mlp_pair(x, ln[:256].contiguous(), 1e-5, small.gated_packed(256)[0], None, 512, s_out.prepare()._packed, None, 256, x) is None
-
-
-@pytest.mark.usefixtures("exact_dequant_policy")
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [2, 3, 4])
 @pytest.mark.parametrize("with_delta", [False, True])
 def test_rows_fused_prologue_equals_separate_ops(M, with_delta, dtype):
