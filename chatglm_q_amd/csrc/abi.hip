@@ -237,6 +237,16 @@ int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int 
     return w4_rows_use_gemm(M, N, K) && !w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0) ? 1 : 0;
 }
 
+int qlinear_gated_serves(int64_t M, int64_t N, int64_t K, int dtype, int weight_bits) {
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return 0;
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0) return 0;
+    // the 256 x 256-tile GEMM's SiLU * gate epilogue (contiguous 16-byte aligned rows assumed: the entry points re-check the operands)
+    if (w4_gemm256_supported(M, N, K, K, nullptr, 2)) return 1;
+    if (weight_bits != 4 || K % 32 != 0) return 0;
+    // int4g32 only: the few-row kernel without K slabs (wide first MLP projections, 3..32 rows)
+    return w4_rows_use_gemm(M, N, K) && w4_fewrow_supported(M, N, K) && w4_fewrow_workspace_bytes(M, N, K) == 0 ? 1 : 0;
+}
+
 int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N,
                              int64_t K, int64_t group, int64_t lda, int64_t ldc, int dtype, int flags,
                              void* workspace, size_t workspace_bytes, void* stream) {

@@ -273,6 +273,7 @@ class ChatGLM2Model(nn.Module):
             # int8-activation modules (act_quant, row-wise scales): the producer in front emits the int8 rows + scales itself
             # (qlinear_rmsnorm_quant_i8 / qlinear_silu_mul_quant_i8) - no quantiser launch, no 16-bit copy of the row
             return (PREQUANT and isinstance(mod, Q8) and mod.act_quant is True and mod.in_features % 16 == 0
+                    and mod.in_features <= 16384      # the quantising producers hold a row in registers (decode_ops.hip)
                     and h.dtype in (torch.float16, torch.bfloat16) and mod.weight_scale.dtype == h.dtype)
         # many-position attention in one launch per layer for ChatGLM2's head geometry; the tile flags (which key tiles a block of
         # query rows can skip / needs no mask for) come from one pass over the mask, shared by all layers
@@ -405,6 +406,9 @@ class ChatGLM2Model(nn.Module):
                 and w_in.out_features == 2 * ffn.hidden_dim and ffn.hidden_dim % 2 == 0 and w_in.in_features % 16 == 0
                 and x.numel() // x.shape[-1] >= 1024):     # int8 weight-only at prefill row counts: the same epilogue on the 256-tile GEMM
             from .int8 import hip_ops as H8
+            if not _lib.get_lib().qlinear_gated_serves(x.numel() // x.shape[-1], w_in.out_features, w_in.in_features,
+                                                       _lib.dtype_code(x.dtype), 8):
+                return None                                # asked BEFORE the gate-interleaved copy is built
             tiled, s_perm, b_perm = w_in.gated_tiled(ffn.hidden_dim)
             return H8.w8_forward_tiled_gated(x, tiled, w_in.out_features, s_perm, b_perm)
         if not (isinstance(w_in, Q4) and x.dtype in (torch.float16, torch.bfloat16) and w_in._packed_supported()
@@ -418,6 +422,8 @@ class ChatGLM2Model(nn.Module):
                 return None
             packed, bias = w_in.gated_packed(ffn.hidden_dim)
             return H4.w4_forward_gated(x, packed, w_in.out_features, bias, part1=True)
+        if not _lib.get_lib().qlinear_gated_serves(rows, w_in.out_features, w_in.in_features, _lib.dtype_code(x.dtype), 4):
+            return None                                    # asked BEFORE the gate-interleaved copies are built
         tiled, bias = w_in.gated_tiled(ffn.hidden_dim)
         return H4.w4_forward_gated(x, tiled, w_in.out_features, bias)
 
@@ -466,7 +472,7 @@ class ChatGLM2Model(nn.Module):
             if kind == "int4":
                 packed, bias = mod.gated_packed(gate_hidden) if gate_hidden else (mod.prepare()._packed, mod.bias)
                 out = H4.w4_forward_fused(flags, x, packed, mod.out_features, bias, None, ln.weight, None, ln.eps,
-                                          plan_out=plan_out, guards=(mod.weight, mod.weight_scale))
+                                          plan_out=plan_out, guards=(mod.weight, mod.weight_scale, mod.bias))
             else:
                 w, sc, bias = mod.gated(gate_hidden) if gate_hidden else (mod.weight, mod.weight_scale, mod.bias)
                 out = H8.w8_forward_fused(flags, x, w, sc, bias, None, ln.weight, None, ln.eps, plan_out=plan_out,

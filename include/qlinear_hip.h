@@ -179,6 +179,10 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * qlinear_w4g32_fwd_tiled), 0 when part 1 does: one or two rows (GEMV), 2..4 rows in the default arithmetic on the 4x4x4
  * matrix instruction while the staged rows stay within 64 KB (w4_rows4.hip), fp32 at any row count. */
 int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags);
+/* 1 when qlinear_w4g32_fwd_tiled_gated (weight_bits 4) / qlinear_w8_fwd_tiled_gated (weight_bits 8) serves M rows of a first MLP
+ * projection (N = 2 * hidden outputs) with SiLU * gate in its epilogue, 0 when it would return QL_ERR_UNSUPPORTED for the shape:
+ * lets a host ask BEFORE it builds the gate-interleaved tile-major copy (~120 MB per ChatGLM2-6B layer). */
+int qlinear_gated_serves(int64_t M, int64_t N, int64_t K, int dtype, int weight_bits);
 size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, int64_t group, int dtype,
