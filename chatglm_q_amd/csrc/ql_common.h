@@ -94,18 +94,29 @@ __device__ __forceinline__ void store_out(T* c, float acc, const T* bias_n) {
 #ifndef QL_STORE_TILE_WAIT
 #define QL_STORE_TILE_WAIT 0
 #endif
-template <typename T, typename F>
+// Which element of a 32 x 32 output block accumulator value i (0..15) of a lane is.  LAYOUT 0: one v_mfma_*_32x32 tile (row (i & 3) +
+// 8 (i >> 2) + 4 (lane >> 5), column lane & 31).  LAYOUT 1 (round 4): 2 x 2 v_mfma_*_16x16 tiles, i = r + 4 dn + 8 dm: tile (dm, dn)
+// register r = row 16 dm + 4 (lane >> 4) + r, column 16 dn + (lane & 15).
+template <int LAYOUT>
+struct Tile32 {
+    static __device__ __forceinline__ int row(int i, int lane) {
+        return LAYOUT == 0 ? (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5) : 16 * (i >> 3) + 4 * (lane >> 4) + (i & 3);
+    }
+    static __device__ __forceinline__ int col(int i, int lane) { return LAYOUT == 0 ? (lane & 31) : 16 * ((i >> 2) & 1) + (lane & 15); }
+};
+template <typename T, int LAYOUT = 0, typename F>
 __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
                                                  const T* __restrict__ bias, int lane, F val) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
-    const int j = lane & 31, kb = lane >> 5;
-    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+    typedef Tile32<LAYOUT> TM;
+    const int c0 = TM::col(0, lane), c1 = TM::col(4, lane);      // the lane's column(s): one (LAYOUT 0) or two
+    const float b0 = (bias && n0 + c0 < N) ? Act<T>::load(bias + n0 + c0) : 0.f;
+    const float b1 = (LAYOUT != 0 && bias && n0 + c1 < N) ? Act<T>::load(bias + n0 + c1) : b0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
         float y = Act<T>::round(val(i));
-        if (bias) y = y + bj;
-        Act<T>::store(lds_wave + row * 32 + j, y);
+        if (bias) y = y + ((LAYOUT != 0 && ((i >> 2) & 1)) ? b1 : b0);
+        Act<T>::store(lds_wave + TM::row(i, lane) * 32 + TM::col(i, lane), y);
     }
     // One wave's LDS instructions execute in issue order, so the reads below see the writes above without a wait (round 3: the
     // explicit lgkmcnt(0) here cost one LDS round trip per 32 x 32 tile, 8 tiles per wave in the 256 x 256-tile GEMMs); the wave
@@ -253,19 +264,20 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {   // rounds each v
 // The same epilogue with the residual stream added (chatglm_q/model.py:243,245: hidden = hidden + sublayer(...)): every 8-column
 // row chunk of the rounded tile meets the same chunk of `resid` (row stride ldr) and leaves as round(y + resid) - the sublayer's
 // output is rounded to T first, as the reference materialises it.  16-byte aligned rows of C and resid (checked by the ABI).
-template <typename T, typename F>
+template <typename T, int LAYOUT = 0, typename F>
 __device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restrict__ C, int64_t ldc, const T* __restrict__ resid,
                                                        int64_t ldr, int m_base, int n0, int M, int N, const T* __restrict__ bias,
                                                        int lane, F val) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
-    const int j = lane & 31, kb = lane >> 5;
-    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+    typedef Tile32<LAYOUT> TM;
+    const int c0 = TM::col(0, lane), c1 = TM::col(4, lane);      // the lane's column(s): one (LAYOUT 0) or two
+    const float b0 = (bias && n0 + c0 < N) ? Act<T>::load(bias + n0 + c0) : 0.f;
+    const float b1 = (LAYOUT != 0 && bias && n0 + c1 < N) ? Act<T>::load(bias + n0 + c1) : b0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
         float y = Act<T>::round(val(i));
-        if (bias) y = y + bj;
-        Act<T>::store(lds_wave + row * 32 + j, y);
+        if (bias) y = y + ((LAYOUT != 0 && ((i >> 2) & 1)) ? b1 : b0);
+        Act<T>::store(lds_wave + TM::row(i, lane) * 32 + TM::col(i, lane), y);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -292,18 +304,19 @@ __device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restric
 // (h[2t], h[2t+1], gate[2t], gate[2t+1]), so an 8-column row chunk of the tile holds two complete quads and becomes 4 outputs -
 // out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias as a second rounded operation) - stored as ONE 8-byte
 // chunk of C, which has N / 2 columns.  Requires N % 8 == 0, ldc % 4 == 0 and 8-byte aligned C rows.
-template <typename T, typename F>
+template <typename T, int LAYOUT = 0, typename F>
 __device__ __forceinline__ void store_tile_32x32_gated(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
                                                        const T* __restrict__ bias, int lane, F val) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
-    const int j = lane & 31, kb = lane >> 5;
-    const float bj = (bias && n0 + j < N) ? Act<T>::load(bias + n0 + j) : 0.f;
+    typedef Tile32<LAYOUT> TM;
+    const int c0 = TM::col(0, lane), c1 = TM::col(4, lane);      // the lane's column(s): one (LAYOUT 0) or two
+    const float b0 = (bias && n0 + c0 < N) ? Act<T>::load(bias + n0 + c0) : 0.f;
+    const float b1 = (LAYOUT != 0 && bias && n0 + c1 < N) ? Act<T>::load(bias + n0 + c1) : b0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * kb;
         float y = Act<T>::round(val(i));
-        if (bias) y = y + bj;
-        Act<T>::store(lds_wave + row * 32 + j, y);
+        if (bias) y = y + ((LAYOUT != 0 && ((i >> 2) & 1)) ? b1 : b0);
+        Act<T>::store(lds_wave + TM::row(i, lane) * 32 + TM::col(i, lane), y);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

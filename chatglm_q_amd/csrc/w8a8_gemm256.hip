@@ -130,6 +130,9 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt], 0, 0, 0);
     };
+#ifdef QL_I256_STAMPS
+    unsigned long long t_vm = 0, t_bar = 0;
+#endif
     auto k_tile = [&](int kt, auto curc) {
         constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
         static_for<3>([&](auto sc_) {
@@ -139,8 +142,19 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
             mma_sub(s);
             __builtin_amdgcn_sched_barrier(0);
         });
+#if defined(QL_I256_STAMPS) && QL_I256_STAMPS > 1
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
         vm_wait_imm<0>();                              // tile kt + 1 has landed (this wave's pieces)
+#if defined(QL_I256_STAMPS) && QL_I256_STAMPS > 1
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#if defined(QL_I256_STAMPS) && QL_I256_STAMPS > 1
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        t_vm += ts1 - ts0;
+        t_bar += ts2 - ts1;
+#endif
         read_frags(nxt, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<4 * NT>([&](auto qc) {              // 4 NT MFMAs, 2 PW = 64 / NW = 4 NT requests: one behind each
@@ -161,7 +175,10 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
     }
     if (kt < ktiles) k_tile(kt, std::integral_constant<int, 0>{});
 #ifdef QL_I256_STAMPS
-    if (lane == 0 && (wave % NWN) == 0 && blockIdx.x < 8192) ql_i256_stamps[((size_t)blockIdx.x * 2 + wr) * 4 + 3] = __builtin_amdgcn_s_memtime() - t_loop0;
+    if (lane == 0 && (wave % NWN) == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = ql_i256_stamps + ((size_t)blockIdx.x * 2 + wr) * 4;
+        o[0] = t_vm; o[1] = t_bar; o[2] = t_loop0; o[3] = __builtin_amdgcn_s_memtime() - t_loop0;
+    }
 #endif
     vm_wait_imm<0>();                                  // the queue is empty before LDS is reused
     __syncthreads();                                   // ... and every wave is past its last fragment read
@@ -204,6 +221,192 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
     }
 }
 
+// ---- round 4: the same GEMM as a RING OF FOUR 64-byte K stages on v_mfma_i32_16x16x64_i8, one wave per SIMD ----------------------------
+// What the measurements of the kernel above said (profiles/r04_gemm_power.txt, tools/i256_timeline.py): its loop waits ~10 cycles per K
+// tile for data and ~115 at the barrier, yet takes 2 850 cycles per 2 048 of MFMA issue at ~1.0 - 1.2 GHz - the chip is POWER bound, and
+// (a) on random operands the 16x16 MFMA shapes sustain 12 - 17 % more than the 32x32 ones under the same cap (MFMA-only loops: 3.84 vs
+// 3.29 POP/s; a 32x32 MFMA moves 4 KB of accumulators in and out per 64 K ops, a 16x16x64 one 1 KB per 32 K), (b) with ONE wave per
+// SIMD everything between two MFMAs costs issue slots, and the 16 LDS-DMA requests (M0 save / set / restore each) sat behind the 16
+// MFMAs of one sub-step, the 8 fragment reads in front of each sub-step.  Here:
+//   * 4 waves as 2 x 2, wave tile 128 x 128 = 8 x 8 tiles of 16 x 16 (256 accumulator registers), one MFMA k-step (64 bytes) per stage;
+//   * LDS = 4 stages x (A 256 rows x 64 B | W 256 columns x 64 B) = 128 KB.  Step t: MFMAs on the fragments of stage t (in registers),
+//     fragment reads of stage t + 1 and the 8 requests of stage t + 4 (into the buffer stage t just left) spread BETWEEN its 64 MFMAs;
+//     ONE barrier per step, vmcnt(16) in front of it: two stages stay in flight across every barrier;
+//   * A stage image: row r = 64 bytes = 4 chunks, chunk c at position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 at a 64-byte
+//     pitch), swizzle in the SOURCE address of the LDS-DMA; W: the tile-major copy lands as it lies ([column tile][half][lane]) and a
+//     lane (column c, k quarter q) of column tile 16 n reads unit half q & 1, lane 32 (q >> 1) + 16 (n & 1) + c: 256 contiguous bytes
+//     per 16 lanes.  K order inside the dot product: quarter q of the MFMA = chunk q of both operands' 64 bytes.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+constexpr int kR4Stage = 32768;                    // A 16 KB | W 16 KB
+constexpr int kR4Lds = 4 * kR4Stage;
+
+template <typename T>
+__global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M, int N, int K,
+                                                              int nbx, int super_rows, const float* __restrict__ a_scale,
+                                                              const T* __restrict__ Sc, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // stage[4]; reused by the epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * 256, n0 = tile.x * 256;
+    const int steps = K >> 6;                          // 64-byte K stages
+
+    // ---- staging share of this wave: A pieces 4 wave .. 4 wave + 3 (16 rows x 64 B each), W column tiles 2 wave, 2 wave + 1 (2 KB each) ----
+    unsigned a_off[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int r = 16 * (4 * wave + n) + (lane >> 2), cp = lane & 3;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_off[n] = (unsigned)row * (unsigned)K + (unsigned)((cp ^ ((r >> 2) & 3)) * 16);
+    }
+    const int ctiles = (N + 31) >> 5;
+    const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)Aq);
+    unsigned long long w_base[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ct_raw = tile.x * 8 + 2 * wave + c;
+        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;      // clamped: loads stay in bounds, stores are masked
+        w_base[c] = sgpr64((unsigned long long)(uintptr_t)Wm + (unsigned long long)ct * (unsigned long long)steps * 2048ull);
+    }
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;                  // + stage * kR4Stage + n * 1024
+    const unsigned w_dma = lds0 + 16384u + (unsigned)(4 * wave) * 1024u;         // + stage * kR4Stage + u * 1024
+    // fragment read addresses: stages 0 / 1 through the 16-bit immediate of one base, stages 2 / 3 of a second one
+    const int a_rd0 = (128 * wr + c16) * 64 + ((kq ^ ((c16 >> 2) & 3)) * 16);    // + mt * 1024
+    const int w_rd0 = 16384 + (4 * wc) * 2048 + (kq & 1) * 1024 + (32 * (kq >> 1) + c16) * 16;   // + (nt >> 1) * 2048 + (nt & 1) * 256
+    const char* a_rd[2] = {smem + a_rd0, smem + a_rd0 + 2 * kR4Stage};
+    const char* w_rd[2] = {smem + w_rd0, smem + w_rd0 + 2 * kR4Stage};
+
+    i32x4v acc[8][8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = i32x4v{0, 0, 0, 0};
+
+    auto issue_piece = [&](int t, int buf, int q) {    // q = 0 .. 3: A pieces, 4 .. 7: W units (column tile (q - 4) >> 1, half (q - 4) & 1)
+        const int k = t < steps ? t : steps - 1;       // past the end: the last stage again (never read; keeps the queue counts fixed)
+        if (q < 4) glds16(a_dma + (unsigned)(buf * kR4Stage + q * 1024), a_off[q], sgpr64(a_base + (unsigned long long)k * 64ull));
+        else {
+            const int u = q - 4;
+            glds16(w_dma + (unsigned)(buf * kR4Stage + u * 1024), w_voff, sgpr64(w_base[u >> 1] + (unsigned long long)(2 * k + (u & 1)) * 1024ull));
+        }
+    };
+    i32x4 fa[2][8], fb[2][8];
+    auto read_a = [&](int buf, int mt, i32x4& x) { x = *reinterpret_cast<const i32x4*>(a_rd[buf >> 1] + (buf & 1) * kR4Stage + mt * 1024); };
+    auto read_b = [&](int buf, int nt, i32x4& x) {
+        x = *reinterpret_cast<const i32x4*>(w_rd[buf >> 1] + (buf & 1) * kR4Stage + (nt >> 1) * 2048 + (nt & 1) * 256);
+    };
+
+    // ---- prologue: stages 0 .. 3 requested, stage 0 landed, its fragments read ------------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(st, st, q);
+    vm_wait_imm<24>();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { read_b(0, i, fb[0][i]); read_a(0, i, fa[0][i]); }
+
+    // ---- step t (buffer t & 3 = BUF): barrier (stage t + 1 landed everywhere, every wave's fragments of stage t are in registers), then
+    // 64 MFMAs with the 16 fragment reads of stage t + 1 behind the first 32 and the 8 requests of stage t + 4 behind every 8th
+    auto step = [&](int t, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value, NXT = (BUF + 1) & 3, cur = BUF & 1, nxt = cur ^ 1;
+        vm_wait_imm<16>();                             // this wave's pieces of stage t + 1 have landed (two younger stages in flight)
+        __syncthreads();
+        static_for<64>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, mt = q >> 3, nt = (mt & 1) ? 7 - (q & 7) : (q & 7);   // serpentine: B fragment reused across the turn
+            // accumulators pinned to the accumulation registers ("+a": left to its own allocation hipcc kept part of the 64 tiles in
+            // VGPRs and moved them back and forth around every step, with spills).  The operands come from ds_read_b128 (hipcc
+            // places the lgkmcnt waits for the "v" inputs itself); nothing reads an accumulator before the epilogue.
+            // The WEIGHT fragment is the first operand: D[i][j] has i = output column, j = row, so a lane ends up with FOUR CONSECUTIVE
+            // COLUMNS of one row (column 4 (lane >> 4) + r, row lane & 15) and the epilogue stores 8-byte row pieces straight from
+            // registers - no LDS transposition (the 32x32 kernels' epilogue: 16 two-byte LDS stores per tile and lane).
+            asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(fb[cur][nt]), "v"(fa[cur][mt]));
+            if constexpr (q < 32 && (q & 1) == 0) {
+                constexpr int i = q >> 1;              // 16 reads: B 0..7 first (all needed by the next step's first row of tiles), then A
+                if constexpr (i < 8) read_b(NXT, i, fb[nxt][i]);
+                else read_a(NXT, i - 8, fa[nxt][i - 8]);
+            }
+            if constexpr ((q & 7) == 5) issue_piece(t + 4, BUF, q >> 3);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    int t = 0;
+    for (; t + 4 <= steps; t += 4) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+        step(t + 2, std::integral_constant<int, 2>{});
+        step(t + 3, std::integral_constant<int, 3>{});
+    }
+    if (t < steps) step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < steps) step(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 < steps) step(t + 2, std::integral_constant<int, 2>{});
+    vm_wait_imm<0>();                                  // the queue is empty before LDS is reused
+    __syncthreads();                                   // ... and every wave is past its last fragment read
+
+    // ---- epilogue: rank-1 scales, 4 consecutive columns of one row per lane and tile -> one 8-byte store -------------------------------
+    const int mw = m0 + 128 * wr, nw = n0 + 128 * wc;
+    const bool wide = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+    float asc[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = mw + 16 * mt + c16;
+        asc[mt] = a_scale[m < M ? m : M - 1];
+    }
+    static_for<8>([&](auto ntc) {
+        constexpr int nt = decltype(ntc)::value;
+        const int nb = nw + 16 * nt + 4 * kq;          // first of the lane's 4 columns
+        float ws[4], bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + r < N ? nb + r : N - 1;
+            ws[r] = Act<T>::load(Sc + n);
+            bs[r] = bias ? Act<T>::load(bias + n) : 0.f;
+        }
+        static_for<8>([&](auto mtc) {
+            constexpr int mt = decltype(mtc)::value;
+            const int m = mw + 16 * mt + c16;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = (float)acc[mt][nt][r] * (asc[mt] * ws[r]);
+                asm volatile("" : "+v"(p));            // the fp32 product exists (the reference's Cast, Mul, then the output dtype:
+                y[r] = Act<T>::round(p);               // chatglm_q/int8/qlinear.py:60-62); left fusable hipcc rounds product -> f16 once
+                if (bias) y[r] = y[r] + bs[r];
+            }
+            if (m < M) {
+                T* dst = C + (int64_t)m * ldc + nb;
+                if (wide && nb + 4 <= N) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(y[0], y[1]), pack2<T>(y[2], y[3])};
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < N) Act<T>::store(dst + r, y[r]);
+            }
+        });
+    });
+}
+
+template <typename T>
+static int launch_i256_r4(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                          int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_r4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kR4Lds) == hipSuccess;
+    }();
+    (void)attr_set;
+    const int nbx = (int)((N + 255) / 256), nby = (int)((M + 255) / 256);
+    const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
+    const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
+    const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+    w8a8_gemm256_r4_kernel<T><<<(unsigned)(nbx * nby), 256, kR4Lds, st>>>(
+        Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), super ? sy : 0, a_scale,
+        (const T*)S, (const T*)bias, (T*)C, ldc);
+    return finish_launch(QL_K_W8A8_GEMM256);
+}
+
 template <typename T, int NW>
 static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                           int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
@@ -225,9 +428,13 @@ static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* 
 #ifndef QL_I256_NW
 #define QL_I256_NW 4
 #endif
+#ifndef QL_I256_RING
+#define QL_I256_RING 1
+#endif
 template <typename T>
 static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                        int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    if (QL_TUNE("QLINEAR_I256_RING", QL_I256_RING)) return launch_i256_r4<T>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 #ifdef QL_DEV_TUNING
     if (QL_TUNE("QLINEAR_I256_NW", QL_I256_NW) != QL_I256_NW)
         return launch_i256_nw<T, 12 - QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);

@@ -31,5 +31,10 @@ b = buf.astype(np.float64)
 kt = K // 128
 loop = b[:, 0, 3].mean()
 rounds = -(-blocks // 256)
+print(f"waits per K tile (wave 0 / wave NWN): vmcnt {b[:, 0, 0].mean() / kt:.0f} / {b[:, 1, 0].mean() / kt:.0f}, barrier {b[:, 0, 1].mean() / kt:.0f} / {b[:, 1, 1].mean() / kt:.0f} cycles"
+      f" (QL_I256_STAMPS=2 builds; 0 otherwise)")
+t0 = b[:, 0, 2]
+order = np.argsort(t0)
+print("block start spread (cycles, sorted starts, every 32nd):", [int(t0[i] - t0[order[0]]) for i in order[::32]][:20])
 print(f"{M}x{K}x{N}: {us:.1f} us per launch; K loop {loop / kt:.0f} cycles per K tile (pure MFMA issue: 2048), {loop:.0f} per block; "
       f"{rounds} rounds -> implied clock >= {rounds * loop / us / 1e3:.2f} GHz")
