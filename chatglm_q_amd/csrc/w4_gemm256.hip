@@ -400,6 +400,439 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     }
 }
 
+// ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
+// int8 kernel from 1.81 to 2.07 POP/s (w8a8_gemm256.hip) applied to the weight-only GEMM.  Measured at 8192 rows, qkv / o / w_in / w_out,
+// TFLOP/s (tools/gemm_yardstick.py, profiles/r04_gemm_power.txt): kernel above 987 / 1 145 / 1 147 / 1 185; ring, 8 waves, jobs between the
+// MFMAs 900 / 1 117 / 1 103 / 1 171; ring, 4 waves 814 / 1 015 / 1 057 / 1 100; ring, 8 waves, ping-pong phases 818 / 976 / 1 036 / 1 094;
+// younger-wave priority 1 / 2: within the run-to-run spread.  Four loop structures, two MFMA shapes, one result: this GEMM is bound by
+// the power budget at the energy per flop its dequant + LDS round trip cost, not by how its instructions are arranged.  Not shipped.
+#ifdef QL_DEV_TUNING
+// The same GEMM as a RING OF FOUR 32-deep K stages on v_mfma_f32_16x16x32_{f16,bf16}, one wave per SIMD -----------------------
+// Why (profiles/r04_gemm_power.txt): these GEMMs are POWER bound (the loop above idles ~20 % of its cycles at ~1.4 GHz), MFMA-only loops
+// on random operands sustain 1.92 - 1.99 PFLOP/s with the 16x16x32 shape against 1.71 - 1.78 with 32x32x16 under the same cap (a 32x32 MFMA
+// moves 4 KB of accumulators in and out per 32 K flops, a 16x16 one 1 KB per 16 K), the vendor's dense f16 kernel on this chip is
+// MT256x256x64 / MI16x16 / 4 waves - and the int8 x int8 kernel restructured this way went 1.81 -> 2.07 POP/s (w8a8_gemm256.hip).
+//   * 4 waves as 2 x 2, wave tile 128 x 128 = 8 x 8 tiles of 16 x 16, 256 accumulator registers pinned to the AGPRs;
+//   * stage = 32 k = ONE int4 group = one MFMA k-step: A 256 rows x 64 B by LDS-DMA (swizzle in the source address, chunk c of row r at
+//     position c ^ ((r >> 2) & 3)), B 256 columns x 32 k dequantised ONCE per block - each of the 256 threads owns one unit (column,
+//     group) per stage, builds its four 8-half fragments dword by dword BETWEEN the MFMAs and stores them fragment-major
+//     ([16-column tile][lane 16 q + c][16 B]); 4 stages x (16 + 16) KB = 128 KB of LDS;
+//   * step t: barrier (A(t + 1), B(t + 1) visible; everybody's fragments of stage t are in registers), 64 MFMAs on stage t with, in
+//     between: the 16 fragment reads of stage t + 1, the dequant of stage t + 2 (its unit was requested two steps ago), the requests
+//     of stage t + 4 (2 weight loads into register set t & 3, 4 A pieces into the buffer stage t just left).  vmcnt(10) at the barrier;
+//   * the WEIGHT fragment is the MFMA's first operand: D[i][j] has i = output column, so a lane holds FOUR CONSECUTIVE COLUMNS of one
+//     row per tile and the epilogue stores 8-byte row pieces straight from registers (SiLU * gate: the lane's four columns are one
+//     (h, h, gate, gate) quad -> one 4-byte store; residual: one 8-byte load) - no LDS transposition.
+#ifdef QL_R4_STAMPS                                  // developer build (tools/r4_timeline.py): wave 0 of every block stamps its phases
+__device__ unsigned long long ql_r4_stamps[16384 * 12];
+#define QL_R4_STAMP(i) do { if (stamp_on) { st_rt[i] = __builtin_amdgcn_s_memrealtime(); st_ck[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define QL_R4_STAMP(i) do { } while (0)
+#endif
+constexpr int kR4Stage = 32768;                    // A 16 KB | B 16 KB
+constexpr int kR4Lds = 4 * kR4Stage;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ void mfma16_acc(f32x4v& acc, const u32x4& w, const u32x4& a) {
+    // accumulators pinned to the accumulation registers ("+a": left to itself hipcc kept part of the 64 tiles in VGPRs and moved
+    // them around every step, with spills); operands come from ds_read_b128 (hipcc places the lgkmcnt waits for "v" inputs itself)
+    if constexpr (Act<T>::code == QL_DTYPE_F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+}
+
+__device__ __forceinline__ void gload8(u32x2& dst, unsigned voff, unsigned long long base) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_imm(u32x2& w, unsigned& s) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w), "+v"(s) : "n"(N) : "memory");
+}
+
+// NW = 4: 2 x 2 waves, wave tile 128 x 128 (one wave per SIMD).  NW = 8: 2 x 4 waves, wave tile 128 x 64, two waves per SIMD - from ONE
+// wave a 16x16 MFMA issues every 20 cycles instead of 16 (tools/microbench/mfma_i8_rate.hip) and the dequant VALU has nothing to hide
+// behind; two waves alternate on the pipe at the full rate.  With 8 waves a thread dequantises HALF a unit (fragments 2 h, 2 h + 1,
+// h = wave >> 2) and the 128 + 128 register budget holds the next stage's A fragments one row behind the current one's.
+// PP (8 waves): PING-PONG.  The two waves of a SIMD (w, w + 4: the wave tile rows 0..127 / 128..255) run half a step apart - a step is
+// [barrier, M: the 32 MFMAs back to back] [barrier, J: fragment reads of the next stage, dequant, requests], and group 1 passes one
+// extra barrier first, so while one wave of a SIMD issues its MFMAs (one per 16 cycles: half the pipe) the other one's LDS / VALU /
+// vector-memory instructions go to the other units.  Measured reason (tools/r4_timeline.py): with both waves in the same phase and
+// their jobs spread between their MFMAs the older wave of each SIMD ran ahead and waited 450 - 530 of every 1 480 - 1 570 cycles at the
+// step's barrier while the younger one finished alone.  M ends before J starts, so ONE set of fragment registers serves both.
+template <typename T, bool W8, bool GATE, int NW, bool PP>
+__global__ __launch_bounds__(NW * 64) void w4_gemm256_r4_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                                int M, int N, int steps, int wsteps, int64_t lda, int nbx, int super_rows,
+                                                                const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                                const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+    static_assert(NW == 4 || NW == 8, "4 waves (2 x 2) or 8 waves (2 x 4)");
+    static_assert(!PP || NW == 8, "ping-pong needs two waves per SIMD");
+    typedef Mma<T> MM;
+    constexpr int NWN = NW / 2;                        // waves side by side in N
+    constexpr int NT = 16 / NWN;                       // 16-column tiles per wave
+    constexpr int NAL = 16 / NW;                       // A pieces a wave stages per step
+    constexpr int NFR = 16 / NW;                       // fragments (of the unit's 4) a thread dequantises: 4 or 2
+    constexpr int NWL = (W8 && NW == 8) ? 1 : 2;       // weight loads per step and thread
+    constexpr int S = 8 * NT;                          // MFMAs per wave and step
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // stage[4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef QL_R4_STAMPS
+    unsigned long long st_rt[4], st_ck[4];
+    const bool stamp_on = wave == 0;
+    QL_R4_STAMP(0);
+#endif
+    const int wr = wave / NWN, wc = wave % NWN;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    const int m0 = tile.y * 256, n0 = tile.x * 256;
+
+    u32 k_mask_lo, k_mask_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
+
+    // ---- staging share: A pieces NAL wave .. (16 rows x 64 B each); weights: unit of column 64 (wave & 3) + lane (column tile
+    // 2 (wave & 3) + (lane >> 5) of the block's 8, j = lane & 31), group t; with 8 waves: its half h = wave >> 2 ----------------------------
+    unsigned a_off[NAL];
+#pragma unroll
+    for (int n = 0; n < NAL; ++n) {
+        const int r = 16 * (NAL * wave + n) + (lane >> 2), cp = lane & 3;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 2) & 3)) * 16);
+    }
+    const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
+    const int ctiles = (N + 31) >> 5;
+    const int wu = wave & 3, hh = NW == 8 ? wave >> 2 : 0;
+    const int ct0_raw = tile.x * 8 + 2 * wu;
+    const int ct0 = ct0_raw < ctiles ? ct0_raw : ctiles - 1;       // clamped: loads stay in bounds, stores are masked
+    const int ct1 = ct0_raw + 1 < ctiles ? ct0_raw + 1 : ctiles - 1;
+    const int jw = lane & 31, ctl = lane >> 5;
+    constexpr unsigned long long kWStep = W8 ? 2048ull : 1024ull;     // bytes of one column tile and 64-deep K step of the tile-major copy
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct0 * (unsigned long long)wsteps * kWStep +
+                                             (unsigned long long)hh * (W8 ? 1024ull : 8ull));
+    const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct0 * (unsigned long long)wsteps * (64ull * sizeof(T)));
+    const unsigned ct_d = ctl ? (unsigned)(ct1 - ct0) : 0u;           // 0 or 1 column tiles past ct0
+    const unsigned w_voff = ct_d * (unsigned)wsteps * (unsigned)kWStep + (unsigned)jw * 16u;
+    const unsigned s_voff = (ct_d * (unsigned)wsteps * 64u + (unsigned)jw) * (unsigned)sizeof(T);
+    const float sc8 = W8 ? Act<T>::load(Sp + (32 * (ctl ? ct1 : ct0) + jw < N ? 32 * (ctl ? ct1 : ct0) + jw : N - 1)) : 0.f;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+    const unsigned a_dma = lds0 + (unsigned)(NAL * wave) * 1024u;                // + stage * kR4Stage + n * 1024
+    // MFMA tile nt of the block (16 per block) does NOT cover 16 consecutive columns: its index i is column 32 (nt >> 1) + 8 (i >> 2) +
+    // 4 (nt & 1) + (i & 3), so that the lane holding D rows 4 q .. 4 q + 3 of tiles 2 p and 2 p + 1 holds EIGHT CONSECUTIVE columns
+    // 32 p + 8 q + 0..7 of its row: one 16-byte store, 64 contiguous bytes per row and instruction.  The B image is [tile][16 q + (i ^
+    // 8 (nt & 1))]: fragment reads are lane-linear up to that flip, which keeps the two tiles a 16-column run writes to on different banks.
+    // This thread's column 32 pc + jw -> tile 2 pc + ((jw >> 2) & 1), index 4 (jw >> 3) + (jw & 3).
+    const int pcw = 2 * wu + ctl, tb = (jw >> 2) & 1;
+    char* b_wr = smem + 16384 + ((2 * pcw + tb) * 64 + ((4 * (jw >> 3) + (jw & 3)) ^ (8 * tb))) * 16 + (NFR == 2 ? hh * 512 : 0);   // + stage * kR4Stage + i * 256
+    const int a_rd0 = (128 * wr + c16) * 64 + ((kq ^ ((c16 >> 2) & 3)) * 16);    // + mt * 1024
+    const int b_rd0 = 16384 + (NT * wc) * 1024 + (16 * kq + c16) * 16, b_rd1 = 16384 + (NT * wc) * 1024 + (16 * kq + (c16 ^ 8)) * 16;   // even / odd tiles, + nt * 1024
+    const char* a_rd[2] = {smem + a_rd0, smem + a_rd0 + 2 * kR4Stage};
+    const char* b_rd[2][2] = {{smem + b_rd0, smem + b_rd0 + 2 * kR4Stage}, {smem + b_rd1, smem + b_rd1 + 2 * kR4Stage}};
+
+    f32x4v acc[8][NT];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // the thread's share of the unit of stage s in register set s & 3.  4 waves: int4 the 16-byte unit + its scale, int8 bytes 0..15 +
+    // bytes 16..31.  8 waves: int4 words 2 h, 2 h + 1 + the scale, int8 bytes 16 h .. 16 h + 15.
+    std::conditional_t<(NFR == 2 && !W8), u32x2, i32x4> wq[4];
+    std::conditional_t<W8, i32x4, unsigned> wsc[4];
+    auto issue_a = [&](int t, int buf, int n) {
+        const int k = t < steps ? t : steps - 1;       // past the end: the last stage again (never read; keeps the queue counts fixed)
+        glds16(a_dma + (unsigned)(buf * kR4Stage + n * 1024), a_off[n], sgpr64(a_base + (unsigned long long)k * 64ull));
+    };
+    auto issue_w = [&](int t, int set, int part) {     // stage t = half (t & 1) of 64-deep step t >> 1 of the tile-major copy
+        const int k = t < steps ? t : steps - 1;
+        if constexpr (W8) {                            // [step][half h][lane 32 kb + j]: bytes 16 h + 0..15 of the stage's 32
+            const unsigned long long b = sgpr64(w_base + (unsigned long long)(k >> 1) * 2048ull + (unsigned long long)(k & 1) * 512ull + (unsigned long long)part * 1024ull);
+            if (part == 0) gload16(wq[set], w_voff, b);
+            else gload16(wsc[set], w_voff, b);
+        } else {
+            const unsigned long long b = sgpr64(w_base + (unsigned long long)(k >> 1) * 1024ull + (unsigned long long)(k & 1) * 512ull);
+            if (part == 0) {
+                if constexpr (NFR == 2) gload8(wq[set], w_voff, b);
+                else gload16(wq[set], w_voff, b);
+            } else gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)((k >> 1) * 64 + (k & 1) * 32) * sizeof(T)));
+        }
+    };
+    typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
+    auto scale_of = [&](auto raw) {
+        if constexpr (W8) return MM::scale_pair((const T*)nullptr, false);          // unused: the channel scale is sc8
+        else {
+            const uint16_t h = (uint16_t)raw;
+            T sv;
+            __builtin_memcpy(&sv, &h, 2);
+            return MM::scale_pair(&sv, true);
+        }
+    };
+    // dword d (0..3) of the thread's i-th fragment (fragment NFR hh + i of the unit) from register set `set`
+    auto dequant_dword = [&](int set, int i, int d, scale_t sc) -> u32 {
+        if constexpr (W8) {
+            const i32x4& unit = (NFR == 4 && (i >> 1)) ? wsc[set] : wq[set];
+            const u32x4 f = w8_dequant_natural<T>((u32)unit[2 * (i & 1)], (u32)unit[2 * (i & 1) + 1], sc8);   // hipcc keeps the dword asked for
+            return f[d];
+        } else {
+            return MM::dequant_part((u32)wq[set][i], d, k_mask_lo, k_mask_hi, k_magic, sc);
+        }
+    };
+    auto wait_w = [&](auto nc, int set) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (NWL == 1) vm_wait_imm<n>(wq[set]);
+        else vm_wait_imm<n>(wq[set], wsc[set]);
+    };
+    constexpr int NFB = PP ? 1 : 2;                    // fragment register sets
+    u32x4 fa[NFB][8], fb[NFB][NT];
+    auto read_a = [&](int buf, int mt, u32x4& x) { x = *reinterpret_cast<const u32x4*>(a_rd[buf >> 1] + (buf & 1) * kR4Stage + mt * 1024); };
+    auto read_b = [&](int buf, int nt, u32x4& x) { x = *reinterpret_cast<const u32x4*>(b_rd[nt & 1][buf >> 1] + (buf & 1) * kR4Stage + nt * 1024); };
+
+    // ---- prologue.  Queue order (the steady state's): W(0) W(1) | A(0) A(1) | W(2) A(2) | W(3) A(3) --------------------------------
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int part = 0; part < NWL; ++part) issue_w(st, st, part);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int n = 0; n < NAL; ++n) issue_a(st, st, n);
+#pragma unroll
+    for (int st = 2; st < 4; ++st) {
+#pragma unroll
+        for (int part = 0; part < NWL; ++part) issue_w(st, st, part);
+#pragma unroll
+        for (int n = 0; n < NAL; ++n) issue_a(st, st, n);
+    }
+    wait_w(std::integral_constant<int, 4 * NAL + 2 * NWL>{}, 0);
+    wait_w(std::integral_constant<int, 4 * NAL + 2 * NWL>{}, 1);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const scale_t sc = scale_of(wsc[st]);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            u32x4 f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) f[d] = dequant_dword(st, i, d, sc);
+            *reinterpret_cast<u32x4*>(b_wr + st * kR4Stage + i * 256) = f;
+        }
+    }
+    if constexpr (PP) vm_wait_imm<2 * (NAL + NWL)>(); // A(0) and A(1) have landed (the ping-pong steps' rule: a stage's pieces are
+    else vm_wait_imm<3 * NAL + 2 * NWL>();             // waited for one step before their first readers); otherwise A(0) alone
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NT; ++i) read_b(0, i, fb[0][i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_a(0, i, fa[0][i]);
+
+    if constexpr (PP) {
+        // ---- ping-pong steps.  Barrier events: group 0's k-th call meets group 1's k-th call, and group 1 made one call more at the
+        // start, so between two events one group is in M(t) and the other in J(t - 1) / J(t).  What the barriers order:
+        //   * J(t) reads stage t + 1: its B image was written in everybody's J(t - 1), its A pieces requested in J(t - 3) and waited
+        //     for at the END of J(t - 1) (vmcnt(2 (NAL + NWL))) - both at least one event before either group's J(t);
+        //   * J(t) refills buffer t & 3 (A pieces of stage t + 4): its last readers were the J(t - 1)s, one event earlier at least;
+        //   * J(t) dequantises stage t + 2 (requested in J(t - 2): vmcnt(2 NAL + NWL) at its start) into buffer (t + 2) & 3.
+        QL_R4_STAMP(1);
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        auto step_pp = [&](int t, auto bufc) {
+            constexpr int BUF = decltype(bufc)::value, NXT = (BUF + 1) & 3, DQ = (BUF + 2) & 3;
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(1);
+            static_for<S>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, mt = q / NT, nt = q % NT;
+                mfma16_acc<T>(acc[mt][nt], fb[0][nt], fa[0][mt]);
+            });
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();
+            wait_w(std::integral_constant<int, 2 * NAL + NWL>{}, DQ);       // W(t + 2) has landed
+#pragma unroll
+            for (int i = 0; i < NT; ++i) read_b(NXT, i, fb[0][i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) read_a(NXT, i, fa[0][i]);
+            const scale_t sc = scale_of(wsc[DQ]);
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {
+                u32x4 f;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) f[d] = dequant_dword(DQ, i, d, sc);
+                *reinterpret_cast<u32x4*>(b_wr + DQ * kR4Stage + i * 256) = f;
+            }
+#pragma unroll
+            for (int part = 0; part < NWL; ++part) issue_w(t + 4, BUF, part);
+#pragma unroll
+            for (int n = 0; n < NAL; ++n) issue_a(t + 4, BUF, n);
+            vm_wait_imm<2 * (NAL + NWL)>();            // this wave's pieces of A(t + 2) have landed
+        };
+        int t = 0;
+        for (; t + 4 <= steps; t += 4) {
+            step_pp(t, std::integral_constant<int, 0>{});
+            step_pp(t + 1, std::integral_constant<int, 1>{});
+            step_pp(t + 2, std::integral_constant<int, 2>{});
+            step_pp(t + 3, std::integral_constant<int, 3>{});
+        }
+        if (t < steps) step_pp(t, std::integral_constant<int, 0>{});
+        if (t + 1 < steps) step_pp(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < steps) step_pp(t + 2, std::integral_constant<int, 2>{});
+        if (wr == 0) __builtin_amdgcn_s_barrier();     // the call group 1 made first
+    } else {
+    // ---- step t (buffer / register set t & 3 = BUF): row mt of the wave tile = NT MFMAs; the next stage's A fragment of row mt is read
+    // behind the row's first MFMA (one row of slack: 9 live A fragments), its B fragments in the first rows, the dequant dwords of stage
+    // t + 2 one per second MFMA, the requests of stage t + 4 in the second half ---------------------------------------------------------------
+#ifdef QL_R4_STAMPS
+    unsigned long long t_vm = 0, t_bar = 0;
+#endif
+    auto step = [&](int t, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value, NXT = (BUF + 1) & 3, DQ = (BUF + 2) & 3, cur = BUF & 1, nxt = cur ^ 1;
+#if defined(QL_R4_STAMPS) && QL_R4_STAMPS > 1
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+        wait_w(std::integral_constant<int, 2 * NAL + NWL>{}, DQ);   // W(t + 2) and A(t + 1) have landed (this wave's pieces)
+#if defined(QL_R4_STAMPS) && QL_R4_STAMPS > 1
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+#if defined(QL_R4_STAMPS) && QL_R4_STAMPS > 1
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        t_vm += ts1 - ts0;
+        t_bar += ts2 - ts1;
+#endif
+        const scale_t sc = scale_of(wsc[DQ]);
+        u32x4 f;
+        static_for<S>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, mt = q / NT, nt = q % NT;
+            mfma16_acc<T>(acc[mt][nt], fb[cur][nt], fa[cur][mt]);
+            // at most one job behind an MFMA, jobs of a kind every fourth MFMA (one wave issues in order: whatever stands between two
+            // of its MFMAs beyond ~3 instructions delays the second one)
+            if constexpr (nt == 0) read_a(NXT, mt, fa[nxt][mt]);                                   // q = NT mt     (q % 4 == 0)
+            if constexpr ((q & 7) == 2 && (q >> 3) < NT) read_b(NXT, q >> 3, fb[nxt][q >> 3]);      // q = 8 nt + 2  (q % 4 == 2)
+            if constexpr ((q & 3) == 1 && (q >> 2) < 4 * NFR) {    // one dword of a fragment at a time; fragment stored when complete
+                constexpr int p = q >> 2, i = p >> 2, d = p & 3;
+                f[d] = dequant_dword(DQ, i, d, sc);
+                if constexpr (d == 3) *reinterpret_cast<u32x4*>(b_wr + DQ * kR4Stage + i * 256) = f;
+            }
+            // queue order inside a step: the weight loads, THEN the A pieces (the wait counts above are written for that order)
+            if constexpr (q >= S / 2 && (q & 3) == 3 && (q - S / 2) / 4 < NWL) issue_w(t + 4, BUF, (q - S / 2) / 4);
+            if constexpr (q >= S / 2 && (q & 3) == 3 && (q - S / 2) / 4 >= NWL && (q - S / 2) / 4 < NWL + NAL) issue_a(t + 4, BUF, (q - S / 2) / 4 - NWL);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    static_assert(S / 4 >= 4 * NFR && S / 8 >= NWL + NAL && S / 8 >= NT, "every job has its slot");
+    QL_R4_STAMP(1);
+#ifdef QL_R4_YOUNG_PRIO
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(QL_R4_YOUNG_PRIO);   // experiment: the younger wave of each SIMD served first
+#endif
+    int t = 0;
+    for (; t + 4 <= steps; t += 4) {
+        step(t, std::integral_constant<int, 0>{});
+        step(t + 1, std::integral_constant<int, 1>{});
+        step(t + 2, std::integral_constant<int, 2>{});
+        step(t + 3, std::integral_constant<int, 3>{});
+    }
+    if (t < steps) step(t, std::integral_constant<int, 0>{});
+    if (t + 1 < steps) step(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 < steps) step(t + 2, std::integral_constant<int, 2>{});
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) wait_w(std::integral_constant<int, 0>{}, st);   // the queue is empty before the registers go out of scope
+    QL_R4_STAMP(2);
+
+    // ---- epilogue: 8 consecutive columns of one row per lane and tile pair -> one 16-byte store ---------------------------------------------
+    const int mw = m0 + 128 * wr, nw = n0 + 16 * NT * wc;
+    const bool wide = GATE || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                               (!resid || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(resid) & 15) == 0)));   // GATE: 8-byte stores, checked by the ABI
+    static_for<NT / 2>([&](auto ppc) {
+        constexpr int pp = decltype(ppc)::value;
+        const int nb = nw + 32 * pp + 8 * kq;          // first of the lane's 8 columns
+        float bs[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bs[r] = (bias && nb + r < N) ? Act<T>::load(bias + nb + r) : 0.f;
+        static_for<8>([&](auto mtc) {
+            constexpr int mt = decltype(mtc)::value;
+            const int m = mw + 16 * mt + c16;
+            float y[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                y[r] = Act<T>::round(r < 4 ? acc[mt][2 * pp][r & 3] : acc[mt][2 * pp + 1][r & 3]);
+                if (bias) y[r] = Act<T>::round(y[r] + bs[r]);
+            }
+            if (m >= M || nb >= N) return;
+            if constexpr (GATE) {                      // two (h0, h1, gate0, gate1) quads -> out[nb / 2 + 0..3] = round(round(silu(h)) * gate)
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float hv = y[4 * (i >> 1) + (i & 1)], gv = y[4 * (i >> 1) + 2 + (i & 1)];
+                    o[i] = Act<T>::round(hv / (1.0f + __expf(-hv))) * gv;
+                }
+                T* dst = C + (int64_t)m * ldc + (nb >> 1);
+                if (nb + 8 <= N) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+                else *reinterpret_cast<u32*>(dst) = pack2<T>(o[0], o[1]);                    // N % 8 == 4: the last quad alone
+            } else {
+                T* dst = C + (int64_t)m * ldc + nb;
+                if (wide && nb + 8 <= N) {
+                    if (resid) {
+                        float r[8];
+                        unpack8<T>(*reinterpret_cast<const u32x4*>(resid + (int64_t)m * ldr + nb), r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] += r[e];
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = pack8<T>(y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if (nb + r < N) Act<T>::store(dst + r, resid ? y[r] + Act<T>::load(resid + (int64_t)m * ldr + nb + r) : y[r]);
+                }
+            }
+        });
+    });
+#ifdef QL_R4_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left
+    QL_R4_STAMP(3);
+    if (stamp_on && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long* o = ql_r4_stamps + (size_t)blockIdx.x * 12;
+        o[10] = t_vm; o[11] = t_bar;
+        for (int i = 0; i < 4; ++i) { o[i] = st_rt[i]; o[4 + i] = st_ck[i]; }
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[8] = hw; o[9] = xcc;
+    }
+#endif
+}
+
+#ifndef QL_G256_NW
+#define QL_G256_NW 8
+#endif
+template <typename T, bool W8, bool GATE, int NW, bool PP>
+static void launch_r4_nw(unsigned grid, hipStream_t st, const T* A, const u32x4* Wt, const T* Sp, int M, int N, int steps, int wsteps, int64_t lda,
+                         int nbx, int sy, const T* bias, T* C, int64_t ldc, const T* resid, int64_t ldr) {
+    static bool attr4 = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_r4_kernel<T, W8, GATE, NW, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kR4Lds) == hipSuccess;
+    }();
+    (void)attr4;
+    w4_gemm256_r4_kernel<T, W8, GATE, NW, PP><<<grid, NW * 64, kR4Lds, st>>>(A, Wt, Sp, M, N, steps, wsteps, lda, nbx, sy, bias, C, ldc, resid, ldr);
+}
+template <typename T, bool W8, bool GATE>
+static void launch_r4(unsigned grid, hipStream_t st, const T* A, const u32x4* Wt, const T* Sp, int M, int N, int steps, int wsteps, int64_t lda,
+                      int nbx, int sy, const T* bias, T* C, int64_t ldc, const T* resid, int64_t ldr) {
+#ifndef QL_R4_PP
+#define QL_R4_PP 0
+#endif
+#ifdef QL_DEV_TUNING
+    const int nw = QL_TUNE("QLINEAR_G256_NW", 8), pp = QL_TUNE("QLINEAR_G256_PP", QL_R4_PP);
+    if (nw == 4) return launch_r4_nw<T, W8, GATE, 4, false>(grid, st, A, Wt, Sp, M, N, steps, wsteps, lda, nbx, sy, bias, C, ldc, resid, ldr);
+    if ((pp != 0) != (QL_R4_PP != 0))
+        return launch_r4_nw<T, W8, GATE, 8, QL_R4_PP == 0>(grid, st, A, Wt, Sp, M, N, steps, wsteps, lda, nbx, sy, bias, C, ldc, resid, ldr);
+#endif
+    launch_r4_nw<T, W8, GATE, 8, QL_R4_PP != 0>(grid, st, A, Wt, Sp, M, N, steps, wsteps, lda, nbx, sy, bias, C, ldc, resid, ldr);
+}
+
+#ifndef QL_G256_RING
+#define QL_G256_RING 0
+#endif
+
+#endif  // QL_DEV_TUNING
+
 template <typename T, bool GATE = false>
 static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
                           hipStream_t st, const void* resid = nullptr, int64_t ldr = 0) {
@@ -415,6 +848,14 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);      // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+#ifdef QL_DEV_TUNING
+    if (QL_TUNE("QLINEAR_G256_RING", QL_G256_RING)) {
+        launch_r4<T, false, GATE>((unsigned)(nbx * nby), st, (const T*)A, Wt, Sp, M, N, K / 32, (int)L.ksteps, lda,
+                                  super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5), super ? sy : 0, (const T*)bias, (T*)C, ldc,
+                                  (const T*)resid, ldr);
+        return finish_launch(QL_K_W4_GEMM256);
+    }
+#endif
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
@@ -433,6 +874,14 @@ static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, con
     const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
     const bool super = !no_super && nbx % 8 == 0 && nby % sy == 0 && nby >= 2 * sy;
+#ifdef QL_DEV_TUNING
+    if (QL_TUNE("QLINEAR_G256_RING", QL_G256_RING)) {
+        launch_r4<T, true, GATE>((unsigned)(nbx * nby), st, (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 32, K / 64, lda,
+                                 super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K), super ? sy : 0, (const T*)bias, (T*)C, ldc,
+                                 (const T*)resid, ldr);
+        return finish_launch(QL_K_W8_GEMM256);
+    }
+#endif
     w4_gemm256_kernel<T, true, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
@@ -519,6 +968,11 @@ int w4_gemm256_gated(int dtype, const void* A, const void* tiled, const void* bi
 
 }  // namespace ql
 
+#if defined(QL_R4_STAMPS) && defined(QL_DEV_TUNING)
+extern "C" int qlinear_r4_stamps_read(unsigned long long* out, int blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_r4_stamps), sizeof(unsigned long long) * 12 * blocks);
+}
+#endif
 #ifdef QL_G256_STAMPS
 extern "C" int qlinear_g256_stamps_read(unsigned long long* out, int blocks) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_g256_stamps), sizeof(unsigned long long) * 8 * blocks);

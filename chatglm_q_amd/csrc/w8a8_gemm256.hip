@@ -30,6 +30,7 @@ __device__ unsigned long long ql_i256_stamps[8192 * 2 * 4];
 constexpr int kI256Tile = 256 * 128;               // one operand tile: 256 rows (columns) x 128 bytes of K
 constexpr int kI256Lds = 4 * kI256Tile;            // A[2] | W[2]
 
+#ifdef QL_DEV_TUNING                                // round 3's kernel: developer library only (QLINEAR_I256_RING=0), the A/B partner of the ring kernel below
 // NW = 8: 2 (M) x 4 (N) waves, wave tile 128 x 64, two waves per SIMD (round 3).
 // NW = 4: 2 x 2 waves, wave tile 128 x 128 = 4 x 4 MFMA tiles (256 accumulator registers), ONE wave per SIMD - the geometry of the
 //         vendor's i8 kernel on this chip (rocprof: MT256x256x128, 256 threads; profiles/r04_vendor_gemm_diff.txt): half the
@@ -221,6 +222,8 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
     }
 }
 
+#endif  // QL_DEV_TUNING
+
 // ---- round 4: the same GEMM as a RING OF FOUR 64-byte K stages on v_mfma_i32_16x16x64_i8, one wave per SIMD ----------------------------
 // What the measurements of the kernel above said (profiles/r04_gemm_power.txt, tools/i256_timeline.py): its loop waits ~10 cycles per K
 // tile for data and ~115 at the barrier, yet takes 2 850 cycles per 2 048 of MFMA issue at ~1.0 - 1.2 GHz - the chip is POWER bound, and
@@ -407,6 +410,7 @@ static int launch_i256_r4(const int8_t* Aq, const float* a_scale, const int8_t* 
     return finish_launch(QL_K_W8A8_GEMM256);
 }
 
+#ifdef QL_DEV_TUNING
 template <typename T, int NW>
 static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                           int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
@@ -425,6 +429,7 @@ static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* 
     return finish_launch(QL_K_W8A8_GEMM256);
 }
 
+#endif
 #ifndef QL_I256_NW
 #define QL_I256_NW 4
 #endif
@@ -434,12 +439,14 @@ static int launch_i256_nw(const int8_t* Aq, const float* a_scale, const int8_t* 
 template <typename T>
 static int launch_i256(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                        int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    if (QL_TUNE("QLINEAR_I256_RING", QL_I256_RING)) return launch_i256_r4<T>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 #ifdef QL_DEV_TUNING
-    if (QL_TUNE("QLINEAR_I256_NW", QL_I256_NW) != QL_I256_NW)
-        return launch_i256_nw<T, 12 - QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    if (!QL_TUNE("QLINEAR_I256_RING", QL_I256_RING)) {
+        if (QL_TUNE("QLINEAR_I256_NW", QL_I256_NW) != QL_I256_NW)
+            return launch_i256_nw<T, 12 - QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+        return launch_i256_nw<T, QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    }
 #endif
-    return launch_i256_nw<T, QL_I256_NW>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    return launch_i256_r4<T>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
 }
 
 // what the kernel needs: 16-bit outputs, whole 128-byte K tiles (two at least), 32-bit byte offsets into Aq
@@ -468,7 +475,7 @@ int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t
 
 }  // namespace ql
 
-#ifdef QL_I256_STAMPS
+#if defined(QL_I256_STAMPS) && defined(QL_DEV_TUNING)
 extern "C" int qlinear_i256_stamps_read(unsigned long long* out, int blocks) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_i256_stamps), sizeof(unsigned long long) * 8 * blocks);
 }
