@@ -128,6 +128,22 @@ def w8_decode(torch, device):
             "GBps": round(per / (ms * 1e-3) / 1e9, 1), "frac_of_8TBps": round(per / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
 
+def _c3_rocprof():
+    """Kernel averages of BASELINE config 3 under rocprofv3 from the newest tracked summary (profiles/rNN_summary.json,
+    w8a8_config3_under_rocprofv3: tools/profile_round.sh + tools/profile_w8a8_c3.py)."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in reversed(sorted(glob.glob(os.path.join(root, "profiles", "r*_summary.json")))):
+        try:
+            d = json.load(open(f))["w8a8_config3_under_rocprofv3"]
+            d["source"] = os.path.relpath(f, root)
+            return d
+        except (KeyError, ValueError, OSError):
+            continue
+    return None
+
+
 def w8a8_config3(torch, device):
     """BASELINE config 3: int8 per-channel weights, int8-quantised activations, 512x4096->4096, through the module path
     (tile-major weights, qlinear_w8a8_linear_tiled); the two kernels also timed apart, and round 1's row-major path."""
@@ -169,8 +185,13 @@ def w8a8_config3(torch, device):
             yard[f"M{Mv}"] = {"us": round(usv, 2), "TOPs": round(2.0 * Mv * N * K / usv / 1e6, 1)}
         except Exception as e:      # not every build ships the op
             yard[f"M{Mv}"] = {"error": repr(e)[:200]}
+    prof = _c3_rocprof()
     return {"workload": "act-quant + i8xi8 MFMA GEMM 512x4096->4096 (fused op time, both kernels), tile-major weights",
             "vendor_i8_gemm_yardstick_torch_int_mm": yard,
+            # the same fraction from the tracked rocprofv3 kernel averages of this workload alone (GEMM + quantiser)
+            "frac_rocprof": (round(ops / ((prof["gemm_avg_ns"] + prof["act_quant_avg_ns"]) * 1e-9) / 1e12 / I8_MFMA_PEAK_TOPS, 4) if prof else None),
+            "gemm_frac_rocprof": (round(ops / (prof["gemm_avg_ns"] * 1e-9) / 1e12 / I8_MFMA_PEAK_TOPS, 4) if prof else None),
+            "rocprof_source": prof.get("source") if prof else None,
             "us": round(us, 2), "TOPs": round(ops / us / 1e6, 1),
             "frac_of_i8_mfma_peak": round(ops / us / 1e6 / I8_MFMA_PEAK_TOPS, 4),
             "act_quant_us": round(us_q, 2), "gemm_us": round(us_g, 2), "gemm_TOPs": round(ops / us_g / 1e6, 1),
@@ -457,5 +478,14 @@ def run(torch, device):
         except Exception as e:      # keep going: extras are informative only
             out[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
+    try:        # BASELINE config 5 as a recomputable fraction: the QLinear flops of the 4 x 2048 prefill over its wall time
+        cp = out["e2e_generate"]["chunked_prefill_seq2048_batch4"]
+        flops = 2.0 * 4 * 2048 * (4096 * 4608 + 4096 * 4096 + 4096 * 27392 + 13696 * 4096) * 28
+        out["prefill_roofline"] = {"workload": "ChatGLM2-6B int4g32 prefill, batch 4 x 2048 positions, one pass of 8192 rows per QLinear call",
+                                   "flops": flops, "seconds": cp["seconds"], "TFLOPs": round(flops / cp["seconds"] / 1e12, 1),
+                                   "frac_of_2.5PF": round(flops / cp["seconds"] / 1e12 / 2500.0, 4),
+                                   "note": "linear-layer flops only (attention, norms, rotary and lm_head run inside the same wall time)"}
+    except (KeyError, TypeError):
+        pass
     out["extras_seconds"] = round(time.perf_counter() - t0, 1)
     return out

@@ -15,6 +15,9 @@ Two independent reference routes are recorded for every matmul case:
 
 bf16 arrays are stored as uint16 bit patterns (numpy has no bf16); key suffix ``_bf16bits``.
 
+Every generator pins ``torch.set_num_threads`` (1 for the small fixtures, a fixed count for the real-dimension ones), so that the
+fp16 outputs of torch's CPU GEMM - whose summation order follows the thread split - regenerate byte for byte.
+
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
 import os
@@ -95,6 +98,7 @@ def triton_int8(a, b_kn, bs):
 
 
 def gen_int4():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     cases = [
         # name, a-shape, K, N, dtype, bias
         ("ref_test_shape", (32, 512), 512, 256, "f32", False),   # tests/test_triton_ops_int4.py:12-13
@@ -160,6 +164,7 @@ def gen_int4():
 
 
 def gen_int8():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     d = {}
     names = []
     # reference test shape: tests/test_triton_ops.py:10-12 (B given as contiguous (K, N), negative scales)
@@ -218,6 +223,7 @@ def gen_int8():
 
 
 def gen_quantizers():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     d = {}
     for dt in ("f32", "f16"):
         tdt = DT[dt]
@@ -238,6 +244,7 @@ def gen_quantizers():
 
 
 def gen_w8a8():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """Exact-integer stage of the W8A8 semantic (SURVEY.md 8a-A7): quantize_int8 on activations
     (fp32 arithmetic) composed with an integer matmul; plus the reference's W8A16 output on the
     same inputs so the quantisation error can be reported."""
@@ -270,6 +277,7 @@ def gen_w8a8():
 
 
 def gen_embedding():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     d = {}
     torch.manual_seed(5000)
     V, D = 128, 64
@@ -288,6 +296,7 @@ def gen_embedding():
 
 
 def gen_model():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """Tiny-config int4g32 ChatGLM2 (hidden 128, FFN 224 = 7 groups, 2 layers, vocab 256): every buffer, the ids, prefill
     logits, one cached decode step, and the sampler's output on fixed logits.  Pins the build's own
     model graph / decode loop (harness for BASELINE configs 4 and 5)."""
@@ -521,6 +530,7 @@ def gen_model_r3():
 
 
 def gen_backward():
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """grad_A of both quantized matmuls through the reference's own autograd functions (CPU route:
     chatglm_q/int4/qlinear.py:53-64, chatglm_q/int8/qlinear.py:41-52)."""
     d = {}

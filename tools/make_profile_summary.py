@@ -53,11 +53,22 @@ summary = {
                      "tools/make_profile_summary.py"],
     },
 }
+# BASELINE config 3 alone (tools/profile_w8a8_c3.py): the GEMM and the quantiser of the 512 x 4096 -> 4096 int8-activation linear
+c3 = os.path.join(src, "c3", "c3_kernel_stats.csv")
+if os.path.exists(c3):
+    rows = [r for r in csv.DictReader(open(c3)) if "ql" in r["Name"]]
+    gemm = max((r for r in rows if "w8a8" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]), default=None)
+    quant = max((r for r in rows if "act_quant" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]), default=None)
+    if gemm and quant:
+        summary["w8a8_config3_under_rocprofv3"] = {
+            "workload": "act-quant + int8 x int8 GEMM 512x4096->4096, 20 weight sets x 15 (tools/profile_w8a8_c3.py)",
+            "gemm_kernel": gemm["Name"][:120], "gemm_calls": int(gemm["Calls"]), "gemm_avg_ns": round(float(gemm["AverageNs"])),
+            "act_quant_calls": int(quant["Calls"]), "act_quant_avg_ns": round(float(quant["AverageNs"]))}
 with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 for a, b in (("bench/bench_kernel_stats.csv", "bench_kernel_stats.csv"), ("decode/decode_kernel_stats.csv", "decode_step_kernel_stats.csv"),
              ("prefill/prefill_kernel_stats.csv", "prefill_kernel_stats.csv"), ("w8a8/w8a8_kernel_stats.csv", "w8a8_kernel_stats.csv"),
-             ("w4a8/w4a8_kernel_stats.csv", "w4a8_kernel_stats.csv")):
+             ("c3/c3_kernel_stats.csv", "w8a8_config3_kernel_stats.csv"), ("gemm/gemm_kernel_stats.csv", "gemm_8192_kernel_stats.csv")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
 for a, b in (("bench_unprofiled.json", "bench_unprofiled.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json")):

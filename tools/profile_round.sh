@@ -15,10 +15,11 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o decode -- python $ROOT/tools/profile_decode.py 64 > $OUT/decode.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prefill -o prefill -- python $ROOT/tools/profile_prefill.py > $OUT/prefill.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w8a8 -o w8a8 -- python $ROOT/tools/w8a8_config3.py > $OUT/w8a8.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/w4a8 -o w4a8 -- python $ROOT/tools/w4a8_sweep.py 8192 > $OUT/w4a8.log 2>&1
-find $OUT/w8a8 $OUT/w4a8 -name "*kernel_trace.csv" -delete
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -o c3 -- python $ROOT/tools/profile_w8a8_c3.py > $OUT/c3.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gemm -o gemm -- python $ROOT/tools/vendor_probe.py all > $OUT/gemm.log 2>&1
+find $OUT/w8a8 $OUT/c3 $OUT/gemm -name "*kernel_trace.csv" -delete
 # condense on the box (the bench kernel trace alone exceeds the 64 MiB return budget), then drop the raw traces
-PROFILE_DST=$ROOT/gpurun_out/profiles_out python $ROOT/tools/make_profile_summary.py ${PROFILE_TAG:-r03} > $OUT/summary.log 2>&1
+PROFILE_DST=$ROOT/gpurun_out/profiles_out python $ROOT/tools/make_profile_summary.py ${PROFILE_TAG:-r04} > $OUT/summary.log 2>&1
 find $OUT/bench $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name "*kernel_trace.csv" -delete
 # keep only what fits the 64 MiB return budget: stats and (for the PMC / bench runs) the counter / kernel trace tables
 find $OUT -name "*_agent_info.csv" -delete
