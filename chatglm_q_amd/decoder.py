@@ -269,6 +269,57 @@ class ChatGLMDecoder:
         self.time_log = time_log
         self.last_stats: dict = {}
 
+    @staticmethod
+    def from_pretrained(path, device=None, torch_dtype=None, tokenizer=None, eos_token: str = "</s>", time_log: bool = False):
+        """A reference-format checkpoint folder (``config.json`` + safetensors shards, chatglm_q/loader.py:69-110) -> a decoder
+        whose ``generate`` / ``generate_ids`` run this build's fused path by default: preallocated cache, 5 launches per layer,
+        one HIP graph per token on a GPU (chatglm_q/decoder.py:49-58 is the reference's constructor of the same name; the hub
+        download it falls back to needs a network and is not offered).  ``device`` defaults to the GPU when there is one.
+        ``tokenizer``: any object with ``encode`` / ``decode``; when omitted and the folder's sentencepiece file can be read, a
+        plain SentencePiece wrapper is used (the reference's chat markers and punctuation fix-ups are text handling, out of scope)."""
+        from pathlib import Path
+        from .loader import load_model
+        path = Path(path)
+        if not path.is_dir():
+            raise FileNotFoundError(f"{path}: not a checkpoint folder (hub ids are not resolved: no network access in this build)")
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        config, model = load_model(path, torch_dtype, device)
+        model.eval()
+        eos_id = None
+        if tokenizer is None:
+            tok_file = path / config.tokenizer_file
+            if tok_file.exists():
+                try:
+                    import sentencepiece
+                    sp = sentencepiece.SentencePieceProcessor(model_file=str(tok_file))
+
+                    class _SP:
+                        def encode(self, text):
+                            return sp.encode(text)
+
+                        def decode(self, ids):
+                            return sp.decode(list(ids))
+                    tokenizer = _SP()
+                    pid = sp.piece_to_id(eos_token)
+                    eos_id = pid if pid != sp.unk_id() else None
+                except Exception:      # unreadable model file / no sentencepiece: token ids only
+                    tokenizer = None
+        elif hasattr(tokenizer, "__getitem__"):
+            try:
+                eos_id = tokenizer[eos_token]               # the reference tokenizer's lookup (chatglm_q/decoder.py:44)
+            except (KeyError, TypeError):
+                eos_id = None
+        return ChatGLMDecoder(config, model, tokenizer, eos_token_id=eos_id, device=device,
+                              max_sequence_length=config.model_config.max_sequence_length, time_log=time_log)
+
+    def save_pretrained(self, path, shard: bool = True):
+        """chatglm_q/decoder.py:60-61: the folder ``from_pretrained`` (here or in the reference) reads back."""
+        from .loader import ChatGLMLoadConfig, save_model
+        if not isinstance(self.config, ChatGLMLoadConfig):
+            raise TypeError("save_pretrained needs the ChatGLMLoadConfig the decoder was built with")
+        save_model(path, self.config, self.model, shard=shard)
+
     def _session_for(self, capacity: int, use_graph: Optional[bool]) -> DecodeSession:
         """One DecodeSession (cache + captured HIP graph) is kept and reused while the requested capacity fits and the
         model's parameters have not moved; a generation then costs no allocation and no re-capture."""

@@ -38,3 +38,24 @@ def test_save_load_roundtrip(tmp_path):
     ids = torch.randint(0, 256, (1, 6))
     with torch.no_grad():
         assert torch.equal(model(input_ids=ids)[1], model2(input_ids=ids)[1])
+
+
+def test_decoder_from_pretrained_folder_roundtrip(tmp_path):
+    """ChatGLMDecoder.from_pretrained / save_pretrained (chatglm_q/decoder.py:49-61) on a checkpoint folder: same greedy ids as the
+    model the folder was written from; a missing folder is an error (hub ids are not resolved)."""
+    import pytest
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    lc = L.ChatGLMLoadConfig(model_config=tiny_cfg(), quant_type="int4g32", torch_dtype="float32")
+    model = M.fill_synthetic_(L.build_model(lc), seed=5)
+    L.save_model(tmp_path / "m", lc, model, shard=True, max_shard_bytes=40000)
+    dec = ChatGLMDecoder.from_pretrained(tmp_path / "m", device="cpu")
+    assert dec.tokenizer is None and dec.max_sequence_length == 64
+    ref = ChatGLMDecoder(lc, model.eval())
+    a = list(dec.generate_ids([3, 7, 11], max_generated_tokens=5, greedy=True, ignore_eos=True))
+    b = list(ref.generate_ids([3, 7, 11], max_generated_tokens=5, greedy=True, ignore_eos=True))
+    assert a == b and len(a) == 5
+    dec.save_pretrained(tmp_path / "again")
+    again = L.ChatGLMLoadConfig.from_json((tmp_path / "again" / "config.json").read_text())
+    assert again.model_config == lc.model_config and again.quant_type == "int4g32" and again.weight_files
+    with pytest.raises(FileNotFoundError):
+        ChatGLMDecoder.from_pretrained(tmp_path / "nope")
