@@ -224,7 +224,17 @@ def prefill_gemm(torch, device):
 
         ms = _graph_time(torch, device, fn) / len(layers)
         flops = 2.0 * M * N * K
+        # yardstick, never the target: the vendor library's DENSE f16 GEMM (hipBLASLt through torch) on the same box, same protocol -
+        # it streams 4 x the weight bytes and dequantises nothing
+        try:
+            wd = [torch.randn(N, K, device=device, dtype=torch.float16) * 0.05 for _ in range(4)]
+            ms_v = _graph_time(torch, device, lambda: [x @ w.t() for w in wd]) / len(wd)
+            vendor = round(flops / (ms_v * 1e-3) / 1e12, 1)
+            del wd
+        except Exception as e:      # pragma: no cover
+            vendor = repr(e)[:120]
         out[name] = {"M": M, "K": K, "N": N, "ms": round(ms, 4), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
+                     "vendor_dense_f16_gemm_yardstick_TFLOPs": vendor,
                      "frac_of_2.5PF_f16_mfma": round(flops / (ms * 1e-3) / 1e12 / 2500.0, 4),
                      "frac_of_mfma_only_loop_on_random_data_1.7PF": round(flops / (ms * 1e-3) / 1e12 / F16_MFMA_RANDOM_DATA_TFLOPS, 4)}
         del layers, x
@@ -252,6 +262,18 @@ def int8_prefill_gemm(torch, device):
                      "int8_activations_frac_of_mfma_only_loop_on_random_data_3.27POPs": round(ops / us_a / 1e6 / I8_MFMA_RANDOM_DATA_TOPS, 4),
                      "int8_activations_us": round(us_a, 1), "int8_activations_TOPs": round(ops / us_a / 1e6, 1),
                      "int8_activations_frac_of_i8_mfma_peak": round(ops / us_a / 1e6 / I8_MFMA_PEAK_TOPS, 4)}
+        # the same GEMM on UNIFORM random int8 rows (quantised Gaussian rows toggle fewer bits: these GEMMs are power bound, the
+        # operand data moves the result by ~3 %) beside the vendor's plain i8 GEMM on exactly those operands
+        try:
+            au = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=device, generator=gen)
+            us_u = _graph_time(torch, device, lambda: [hip_ops.w8a8_gemm_tiled(au, a_s, t, N, sc) for t in tiled]) / len(tiled) * 1e3
+            wv = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=device, generator=gen).t() for _ in range(3)]
+            us_v = _graph_time(torch, device, lambda: [torch._int_mm(au, w) for w in wv]) / len(wv) * 1e3
+            out[name]["uniform_random_operands"] = {"int8_activations_TOPs": round(ops / us_u / 1e6, 1),
+                                                    "vendor_i8_gemm_yardstick_torch_int_mm_TOPs": round(ops / us_v / 1e6, 1)}
+            del wv, au
+        except Exception as e:      # pragma: no cover
+            out[name]["uniform_random_operands"] = {"error": repr(e)[:120]}
         del tiled
         torch.cuda.empty_cache()
     return out
