@@ -237,8 +237,11 @@ __global__ __launch_bounds__(NW * 64) void w8a8_gemm256_kernel(const int8_t* __r
 //     ONE barrier per step, vmcnt(16) in front of it: two stages stay in flight across every barrier;
 //   * A stage image: row r = 64 bytes = 4 chunks, chunk c at position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 at a 64-byte
 //     pitch), swizzle in the SOURCE address of the LDS-DMA; W: the tile-major copy lands as it lies ([column tile][half][lane]) and a
-//     lane (column c, k quarter q) of column tile 16 n reads unit half q & 1, lane 32 (q >> 1) + 16 (n & 1) + c: 256 contiguous bytes
-//     per 16 lanes.  K order inside the dot product: quarter q of the MFMA = chunk q of both operands' 64 bytes.
+//     lane (index i, k quarter q) of an MFMA tile reads unit half q & 1, lane 32 (q >> 1) + its column (mapping at w_rd0 below).
+//     K order inside the dot product: quarter q of the MFMA = chunk q of both operands' 64 bytes;
+//   * the WEIGHT fragment is the MFMA's first operand (D[i][j]: i = output column, j = row), and an MFMA tile's 16 columns are chosen
+//     so that a lane ends up with EIGHT CONSECUTIVE columns of one row per tile pair: the epilogue stores 16-byte row pieces straight
+//     from registers, 64 contiguous bytes per row and instruction - no LDS transposition.
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 constexpr int kR4Stage = 32768;                    // A 16 KB | W 16 KB
 constexpr int kR4Lds = 4 * kR4Stage;
@@ -279,9 +282,16 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
     const unsigned w_dma = lds0 + 16384u + (unsigned)(4 * wave) * 1024u;         // + stage * kR4Stage + u * 1024
     // fragment read addresses: stages 0 / 1 through the 16-bit immediate of one base, stages 2 / 3 of a second one
     const int a_rd0 = (128 * wr + c16) * 64 + ((kq ^ ((c16 >> 2) & 3)) * 16);    // + mt * 1024
-    const int w_rd0 = 16384 + (4 * wc) * 2048 + (kq & 1) * 1024 + (32 * (kq >> 1) + c16) * 16;   // + (nt >> 1) * 2048 + (nt & 1) * 256
+    // MFMA tile nt of the wave (column tile ct = 4 wc + (nt >> 1) of the block, b = nt & 1) does NOT cover 16 consecutive columns: its
+    // index i = 4 q + e is column 8 q + 4 (b ^ (q >> 1)) + e of the 32, so that the lane holding D rows 4 q .. 4 q + 3 of tiles 2 p and
+    // 2 p + 1 holds the EIGHT CONSECUTIVE columns 8 q .. 8 q + 7 of its row (one 16-byte store; which tile holds the lower four flips
+    // with q >> 1) - and the 16 lanes of a fragment read still cover 256 distinct bytes modulo the bank row (conflict-free:
+    // 8 (q & 1) + 4 (b ^ (q >> 1)) + e takes all 16 values).
+    const int qd = c16 >> 2, ed = c16 & 3;
+    const int w_rd0 = 16384 + (4 * wc) * 2048 + (kq & 1) * 1024 + (32 * (kq >> 1) + 8 * qd + 4 * (0 ^ (qd >> 1)) + ed) * 16;   // even tiles, + (nt >> 1) * 2048
+    const int w_rd1 = 16384 + (4 * wc) * 2048 + (kq & 1) * 1024 + (32 * (kq >> 1) + 8 * qd + 4 * (1 ^ (qd >> 1)) + ed) * 16;   // odd tiles
     const char* a_rd[2] = {smem + a_rd0, smem + a_rd0 + 2 * kR4Stage};
-    const char* w_rd[2] = {smem + w_rd0, smem + w_rd0 + 2 * kR4Stage};
+    const char* w_rd[2][2] = {{smem + w_rd0, smem + w_rd0 + 2 * kR4Stage}, {smem + w_rd1, smem + w_rd1 + 2 * kR4Stage}};
 
     i32x4v acc[8][8];
 #pragma unroll
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
     i32x4 fa[2][8], fb[2][8];
     auto read_a = [&](int buf, int mt, i32x4& x) { x = *reinterpret_cast<const i32x4*>(a_rd[buf >> 1] + (buf & 1) * kR4Stage + mt * 1024); };
     auto read_b = [&](int buf, int nt, i32x4& x) {
-        x = *reinterpret_cast<const i32x4*>(w_rd[buf >> 1] + (buf & 1) * kR4Stage + (nt >> 1) * 2048 + (nt & 1) * 256);
+        x = *reinterpret_cast<const i32x4*>(w_rd[nt & 1][buf >> 1] + (buf & 1) * kR4Stage + (nt >> 1) * 2048);
     };
 
     // ---- prologue: stages 0 .. 3 requested, stage 0 landed, its fragments read ------------------------------------------------------
@@ -350,21 +360,22 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
     vm_wait_imm<0>();                                  // the queue is empty before LDS is reused
     __syncthreads();                                   // ... and every wave is past its last fragment read
 
-    // ---- epilogue: rank-1 scales, 4 consecutive columns of one row per lane and tile -> one 8-byte store -------------------------------
+    // ---- epilogue: rank-1 scales, 8 consecutive columns of one row per lane and tile pair -> one 16-byte store --------------------------
     const int mw = m0 + 128 * wr, nw = n0 + 128 * wc;
-    const bool wide = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 7) == 0;
+    const bool wide = (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const bool flip = (kq >> 1) != 0;                  // quads 2, 3: the odd tile of a pair holds the lower four columns
     float asc[8];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int m = mw + 16 * mt + c16;
         asc[mt] = a_scale[m < M ? m : M - 1];
     }
-    static_for<8>([&](auto ntc) {
-        constexpr int nt = decltype(ntc)::value;
-        const int nb = nw + 16 * nt + 4 * kq;          // first of the lane's 4 columns
-        float ws[4], bs[4];
+    static_for<4>([&](auto ppc) {
+        constexpr int pp = decltype(ppc)::value;
+        const int nb = nw + 32 * pp + 8 * kq;          // first of the lane's 8 columns
+        float ws[8], bs[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 8; ++r) {
             const int n = nb + r < N ? nb + r : N - 1;
             ws[r] = Act<T>::load(Sc + n);
             bs[r] = bias ? Act<T>::load(bias + n) : 0.f;
@@ -372,20 +383,22 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
         static_for<8>([&](auto mtc) {
             constexpr int mt = decltype(mtc)::value;
             const int m = mw + 16 * mt + c16;
-            float y[4];
+            float y[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = (float)acc[mt][nt][r] * (asc[mt] * ws[r]);
+            for (int r = 0; r < 8; ++r) {
+                const int a0 = acc[mt][2 * pp][r & 3], a1 = acc[mt][2 * pp + 1][r & 3];
+                const int av = ((r < 4) != flip) ? a0 : a1;
+                float p = (float)av * (asc[mt] * ws[r]);
                 asm volatile("" : "+v"(p));            // the fp32 product exists (the reference's Cast, Mul, then the output dtype:
                 y[r] = Act<T>::round(p);               // chatglm_q/int8/qlinear.py:60-62); left fusable hipcc rounds product -> f16 once
                 if (bias) y[r] = y[r] + bs[r];
             }
-            if (m < M) {
+            if (m < M && nb < N) {
                 T* dst = C + (int64_t)m * ldc + nb;
-                if (wide && nb + 4 <= N) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(y[0], y[1]), pack2<T>(y[2], y[3])};
+                if (wide && nb + 8 <= N) *reinterpret_cast<u32x4*>(dst) = pack8<T>(y);
                 else
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 8; ++r)
                         if (nb + r < N) Act<T>::store(dst + r, y[r]);
             }
         });
