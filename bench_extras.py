@@ -488,13 +488,29 @@ def prefill_attention(torch, device):
             "rel_l2_between_routes": float((a.float() - b.float()).norm() / b.float().norm())}
 
 
+def int8_model_prefill(torch, device):
+    """The int8 model family at BASELINE config 5's workload (4 x 2048 positions, one pass): weight-only (the reference's int8 forward)
+    beside int8 activations (module.act_quant: chatglm_q/int8/qlinear.py:56-62 - the north_star's 'MFMA where activations are
+    pre-quantized to int8': quantising producers + the int8 x int8 ring GEMM)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import int8_prefill
+    r = int8_prefill.run(torch, device)
+    flops = 2.0 * 4 * 2048 * (4096 * 4608 + 4096 * 4096 + 4096 * 27392 + 13696 * 4096) * 28
+    for k in ("weight_only", "int8_activations"):
+        r[k]["linear_Tops_per_s_if_all_time_were_linear"] = round(flops / r[k]["seconds"] / 1e12, 1)
+    r["workload"] = "ChatGLM2-6B int8 per-channel weights, prefill batch 4 x 2048 (8192 rows per QLinear call), fp16, synthetic weights"
+    return r
+
+
 def run(torch, device):
     out = {}
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
                      ("prefill_gemm_M8192", prefill_gemm), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
-                     ("prefill_attention_b4_s2048", prefill_attention), ("e2e_generate", e2e_generate), ("e2e_cpu", e2e_cpu)]:
+                     ("prefill_attention_b4_s2048", prefill_attention), ("e2e_generate", e2e_generate), ("int8_model_prefill", int8_model_prefill),
+                     ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)
         except Exception as e:      # keep going: extras are informative only
