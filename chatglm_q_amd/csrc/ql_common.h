@@ -156,17 +156,18 @@ __device__ __forceinline__ TileXY xcd_tile(unsigned id, unsigned total, int nbx)
     const unsigned nby = total / (unsigned)(-nbx);
     return {(int)(p / nby), (int)(p % nby)};
 }
-// Super-tile order for many-row GEMMs: an XCD's consecutive positions walk 8-column x `sy`-row super tiles, so that the
-// blocks it runs AT THE SAME TIME (32 CUs x 1-2 blocks) share 8 + sy operand panels instead of 32 + 1-2.  Measured reason
-// (profiles/r02_w8a8_l2_pmc.txt): with whole row tiles per XCD the 8192 x 4096 x 4096 int8 GEMM hit its L2s only 50 % of
-// the time and pulled 1.09 GB over the fabric (every XCD re-streamed all of W for each of its row tiles) - the L2s hold
-// 4 MB, so what counts is which tiles are in flight together, not which ones an XCD owns.  Needs nbx % 8 == 0 and
-// nby % sy == 0 (the launchers fall back to xcd_tile otherwise).
+// Grouped order for many-row GEMMs: an XCD's consecutive positions walk GROUPS of `sy` tile rows column by column (sy tiles down, then
+// the next column), so that the blocks it runs AT THE SAME TIME (32 CUs x 1 block) are 32 / sy columns x sy rows and share 32 / sy + sy
+// operand panels instead of 32 + 1.  Measured reason (profiles/r02_w8a8_l2_pmc.txt): with whole row tiles per XCD the 8192 x 4096 x
+// 4096 int8 GEMM hit its L2s only 50 % of the time and pulled 1.09 GB over the fabric - the L2s hold 4 MB, so what counts is which
+// tiles are in flight together, not which ones an XCD owns.  Any nbx / nby (round 4: the last group may be shorter; before, the
+// order needed nbx % 8 == 0 and the widest layer shapes - 107 and 18 column tiles - fell back to whole rows: 33 panels per 32 tiles).
 __device__ __forceinline__ TileXY xcd_tile_super(unsigned id, unsigned total, int nbx, int sy) {
     const unsigned c = id & 7u, i = id >> 3, q = total >> 3, r = total & 7u;
     const unsigned p = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + i;
-    const unsigned per = 8u * (unsigned)sy, s = p / per, w = p % per, spr = (unsigned)nbx >> 3;
-    return {(int)((s % spr) * 8u + (w & 7u)), (int)((s / spr) * (unsigned)sy + (w >> 3))};
+    const unsigned nby = total / (unsigned)nbx, per = (unsigned)sy * (unsigned)nbx, g = p / per, w = p - g * per;
+    const unsigned left = nby - g * (unsigned)sy, rows = left < (unsigned)sy ? left : (unsigned)sy;
+    return {(int)(w / rows), (int)(g * (unsigned)sy + w % rows)};
 }
 // which order moves fewer bytes into the L2s: a_bytes / w_bytes are the whole operands
 inline int xcd_order(int nbx, int nby, double a_bytes, double w_bytes) {
