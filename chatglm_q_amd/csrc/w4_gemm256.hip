@@ -148,19 +148,12 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
     const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;    // + buffer * kG256ABuf + n * 1024
     char* b_lds = smem + 2 * kG256ABuf;
-    // An MFMA tile's index i does NOT stand for column i of its 32: with the weight fragment as the MFMA's FIRST operand the lane of
-    // row r holds D rows (e + 8 g + 4 kb'), e, g = 0..3 - index 8 g + 4 kb' + e is made column 16 kb' + 4 g + e, so that the lane's 16
-    // accumulator registers are SIXTEEN CONSECUTIVE columns of one output row and the epilogue stores two 16-byte pieces straight
-    // from registers (round 4; before: 16 two-byte LDS stores + 2 reads per 32 x 32 tile and wave).  Index x lives at lane slot
-    // P(x) = x ^ (bit 4 of x -> bit 2): the 16 lanes of a fragment write (16 consecutive columns) and of a fragment read (16
-    // consecutive indices) both cover 16 distinct 16-byte slots of the 256-byte bank row.
-    const int j_idx = 8 * ((j >> 2) & 3) + 4 * (j >> 4) + (j & 3);                    // this thread's column j of its tile -> index
-    const int b_wr = ((wave * 4) * 64 + 32 * kb + (j_idx ^ (((j_idx >> 4) & 1) << 2))) * 16;   // + buffer * kG256BBuf + s * 1024
+    const int b_wr = ((wave * 4) * 64 + lane) * 16;                // + buffer * kG256BBuf + s * 1024
     // fragment read offsets (per sub-step s): A rows 128 wr + 32 mt + (lane & 31), chunk 4 kb + s; B column tiles 2 wc + nt
     int a_rd[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
-    const int b_rd = ((2 * wc) * 4 * 64 + 32 * kb + (j ^ (((j >> 4) & 1) << 2))) * 16;   // index j of the tile; + nt * 4096 + s * 1024
+    const int b_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -273,8 +266,8 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fb[s & 1][nt]),
-                                      __builtin_bit_cast(typename MM::frag, fa[s & 1][mt]), acc[mt][nt]);
+                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
+                                      __builtin_bit_cast(typename MM::frag, fb[s & 1][nt]), acc[mt][nt]);
 #if QL_G256_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -339,7 +332,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
             const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ka * 128ull);
             static_for<8>([&](auto qc) {
                 constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
-                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fb[1][nt]), __builtin_bit_cast(typename MM::frag, fa[1][mt]), acc[mt][nt]);
+                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
                 if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
                 else if constexpr (q == 4) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile));
                 else if constexpr (q == 5) issue_w2(kw, nxt);
@@ -373,68 +366,38 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     vm_wait_imm<0>(wq[1], wsc[1]);
     __syncthreads();                                   // ... and every wave is past its last fragment read
 
-    // ---- epilogue: 16 consecutive columns of one row per lane and tile -> two 16-byte stores straight from registers ----------------
-    // lane (row j, kb) of tile (mt, nt): row mw + 32 mt + j, columns nw + 32 nt + 16 kb + i for accumulator register i
+    // ---- epilogue: rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global (ql_common.h) -------------
     const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
-    const bool wide = GATE || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-                               (!resid || ((ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(resid) & 15) == 0)));   // GATE: alignment checked by the ABI
+    if (GATE || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)) {   // GATE: 8-byte chunks, alignment checked by the ABI
+        T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if constexpr (GATE)
+                    store_tile_32x32_gated<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else if (resid)                        // kernel-uniform: the residual stream is added in the row-chunk pass
+                    store_tile_32x32_resid<T>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else
+                    store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+#ifdef QL_G256_STAMPS
+        if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_g256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 1] = QL_G256_T() - t_loop1;
+#endif
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int nb = nw + 32 * nt + 16 * kb;         // first of the lane's 16 columns
-        float bs[16];
+        const int n = nw + 32 * nt + j;
+        if (n >= N) continue;
+        const T* bn = bias ? bias + n : nullptr;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bs[i] = (bias && nb + i < N) ? Act<T>::load(bias + nb + i) : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = mw + 32 * mt + j;
-            float y[16];
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                y[i] = Act<T>::round(acc[mt][nt][i]);
-                if (bias) y[i] = Act<T>::round(y[i] + bs[i]);
+                const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
+                if (m < M) store_out<T>(C + (int64_t)m * ldc + n, acc[mt][nt][i], bn);
             }
-            if (m >= M || nb >= N) continue;
-            if constexpr (GATE) {                      // four (h0, h1, gate0, gate1) quads -> out[nb / 2 + 0..7] = round(round(silu(h)) * gate)
-                float o[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float hv = y[4 * (i >> 1) + (i & 1)], gv = y[4 * (i >> 1) + 2 + (i & 1)];
-                    o[i] = Act<T>::round(hv / (1.0f + __expf(-hv))) * gv;
-                }
-                T* dst = C + (int64_t)m * ldc + (nb >> 1);
-                if (nb + 16 <= N) *reinterpret_cast<u32x4*>(dst) = pack8<T>(o);
-                else
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (nb + 2 * i < N) Act<T>::store(dst + i, o[i]);
-            } else {
-                T* dst = C + (int64_t)m * ldc + nb;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float yh[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) yh[e] = y[8 * h + e];
-                    if (wide && nb + 8 * h + 8 <= N) {
-                        if (resid) {
-                            float r[8];
-                            unpack8<T>(*reinterpret_cast<const u32x4*>(resid + (int64_t)m * ldr + nb + 8 * h), r);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) yh[e] += r[e];
-                        }
-                        *reinterpret_cast<u32x4*>(dst + 8 * h) = pack8<T>(yh);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (nb + 8 * h + e < N)
-                                Act<T>::store(dst + 8 * h + e, resid ? yh[e] + Act<T>::load(resid + (int64_t)m * ldr + nb + 8 * h + e) : yh[e]);
-                    }
-                }
-            }
-        }
     }
-#ifdef QL_G256_STAMPS
-    if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_g256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 1] = QL_G256_T() - t_loop1;
-#endif
 }
 
 // ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
