@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 // MT256x256x64 / MI16x16 / 4 waves - and the int8 x int8 kernel restructured this way went 1.81 -> 2.07 POP/s (w8a8_gemm256.hip).
 //   * 4 waves as 2 x 2, wave tile 128 x 128 = 8 x 8 tiles of 16 x 16, 256 accumulator registers pinned to the AGPRs;
 //   * stage = 32 k = ONE int4 group = one MFMA k-step: A 256 rows x 64 B by LDS-DMA (swizzle in the source address, chunk c of row r at
-//     position c ^ ((r >> 2) & 3)), B 256 columns x 32 k dequantised ONCE per block - each of the 256 threads owns one unit (column,
+//     position c ^ (2 (r >> 3 & 1)): conflict-free for the four non-contiguous 16-lane groups of a ds_read_b128), B 256 columns x 32 k dequantised ONCE per block - each of the 256 threads owns one unit (column,
 //     group) per stage, builds its four 8-half fragments dword by dword BETWEEN the MFMAs and stores them fragment-major
 //     ([16-column tile][lane 16 q + c][16 B]); 4 stages x (16 + 16) KB = 128 KB of LDS;
 //   * step t: barrier (A(t + 1), B(t + 1) visible; everybody's fragments of stage t are in registers), 64 MFMAs on stage t with, in
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm256_r4_kernel(const T* __restr
     for (int n = 0; n < NAL; ++n) {
         const int r = 16 * (NAL * wave + n) + (lane >> 2), cp = lane & 3;
         const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
-        a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 2) & 3)) * 16);
+        a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ (((r >> 3) & 1) << 1)) * 16);
     }
     const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
     const int ctiles = (N + 31) >> 5;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm256_r4_kernel(const T* __restr
     // This thread's column 32 pc + jw -> tile 2 pc + ((jw >> 2) & 1), index 4 (jw >> 3) + (jw & 3).
     const int pcw = 2 * wu + ctl, tb = (jw >> 2) & 1;
     char* b_wr = smem + 16384 + ((2 * pcw + tb) * 64 + ((4 * (jw >> 3) + (jw & 3)) ^ (8 * tb))) * 16 + (NFR == 2 ? hh * 512 : 0);   // + stage * kR4Stage + i * 256
-    const int a_rd0 = (128 * wr + c16) * 64 + ((kq ^ ((c16 >> 2) & 3)) * 16);    // + mt * 1024
+    const int a_rd0 = (128 * wr + c16) * 64 + ((kq ^ (((c16 >> 3) & 1) << 1)) * 16);    // + mt * 1024
     const int b_rd0 = 16384 + (NT * wc) * 1024 + (16 * kq + c16) * 16, b_rd1 = 16384 + (NT * wc) * 1024 + (16 * kq + (c16 ^ 8)) * 16;   // even / odd tiles, + nt * 1024
     const char* a_rd[2] = {smem + a_rd0, smem + a_rd0 + 2 * kR4Stage};
     const char* b_rd[2][2] = {{smem + b_rd0, smem + b_rd0 + 2 * kR4Stage}, {smem + b_rd1, smem + b_rd1 + 2 * kR4Stage}};
