@@ -762,8 +762,21 @@ static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_
 
 int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
                     int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
-    if (w8a8_gemm256_supported(dtype, M, N, K, Aq))    // prefill row counts: 256 x 256 tiles (w8a8_gemm256.hip)
+    if (w8a8_gemm256_supported(dtype, M, N, K, Aq)) {  // prefill row counts: 256 x 256 tiles (w8a8_gemm256.hip)
+        // a last round of blocks filled to 40 % or less (qkv_proj at 8192 rows: 576 blocks = 2.25 rounds) is peeled off: whole
+        // rounds on the 256-tile kernel, the remaining rows as a second launch on the 128-row tiles below (the weight-only GEMM's
+        // rule, w4_gemm.hip: w4_gemm256_rows)
+        const int64_t nbx = (N + 255) / 256, nby = (M + 255) / 256, blocks = nbx * nby, cus = cu_count();
+        const int64_t full = blocks / cus, tail = blocks - full * cus, m_main = (full * cus / nbx) * 256;
+        const size_t esz = dtype == QL_DTYPE_F32 ? 4 : 2;
+        if (!(dispatch_flags() & QL_D_NOPEEL) && full >= 1 && tail > 0 && tail * 10 <= cus * 4 && m_main >= 256 && m_main < M) {
+            const int rc = w8a8_gemm256(dtype, Aq, a_scale, Wm, S, bias, C, m_main, N, K, ldc, st);
+            if (rc != 0) return rc;
+            return w8a8_gemm_tiled(dtype, Aq + m_main * K, a_scale + m_main, Wm, S, bias, (char*)C + (size_t)(m_main * ldc) * esz, M - m_main, N, K,
+                                   ldc, st);
+        }
         return w8a8_gemm256(dtype, Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    }
     switch (dtype) {
     case QL_DTYPE_F32: return launch_w8a8_tiled<float>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
     case QL_DTYPE_F16: return launch_w8a8_tiled<f16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
