@@ -149,7 +149,7 @@ __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C,
 struct TileXY {
     int x, y;
 };
-__device__ __forceinline__ TileXY xcd_tile(unsigned id, unsigned total, int nbx) {
+__host__ __device__ __forceinline__ TileXY xcd_tile(unsigned id, unsigned total, int nbx) {
     const unsigned c = id & 7u, i = id >> 3, q = total >> 3, r = total & 7u;
     const unsigned p = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + i;
     if (nbx > 0) return {(int)(p % (unsigned)nbx), (int)(p / (unsigned)nbx)};
@@ -162,7 +162,7 @@ __device__ __forceinline__ TileXY xcd_tile(unsigned id, unsigned total, int nbx)
 // 4096 int8 GEMM hit its L2s only 50 % of the time and pulled 1.09 GB over the fabric - the L2s hold 4 MB, so what counts is which
 // tiles are in flight together, not which ones an XCD owns.  Any nbx / nby (round 4: the last group may be shorter; before, the
 // order needed nbx % 8 == 0 and the widest layer shapes - 107 and 18 column tiles - fell back to whole rows: 33 panels per 32 tiles).
-__device__ __forceinline__ TileXY xcd_tile_super(unsigned id, unsigned total, int nbx, int sy) {
+__host__ __device__ __forceinline__ TileXY xcd_tile_super(unsigned id, unsigned total, int nbx, int sy) {
     const unsigned c = id & 7u, i = id >> 3, q = total >> 3, r = total & 7u;
     const unsigned p = (c < r ? c * (q + 1) : r * (q + 1) + (c - r) * q) + i;
     const unsigned nby = total / (unsigned)nbx, per = (unsigned)sy * (unsigned)nbx, g = p / per, w = p - g * per;

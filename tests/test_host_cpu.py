@@ -268,3 +268,54 @@ def test_attention_tile_flags_against_brute_force():
                     tile = rows[:, kt * KB:(kt + 1) * KB]
                     want = 0 if (bool((tile <= -1e9).all()) and rows_ok) else 2 if bool((tile == 0).all()) else 1
                     assert int(flags[b, qb, kt]) == want, (b, qb, kt)
+
+
+def test_tile_orders_are_bijective_for_any_grid(tmp_path):
+    """csrc/ql_common.h: xcd_tile / xcd_tile_super map a workgroup id to an output tile; every tile of the grid must be produced exactly
+    once for ANY (column tiles, row tiles) - round 4 opened the grouped order to column counts that are not multiples of 8 (w_in: 107).
+    The two functions are __host__ __device__: compiled for the host by hipcc (no GPU needed) and swept here."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = tmp_path / "tiles.hip"
+    src.write_text('''
+#include "%s/chatglm_q_amd/csrc/ql_common.h"
+#include <cstdio>
+#include <vector>
+int main() {
+    long bad = 0, grids = 0;
+    for (int nbx = 1; nbx <= 130; ++nbx)
+        for (int nby = 1; nby <= 40; ++nby) {
+            const unsigned total = (unsigned)(nbx * nby);
+            for (int mode = 0; mode < 4; ++mode) {                      // row-major, column-major, groups of 4 rows, groups of 2 rows
+                std::vector<char> seen(total, 0);
+                for (unsigned id = 0; id < total; ++id) {
+                    const ql::TileXY t = mode == 0 ? ql::xcd_tile(id, total, nbx) : mode == 1 ? ql::xcd_tile(id, total, -nbx)
+                                                   : ql::xcd_tile_super(id, total, nbx, mode == 2 ? 4 : 2);
+                    if (t.x < 0 || t.x >= nbx || t.y < 0 || t.y >= nby || seen[t.y * nbx + t.x]++) ++bad;
+                }
+                ++grids;
+            }
+        }
+    // what the grouped order is for: the 32 tiles an XCD runs together (consecutive positions of one XCD) span few operand panels
+    const unsigned total = 107 * 32;
+    int worst = 0;
+    for (unsigned first = 0; first + 32 * 8 <= total; first += 32 * 8) {   // ids first + 8 i + c, i < 32: 32 consecutive positions of XCD c
+        bool col[107] = {false}, row[32] = {false};
+        for (unsigned i = 0; i < 32; ++i) { const ql::TileXY t = ql::xcd_tile_super(first + 8 * i, total, 107, 4); col[t.x] = row[t.y] = true; }
+        int panels = 0;
+        for (bool b : col) panels += b;
+        for (bool b : row) panels += b;
+        if (panels > worst) worst = panels;
+    }
+    printf("%%ld %%ld %%d\\n", bad, grids, worst);
+    return 0;
+}
+''' % ROOT)
+    exe = tmp_path / "tiles.bin"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", str(src), "-o", str(exe)], check=True, capture_output=True)
+    bad, grids, worst = (int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert bad == 0 and grids == 130 * 40 * 4
+    assert worst <= 13          # 8 or 9 columns x 4 rows (+ a group boundary): 33 with whole rows
