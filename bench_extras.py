@@ -211,7 +211,8 @@ def prefill_gemm(torch, device):
     gen = torch.Generator(device=device).manual_seed(17)
     M = int(os.environ.get("PREFILL_GEMM_M", 8192))          # tools/prefill_gemm_ab.py sweeps it
     out = {}
-    for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 4096, 27392), ("w_out", 13696, 4096)]:
+    for name, K, N in [("qkv_proj", 4096, 4608), ("o_proj", 4096, 4096), ("w_in", 4096, 27392), ("w_out", 13696, 4096),
+                       ("lm_head", 4096, 65024)]:          # every layer shape (a real prefill runs lm_head on the last position only)
         # four weight sets per captured graph: a fresh set of weights per launch (as in a model), and the ~10 us a graph replay costs on
         # its own (MI355X_MICROARCH.md, graph-replay-floor) is spread over four launches instead of charged to one 250 us kernel
         layers = [_w4_layer(torch, device, K, N, False, gen) for _ in range(4)]
