@@ -149,6 +149,9 @@ DEV_EXPORTS = {
     "qlinear_w4g32_mlp_engine_supported": (c_int, [c_int64, c_int64, c_int64]),
     "qlinear_w4g32_mlp_engine": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                          c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "qlinear_dev_dense256_image_bytes": (c_size_t, [c_int64, c_int64]),
+    "qlinear_dev_dense256_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "qlinear_dev_dense256_fwd": (c_int, [c_void_p] * 5 + [c_int64] * 6 + [c_int, c_int, c_void_p]),
 }
 
 

@@ -112,4 +112,25 @@ int qlinear_w4a8_linear(const void* A, const void* packed_a8, const void* bias, 
     return w4a8_gemm(dtype, Aq, a_scale, packed_a8, bias, C, M, N, K, ldc, (hipStream_t)stream);
 }
 
+/* round 4 experiment: dequantise once per call, then a dense 16-bit GEMM (w4_dense256.hip) */
+size_t qlinear_dev_dense256_image_bytes(int64_t N, int64_t K) { return N > 0 && K > 0 && K % 32 == 0 ? dense256_image_bytes(N, K) : 0; }
+
+int qlinear_dev_dense256_expand(const void* tiled, const void* S, void* image, int64_t N, int64_t K, int dtype, int weight_bits, void* stream) {
+    if (!tiled || !image || (weight_bits == 8 && !S)) return QL_ERR_NULL_POINTER;
+    if (weight_bits != 4 && weight_bits != 8) return QL_ERR_UNSUPPORTED;
+    if (!fits_i32(N) || !fits_i32(K) || K % 32 != 0 || (weight_bits == 8 && K % 64 != 0)) return QL_ERR_BAD_SHAPE;
+    if (!aligned(tiled, 16) || !aligned(image, 16)) return QL_ERR_MISALIGNED;
+    return dense256_expand(dtype, weight_bits == 8, tiled, S, image, N, K, (hipStream_t)stream);
+}
+
+int qlinear_dev_dense256_fwd(const void* A, const void* image, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K,
+                             int64_t lda, int64_t ldc, int64_t ldr, int dtype, int gate, void* stream) {
+    if (!A || !image || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || lda < K || ldc < (gate ? N / 2 : N) || (gate && N % 8 != 0)) return QL_ERR_BAD_SHAPE;
+    if (!dense256_can_run(M, N, K, lda, A)) return QL_ERR_UNSUPPORTED;
+    if (gate && (residual || ldc % 4 != 0 || !aligned(C, 8))) return QL_ERR_MISALIGNED;
+    return dense256(dtype, gate != 0, A, image, bias, residual, C, M, N, K, lda, ldc, ldr, (hipStream_t)stream);
+}
+
 }  // extern "C"

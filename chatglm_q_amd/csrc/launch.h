@@ -177,6 +177,12 @@ int w4_gemm256_gated(int dtype, const void* A, const void* tiled, const void* bi
                      int64_t ldc, hipStream_t st);   // gate-interleaved copy, SiLU * gate epilogue: C (M, N / 2)
 int w8_gemm256(int dtype, const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldc, hipStream_t st);   // int8 per-channel weights (tile-major copy) through the same kernel
+// w4_dense256.hip: dequantise the call's weights once into a 16-bit fragment-major image, then a dense 16-bit ring GEMM on it
+size_t dense256_image_bytes(int64_t N, int64_t K);
+bool dense256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A);
+int dense256_expand(int dtype, bool w8, const void* tiled, const void* S, void* image, int64_t N, int64_t K, hipStream_t st);
+int dense256(int dtype, bool gate, const void* A, const void* image, const void* bias, const void* resid, void* C, int64_t M, int64_t N,
+             int64_t K, int64_t lda, int64_t ldc, int64_t ldr, hipStream_t st);
 // w8a8_gemm256.hip: int8 activations x tile-major int8 weights, many rows, 256 x 256 tiles, both operands by LDS-DMA
 bool w8a8_gemm256_can_run(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq);
 bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq);

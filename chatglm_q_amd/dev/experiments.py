@@ -256,3 +256,38 @@ def w4a8_module_forward(mod, input: Tensor) -> Tensor | None:
         mod._a8, mod._a8_key = pack_w4a8(mod.weight, mod.weight_scale), key
         _lib.bump_layout_epoch()
     return w4a8_forward(input, mod._a8, mod.out_features, mod.bias, per_tensor=mod.act_quant == "per_tensor")
+
+
+# ---- round 4: dequantise once per call + dense 16-bit ring GEMM (csrc/w4_dense256.hip) ------------------------------------------
+def dense256_image(tiled: Tensor, n_out: int, k_in: int, dtype: torch.dtype, scale: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+    """The 16-bit fragment-major image of a weight (``qlinear_dev_dense256_expand``): ``tiled`` = part 2 of the int4 layout, or the
+    tile-major int8 copy with its per-channel ``scale``.  ``out``: a scratch buffer to reuse (any layer's image fits the largest)."""
+    lib = _lib.get_dev_lib()
+    need = int(lib.qlinear_dev_dense256_image_bytes(n_out, k_in))
+    img = out if out is not None and out.numel() >= need else torch.empty(need, dtype=torch.uint8, device=tiled.device)
+    with torch.cuda.device(tiled.device):
+        st = lib.qlinear_dev_dense256_expand(tiled.data_ptr(), _lib.ptr(scale), img.data_ptr(), n_out, k_in, _lib.dtype_code(dtype),
+                                             4 if scale is None else 8, _lib.stream_ptr(tiled.device))
+    _lib.check(st, "qlinear_dev_dense256_expand")
+    return img
+
+
+def dense256_forward(a: Tensor, image: Tensor, n_out: int, bias: Tensor | None = None, residual: Tensor | None = None,
+                     gate: bool = False) -> Tensor:
+    """``a @ dequant(W) (+ bias) (+ residual)`` or, with ``gate``, SiLU * gate of it (gate-interleaved weight copy): the dense ring GEMM
+    on an image built by ``dense256_image``."""
+    lib = _lib.get_dev_lib()
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K)
+    if a2.stride(1) != 1 or a2.stride(0) % 8:
+        a2 = a2.contiguous()
+    M = a2.shape[0]
+    cols = n_out // 2 if gate else n_out
+    c = torch.empty((M, cols), device=a.device, dtype=a.dtype)
+    r2 = residual.reshape(M, n_out) if residual is not None else None
+    with torch.cuda.device(a.device):
+        st = lib.qlinear_dev_dense256_fwd(a2.data_ptr(), image.data_ptr(), _lib.ptr(bias), _lib.ptr(r2), c.data_ptr(), M, n_out, K, a2.stride(0),
+                                          cols, r2.stride(0) if r2 is not None else 0, _lib.dtype_code(a.dtype), 1 if gate else 0,
+                                          _lib.stream_ptr(a.device))
+    _lib.check(st, "qlinear_dev_dense256_fwd")
+    return c.reshape(*a.shape[:-1], cols)

@@ -68,6 +68,15 @@ int qlinear_w4a8_fwd(const int8_t* Aq, const float* a_scale, const void* packed_
 int qlinear_w4a8_linear(const void* A, const void* packed_a8, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes, void* stream);
 
+/* round 4 experiment (w4_dense256.hip): many-row weight-only GEMM as two launches - the call's weights dequantised ONCE into a 16-bit
+ * fragment-major image of qlinear_dev_dense256_image_bytes(N, K) bytes (from part 2 of the int4 layout, weight_bits 4, or the tile-major
+ * int8 copy + its scales S, weight_bits 8; the reference's per-weight rounding), then a dense ring GEMM on that image; gate: SiLU * gate
+ * epilogue on a gate-interleaved copy (C has N / 2 columns), residual nullable. */
+size_t qlinear_dev_dense256_image_bytes(int64_t N, int64_t K);
+int qlinear_dev_dense256_expand(const void* tiled, const void* S, void* image, int64_t N, int64_t K, int dtype, int weight_bits, void* stream);
+int qlinear_dev_dense256_fwd(const void* A, const void* image, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K,
+                             int64_t lda, int64_t ldc, int64_t ldr, int dtype, int gate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
