@@ -104,7 +104,7 @@ struct Tile32 {
     }
     static __device__ __forceinline__ int col(int i, int lane) { return LAYOUT == 0 ? (lane & 31) : 16 * ((i >> 2) & 1) + (lane & 15); }
 };
-template <typename T, int LAYOUT = 0, typename F>
+template <typename T, int LAYOUT = 0, bool NT = false, typename F>
 __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
                                                  const T* __restrict__ bias, int lane, F val) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
@@ -132,7 +132,9 @@ __device__ __forceinline__ void store_tile_32x32(T* lds_wave, T* __restrict__ C,
         const int m = m_base + row, n = n0 + c8;
         if (m >= M || n >= N) continue;
         if (n + 8 <= N) {
-            *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = *reinterpret_cast<const u32x4*>(lds_wave + row * 32 + c8);
+            const u32x4 chunk = *reinterpret_cast<const u32x4*>(lds_wave + row * 32 + c8);
+            if constexpr (NT) __builtin_nontemporal_store(chunk, reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n));   // many-row GEMMs: read by the next launch at the earliest
+            else *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = chunk;
         } else {                                 // ragged last chunk of the matrix: element by element from LDS
             for (int e = 0; e < N - n; ++e) C[(int64_t)m * ldc + n + e] = lds_wave[row * 32 + c8 + e];
         }
@@ -265,7 +267,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {   // rounds each v
 // The same epilogue with the residual stream added (chatglm_q/model.py:243,245: hidden = hidden + sublayer(...)): every 8-column
 // row chunk of the rounded tile meets the same chunk of `resid` (row stride ldr) and leaves as round(y + resid) - the sublayer's
 // output is rounded to T first, as the reference materialises it.  16-byte aligned rows of C and resid (checked by the ABI).
-template <typename T, int LAYOUT = 0, typename F>
+template <typename T, int LAYOUT = 0, bool NT = false, typename F>
 __device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restrict__ C, int64_t ldc, const T* __restrict__ resid,
                                                        int64_t ldr, int m_base, int n0, int M, int N, const T* __restrict__ bias,
                                                        int lane, F val) {
@@ -292,7 +294,8 @@ __device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restric
             unpack8<T>(*reinterpret_cast<const u32x4*>(resid + (int64_t)m * ldr + n), r);
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = y[e] + r[e];
-            *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = pack8<T>(y);
+            if constexpr (NT) __builtin_nontemporal_store(pack8<T>(y), reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n));
+            else *reinterpret_cast<u32x4*>(C + (int64_t)m * ldc + n) = pack8<T>(y);
         } else {                                 // ragged last chunk of the matrix: element by element
             for (int e = 0; e < N - n; ++e)
                 Act<T>::store(C + (int64_t)m * ldc + n + e, (float)lds_wave[row * 32 + c8 + e] + Act<T>::load(resid + (int64_t)m * ldr + n + e));
@@ -305,7 +308,7 @@ __device__ __forceinline__ void store_tile_32x32_resid(T* lds_wave, T* __restric
 // (h[2t], h[2t+1], gate[2t], gate[2t+1]), so an 8-column row chunk of the tile holds two complete quads and becomes 4 outputs -
 // out[2t + i] = round(round(silu(y_i)) * y_{i+2}), y = rounded sum (+ bias as a second rounded operation) - stored as ONE 8-byte
 // chunk of C, which has N / 2 columns.  Requires N % 8 == 0, ldc % 4 == 0 and 8-byte aligned C rows.
-template <typename T, int LAYOUT = 0, typename F>
+template <typename T, int LAYOUT = 0, bool NT = false, typename F>
 __device__ __forceinline__ void store_tile_32x32_gated(T* lds_wave, T* __restrict__ C, int64_t ldc, int m_base, int n0, int M, int N,
                                                        const T* __restrict__ bias, int lane, F val) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
@@ -335,7 +338,9 @@ __device__ __forceinline__ void store_tile_32x32_gated(T* lds_wave, T* __restric
                 const float hv = y[4 * t + i], gv = y[4 * t + 2 + i];
                 o[2 * t + i] = Act<T>::round(hv / (1.0f + __expf(-hv))) * gv;
             }
-        *reinterpret_cast<u32x2*>(C + (int64_t)m * ldc + (n >> 1)) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+        const u32x2 packed = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+        if constexpr (NT) __builtin_nontemporal_store(packed, reinterpret_cast<u32x2*>(C + (int64_t)m * ldc + (n >> 1)));
+        else *reinterpret_cast<u32x2*>(C + (int64_t)m * ldc + (n >> 1)) = packed;
     }
     __builtin_amdgcn_wave_barrier();
 }

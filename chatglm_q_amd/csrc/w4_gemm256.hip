@@ -375,11 +375,11 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 if constexpr (GATE)
-                    store_tile_32x32_gated<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                    store_tile_32x32_gated<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
                 else if (resid)                        // kernel-uniform: the residual stream is added in the row-chunk pass
-                    store_tile_32x32_resid<T>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                    store_tile_32x32_resid<T, 0, true>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
                 else
-                    store_tile_32x32<T>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                    store_tile_32x32<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
 #ifdef QL_G256_STAMPS
         if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 8192) ql_g256_stamps[((size_t)blockIdx.x * 2 + (wave >> 2)) * 4 + 1] = QL_G256_T() - t_loop1;
 #endif

@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
             }
             if (m < M && nb < N) {
                 T* dst = C + (int64_t)m * ldc + nb;
-                if (wide && nb + 8 <= N) *reinterpret_cast<u32x4*>(dst) = pack8<T>(y);
+                if (wide && nb + 8 <= N)                // non-temporal: the output is read by the NEXT launch at the earliest (interleaved A/B, 8192 x 4096 x
+                    __builtin_nontemporal_store(pack8<T>(y), reinterpret_cast<u32x4*>(dst));   // 4096: 128.8 -> 123.6 us, 2.13 -> 2.22 POP/s)
                 else
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
