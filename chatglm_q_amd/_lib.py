@@ -99,6 +99,7 @@ EXPORTS = {
     "qlinear_act_quant_i8_rowwise": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_act_quant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "qlinear_w8a8_fwd_tiled": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
+    "qlinear_w8a8_fwd_tiled_gated": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
     "qlinear_w8a8_fwd_tiled256": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p]),
     "qlinear_w8a8_linear_tiled": (c_int, [c_void_p] * 5 + [c_int64] * 5 + [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_w8a8_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

@@ -484,6 +484,16 @@ int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* t
     return w8a8_gemm_tiled(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
 }
 
+int qlinear_w8a8_fwd_tiled_gated(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                                 int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream) {
+    if (!Aq || !a_scale || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || N % 4 != 0 || ldc < N / 2) return QL_ERR_BAD_SHAPE;
+    if (!aligned(Aq, 16) || !aligned(tiled, 16) || !aligned(C, 8) || ldc % 4 != 0) return QL_ERR_MISALIGNED;
+    if (N % 32 != 0 || !w8a8_gemm256_supported(dtype, M, N, K, Aq)) return QL_ERR_UNSUPPORTED;   /* projection + qlinear_silu_mul(_quant_i8) instead */
+    return w8a8_gemm256_gated(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, (hipStream_t)stream);
+}
+
 int qlinear_w8a8_linear_tiled(const void* A, const void* tiled, const void* S, const void* bias, void* C, int64_t M, int64_t N,
                               int64_t K, int64_t lda, int64_t ldc, int dtype, int flags, void* workspace, size_t workspace_bytes,
                               void* stream) {

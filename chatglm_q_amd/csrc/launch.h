@@ -188,6 +188,8 @@ bool w8a8_gemm256_can_run(int dtype, int64_t M, int64_t N, int64_t K, const void
 bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const void* Aq);
 int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                  int64_t N, int64_t K, int64_t ldc, hipStream_t st);
+int w8a8_gemm256_gated(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                       int64_t N, int64_t K, int64_t ldc, hipStream_t st);   // gate-interleaved copy, SiLU * gate epilogue: C (M, N / 2)
 // w8_gemm.hip (M > 4, fp16 / bf16, MFMA)
 int w8_gemm(int dtype, const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N,
             int64_t K, int64_t ldw, int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);

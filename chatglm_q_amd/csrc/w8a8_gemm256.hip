@@ -248,7 +248,9 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 constexpr int kR4Stage = 32768;                    // A 16 KB | W 16 KB
 constexpr int kR4Lds = 4 * kR4Stage;
 
-template <typename T>
+// GATE: the weight copy is gate-interleaved (a first MLP projection: columns in (h, h, gate, gate) quads) and the epilogue applies
+// SiLU * gate - the lane's 8 consecutive columns are two quads, 4 outputs, one 8-byte store; C has N / 2 columns.
+template <typename T, bool GATE = false>
 __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M, int N, int K,
                                                               int nbx, int super_rows, const float* __restrict__ a_scale,
                                                               const T* __restrict__ Sc, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
@@ -393,9 +395,22 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
                 float p = (float)av * (asc[mt] * ws[r]);
                 asm volatile("" : "+v"(p));            // the fp32 product exists (the reference's Cast, Mul, then the output dtype:
                 y[r] = Act<T>::round(p);               // chatglm_q/int8/qlinear.py:60-62); left fusable hipcc rounds product -> f16 once
-                if (bias) y[r] = y[r] + bs[r];
+                if (bias) y[r] = GATE ? Act<T>::round(y[r] + bs[r]) : y[r] + bs[r];     // (the plain store rounds the sum itself)
             }
-            if (m < M && nb < N) {
+            if constexpr (GATE) {
+                if (m < M && nb < N) {                 // out[nb / 2 + i] = round(round(silu(h_i)) * gate_i)   (chatglm_q/model.py:200-201)
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float hv = y[4 * (i >> 1) + (i & 1)], gv = y[4 * (i >> 1) + 2 + (i & 1)];
+                        o[i] = Act<T>::round(hv / (1.0f + __expf(-hv))) * gv;
+                    }
+                    T* dst = C + (int64_t)m * ldc + (nb >> 1);
+                    const u32x2 packed = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+                    if (nb + 8 <= N) __builtin_nontemporal_store(packed, reinterpret_cast<u32x2*>(dst));
+                    else *reinterpret_cast<u32*>(dst) = packed[0];                             // N % 8 == 4: the last quad alone
+                }
+            } else if (m < M && nb < N) {
                 T* dst = C + (int64_t)m * ldc + nb;
                 if (wide && nb + 8 <= N)                // non-temporal: the output is read by the NEXT launch at the earliest (interleaved A/B, 8192 x 4096 x
                     __builtin_nontemporal_store(pack8<T>(y), reinterpret_cast<u32x4*>(dst));   // 4096: 128.8 -> 123.6 us, 2.13 -> 2.22 POP/s)
@@ -408,11 +423,11 @@ __global__ __launch_bounds__(256) void w8a8_gemm256_r4_kernel(const int8_t* __re
     });
 }
 
-template <typename T>
+template <typename T, bool GATE = false>
 static int launch_i256_r4(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
                           int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
     static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_r4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_r4_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kR4Lds) == hipSuccess;
     }();
     (void)attr_set;
@@ -422,7 +437,7 @@ static int launch_i256_r4(const int8_t* Aq, const float* a_scale, const int8_t* 
     // grouped order (ql_common.h: xcd_tile_super) for column counts that are a multiple of 8 or wide (w_in: 107 column tiles, int8 x int8
     // 1.80 -> 2.05 POP/s, int4g32 +1.5 %); 18 column tiles (qkv_proj) measured better in whole rows (tools/ab/run_sy_sweep.sh: 1.78 vs 1.68 POP/s)
     const bool super = !no_super && nby >= 2 && (nbx % 8 == 0 || nbx >= 32);
-    w8a8_gemm256_r4_kernel<T><<<(unsigned)(nbx * nby), 256, kR4Lds, st>>>(
+    w8a8_gemm256_r4_kernel<T, GATE><<<(unsigned)(nbx * nby), 256, kR4Lds, st>>>(
         Aq, Wm, (int)M, (int)N, (int)K, super ? nbx : xcd_order(nbx, nby, (double)M * K, (double)N * K), super ? sy : 0, a_scale,
         (const T*)S, (const T*)bias, (T*)C, ldc);
     return finish_launch(QL_K_W8A8_GEMM256);
@@ -482,6 +497,16 @@ bool w8a8_gemm256_supported(int dtype, int64_t M, int64_t N, int64_t K, const vo
     if (min_blocks > 0) return blocks >= min_blocks;
     const int64_t cus = cu_count(), rounds = (blocks + cus - 1) / cus;
     return blocks >= cus && blocks * 10 >= rounds * cus * 7;
+}
+
+// gate-interleaved copy of a first MLP projection, SiLU * gate in the epilogue: C is (M, N / 2)
+int w8a8_gemm256_gated(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,
+                       int64_t N, int64_t K, int64_t ldc, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F16: return launch_i256_r4<f16, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    case QL_DTYPE_BF16: return launch_i256_r4<__bf16, true>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
 }
 
 int w8a8_gemm256(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C, int64_t M,

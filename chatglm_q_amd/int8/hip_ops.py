@@ -360,6 +360,23 @@ def w8a8_gemm_tiled(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale
     return c
 
 
+def w8a8_gemm_tiled_gated(a_q: Tensor, a_s: Tensor, gated_tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor | None:
+    """Pre-quantised int8 rows x the GATE-INTERLEAVED tile-major copy of a first MLP projection with SiLU * gate in the GEMM's epilogue
+    (``qlinear_w8a8_fwd_tiled_gated``): (M, K) -> (M, n_out / 2), bit-equal to ``w8a8_gemm_tiled`` + ``silu_mul``.  ``w_scale`` / ``bias``
+    in the copy's column order (``DynamicQuantizeLinear.gated_tiled``).  None when the many-row kernel does not serve the row count."""
+    lib = _lib.get_lib()
+    M, K = a_q.shape
+    c = torch.empty((M, n_out // 2), device=a_q.device, dtype=w_scale.dtype)
+    with torch.cuda.device(a_q.device):
+        st = lib.qlinear_w8a8_fwd_tiled_gated(a_q.data_ptr(), a_s.data_ptr(), gated_tiled.data_ptr(), w_scale.contiguous().data_ptr(),
+                                              _lib.ptr(bias), c.data_ptr(), M, n_out, K, n_out // 2, _lib.dtype_code(w_scale.dtype),
+                                              _lib.stream_ptr(a_q.device))
+    if st == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(st, "qlinear_w8a8_fwd_tiled_gated")
+    return c
+
+
 def w8a8_gemm256(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None,
                  out: Tensor | None = None) -> Tensor:
     """The many-row kernel alone (``qlinear_w8a8_fwd_tiled256``: 256 x 256 tiles, both operands by LDS-DMA) for any row count -

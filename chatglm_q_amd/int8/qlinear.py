@@ -13,6 +13,8 @@ bit-compatible with the weight-only path (quantisation error ~1e-2 relative) and
 from __future__ import annotations
 
 import torch
+from typing import Optional
+
 from torch import Tensor, nn
 from torch.autograd.function import FunctionCtx
 
@@ -124,6 +126,20 @@ class DynamicQuantizeLinear(nn.Module):
         if a_q.dtype != torch.int8 or a_q.dim() != 2 or a_q.shape[1] != self.in_features or self.in_features % 16:
             raise ValueError("forward_quantized takes int8 rows of in_features (a multiple of 16) values")
         return hip_ops.w8a8_gemm_tiled(a_q, a_scale, self.prepare()._tiled, self.out_features, self.weight_scale, self.bias)
+
+    def forward_quantized_gated(self, a_q: Tensor, a_scale: Tensor, hidden: int) -> Optional[Tensor]:
+        """``forward_quantized`` of a first MLP projection (``out_features == 2 * hidden``) followed by SiLU * gate, in ONE launch at
+        prefill row counts (the int8 x int8 ring GEMM's gate epilogue on the gate-interleaved copy): (rows, hidden), bit-equal to the
+        two launches.  None when the library does not serve the shape that way - asked BEFORE the copy is built."""
+        if a_q.dtype != torch.int8 or a_q.dim() != 2 or a_q.shape[1] != self.in_features:
+            raise ValueError("forward_quantized_gated takes int8 rows of in_features values")
+        from .. import _lib
+        if (self.out_features != 2 * hidden or hidden % 2 or self.in_features % 128 or self.in_features < 256 or
+                not _lib.get_lib().qlinear_gated_serves(a_q.shape[0], self.out_features, self.in_features,
+                                                        _lib.dtype_code(self.weight_scale.dtype), 8)):
+            return None
+        tiled, s_perm, b_perm = self.gated_tiled(hidden)
+        return hip_ops.w8a8_gemm_tiled_gated(a_q, a_scale, tiled, self.out_features, s_perm, b_perm)
 
     def forward(self, input: Tensor):
         plan = self._plans.get(input.numel())      # pre-bound launch for this row count (re-validates buffers and input)

@@ -321,7 +321,11 @@ class ChatGLM2Model(nn.Module):
             else:
                 if prequant(layer.ffn.w_in):
                     h, a_q, a_s, _ = F_.rmsnorm_quant(h, layer.ffn_ln.weight, layer.ffn_ln.eps, o)
-                    y, u = None, layer.ffn.w_in.forward_quantized(a_q, a_s).view(B, S, -1)
+                    y = layer.ffn.w_in.forward_quantized_gated(a_q, a_s, layer.ffn.hidden_dim) if GATED_PREFILL and B * S >= 1024 else None
+                    if y is not None:                  # SiLU * gate came out of the int8 x int8 GEMM: (B, S, hidden)
+                        y, u = y.view(B, S, -1), None
+                    else:
+                        u = layer.ffn.w_in.forward_quantized(a_q, a_s).view(B, S, -1)
                 else:
                     if o is None:
                         x = F_.rmsnorm(h, layer.ffn_ln.weight, layer.ffn_ln.eps)

@@ -350,6 +350,11 @@ int qlinear_w8a8_fwd_tiled(const int8_t* Aq, const float* a_scale, const void* t
  * unless fp16 / bf16, K % 128 == 0, K >= 256 and M * K < 2^31. */
 int qlinear_w8a8_fwd_tiled256(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
                               int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
+/* int8 ACTIVATIONS x the gate-interleaved tile-major copy of a first MLP projection (round 4): the many-row ring kernel with SiLU * gate
+ * (chatglm_q/model.py:200-201) in its epilogue, C (M, N / 2) with 8-byte aligned rows; bit-equal to qlinear_w8a8_fwd_tiled followed by
+ * qlinear_silu_mul.  QL_ERR_UNSUPPORTED when the 256 x 256-tile kernel does not serve the row count (qlinear_gated_serves(.., 8)). */
+int qlinear_w8a8_fwd_tiled_gated(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                                 int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
 /* Both steps of the int8-activation linear in ONE call (two launches): quantise A (M, K) row-wise (or per tensor:
  * flags & QL_FLAG_ACT_PER_TENSOR) into the workspace, then the tile-major GEMM.  workspace: qlinear_workspace_bytes(
  * QL_OP_W8A8_LINEAR_TILED, M, N, K, 0) bytes, 16-byte aligned; it holds Aq (M * K bytes) followed by a_scale (M floats)

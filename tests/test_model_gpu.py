@@ -673,3 +673,36 @@ def test_rows_fused_prologue_equals_separate_ops(M, with_delta, dtype):
     small.weight.fill_(0x88)
     small.weight_scale.fill_(0.01)
     assert H4.w4_forward_rows_fused(_lib.PRO_ADDNORM, h5, small.prepare()._packed, 64, None, None, w[:256].contiguous(), 1e-5) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("M", [4096, 2048 + 200])
+def test_int8_activation_gate_epilogue_equals_separate_ops(dtype, bias, M):
+    """int8 ACTIVATIONS at prefill row counts: ``forward_quantized_gated`` (qlinear_w8a8_fwd_tiled_gated: SiLU * gate in the int8 x int8
+    ring GEMM's epilogue on the gate-interleaved copy, output (M, hidden)) against ``forward_quantized`` followed by silu_mul - same
+    integer sums, same rounding sequence, bit for bit (chatglm_q/model.py:199-201 on chatglm_q/int8/qlinear.py:56-62); row counts the
+    many-row kernel does not serve report None before any copy is built."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int8 import hip_ops as H8
+    from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear as Q8
+    g = torch.Generator(device=DEV).manual_seed(23)
+    K, hidden = 4096, 13696
+    layer = Q8(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(-128, 128, layer.weight.shape, dtype=torch.int8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(2 * hidden, device=DEV, generator=g) * 0.001 + 0.0002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(dtype))
+    layer.act_quant = True
+    x = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    a_q, a_s = H8.act_quant_rowwise(x)
+    assert layer.forward_quantized_gated(a_q, a_s, hidden) is not None          # builds the gate-interleaved copy
+    before = _lib.launch_count()
+    got = layer.forward_quantized_gated(a_q, a_s, hidden)
+    assert got is not None and got.shape == (M, hidden) and _lib.launch_count() - before == 1
+    with torch.no_grad():
+        want = F_.silu_mul(layer.forward_quantized(a_q, a_s), hidden)
+    assert torch.equal(got, want)
+    small = Q8(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
+    small.act_quant = True
+    assert small.forward_quantized_gated(a_q[:40], a_s[:40], hidden) is None and small._gated_tiled is None
