@@ -171,3 +171,46 @@ def test_w4a8_vs_oracle(M, K, N, dt):
     ref_t = O.w4a8_matmul(t2n(a), qw.numpy(), t2n(sc), t2n(bias), dtype=dt, per_tensor=True)
     with torch.no_grad():
         assert O.rel_l2(t2n(layer(a.to(DEV))), ref_t) <= {"f16": 3e-4, "bf16": 2e-3}[dt]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,bias", [(512, 4096, 4096, False), (300, 384, 264, True), (1000, 13696, 520, False), (256, 128, 256, True)])
+def test_dense256_two_launch_gemm_matches_the_fused_kernel(M, K, N, bias, dtype):
+    """Round-4 experiment (w4_dense256.hip): the call's int4g32 weights dequantised ONCE into a 16-bit fragment-major image
+    (qlinear_dev_dense256_expand, the reference's per-weight rounding) + the dense ring GEMM on it, against the fused 256-tile kernel:
+    same dequantised weights, another summation order inside the MFMAs (<= 1e-4 relative in fp16); plain, + residual, SiLU * gate;
+    ragged M / N, K with an odd number of 64-deep steps; the int8 weight-only form against its fused twin."""
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear as Q4
+    from chatglm_q_amd.int8 import hip_ops as H8
+    from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear as Q8
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    tol = 1e-4 if dtype == torch.float16 else 2e-3
+    layer = Q4(K, N, bias=bias, dtype=dtype, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(dtype))
+    if bias:
+        layer.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+    x = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    h = torch.randn(M, N, device=DEV, generator=g).to(dtype)
+    tiled = layer.tiled()
+    want = H4.w4_forward_tiled256(x, tiled, N, layer.bias) if hasattr(H4, "w4_forward_tiled256") else layer(x)
+    img = X.dense256_image(tiled, N, K, dtype)
+    got = X.dense256_forward(x, img, N, layer.bias)
+    assert O.rel_l2(t2n(got), t2n(want)) <= tol
+    got_r = X.dense256_forward(x, img, N, layer.bias, residual=h)
+    assert O.rel_l2(t2n(got_r), t2n(h + want)) <= tol
+    if N % 32 == 0:
+        gt, gb = layer.gated_tiled(N // 2)
+        got_g = X.dense256_forward(x, X.dense256_image(gt, N, K, dtype), N, gb, gate=True)
+        assert O.rel_l2(t2n(got_g), t2n(F_.silu_mul(want, N // 2))) <= 4 * tol
+    if K % 64 == 0:
+        l8 = Q8(K, N, bias=bias, dtype=dtype, device=DEV)
+        l8.weight.copy_(torch.randint(-128, 128, l8.weight.shape, dtype=torch.int8, device=DEV, generator=g))
+        l8.weight_scale.copy_((torch.rand(N, device=DEV, generator=g) * 0.001 + 0.0002).to(dtype))
+        if bias:
+            l8.bias.copy_((torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype))
+        t8 = H8.tile_w8(l8.weight)
+        want8 = H8.w8_forward_tiled(x, t8, N, l8.weight_scale, l8.bias)
+        got8 = X.dense256_forward(x, X.dense256_image(t8, N, K, dtype, scale=l8.weight_scale), N, l8.bias)
+        assert O.rel_l2(t2n(got8), t2n(want8)) <= tol
