@@ -400,6 +400,253 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     }
 }
 
+// ---- round 5: the same GEMM as ONE PERSISTENT launch -------------------------------------------------------------------------------
+// Why (profiles/r04_gemm_power.txt, LABNOTES 4c): per 256 x 256 tile the kernel above spends ~3.5 k shader cycles in its prologue (the
+// first operand tiles' round trip with nothing to hide it behind) and ~8.7 k in its epilogue (every CU writes its 128 KB at the same
+// moment: the rounds of a grid run in lockstep, 32 MB per burst) beside ~166 k of K loop at K = 4096 - and the vendor's dense kernel,
+// which runs one workgroup per CU over all of its tiles, does not.  Here:
+//   * grid = one workgroup per CU; workgroup b computes the tiles b, b + grid, b + 2 grid, ... of the SAME XCD-aware tile order (the
+//     id -> XCD relation of a 1-D grid is id mod 8 and grid % 8 == 0, so a workgroup's tiles keep its XCD's panel sharing);
+//   * the K loops of a workgroup's tiles are ONE stream of K tiles: the loads of the last iterations of a tile (two A tiles, three
+//     weight units ahead) already address the NEXT tile - where the kernel above re-requests its last K tile "past the end" to keep
+//     the queue counts fixed - so the next tile's first fragments are in registers when the epilogue starts: no prologue after
+//     the first tile, the queue never drains;
+//   * the epilogue's stores are fire-and-forget: they drain while the next tile's MFMAs run.  vmcnt retires in issue order, so
+//     the two K tiles behind an epilogue wait with the epilogue's store count added to their immediates (k_tile<.., NSW, NSA>: a
+//     wait for a load OLDER than the stores must not wait for them) - the count is the least a wave can issue, kG256PStores on a
+//     full tile (ragged tiles: 0, an over-wait); the barriers are raw s_barrier (a __syncthreads() would drain the compiler-visible
+//     stores with vmcnt(0));
+//   * the epilogue's row-chunk transposition has its own 16 KB of LDS behind the four operand buffers (144 KB in all): the A / B
+//     buffers hold the next tile by then.
+// Requires whole PAIRS of 64-deep K tiles (K % 128 == 0, K >= 1024: the buffer parity of a tile's first K tile is then fixed and
+// the three cursors - weights, activations, compute - change tile in that order without overtaking) and the 16-byte-chunk epilogue.
+constexpr int kG256PEpi = 8 * 2048;
+constexpr int kG256PLds = kG256Lds + kG256PEpi;
+constexpr int kG256PStores = 16;                   // vector-memory instructions one wave's epilogue issues on a FULL tile (8 sub-tiles x 2 row-chunk passes)
+
+__device__ __forceinline__ void lds_barrier() {    // this wave's LDS writes have landed, then the block barrier; no vmcnt
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, bool GATE = false>
+__global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                          int M, int N, int ksteps, int64_t lda, int nbx, int super_rows, int total,
+                                                          const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                          const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+    typedef Mma<T> MM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2] | epilogue scratch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int j = lane & 31, kb = lane >> 5;
+    const unsigned grid = gridDim.x;
+    auto tile_of = [&](unsigned id) {
+        return super_rows ? xcd_tile_super(id, (unsigned)total, nbx, super_rows) : xcd_tile(id, (unsigned)total, nbx);
+    };
+
+    u32 k_mask_lo, k_mask_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
+
+    // ---- the three cursors.  Weights (3 K tiles ahead of the MFMAs), activations (2 ahead), compute. ------------------------------
+    const int ctiles = (N + 31) >> 5;
+    const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
+    unsigned long long w_base, s_base;                 // of the weight cursor's tile: this wave's column tile
+    auto set_w = [&](int tx) {
+        const int ct_raw = tx * 8 + wave;
+        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;      // clamped: loads stay in bounds, stores are masked
+        w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
+        s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
+    };
+    unsigned a_off[4];                                 // of the activation cursor's tile: lane -> (row, stored chunk position)
+    auto set_a = [&](int ty) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
+            const int row = (ty * 256 + r < M) ? (ty * 256 + r) : (M - 1);
+            a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
+        }
+    };
+    TileXY tile = tile_of(blockIdx.x);                 // the compute cursor's tile
+    TileXY tile_nx = tile;                             // the tile the load cursors move / have moved to (valid while more = true)
+    unsigned id_nx = blockIdx.x + grid;
+    bool more = false;                                 // the weight cursor found another tile (latched for the other two)
+    int wk, ak;                                        // next K tile each load cursor requests
+    set_w(tile.x);
+    set_a(tile.y);
+
+    const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
+    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;    // + buffer * kG256ABuf + n * 1024
+    char* b_lds = smem + 2 * kG256ABuf;
+    const int b_wr = ((wave * 4) * 64 + lane) * 16;                // + buffer * kG256BBuf + s * 1024
+    int a_rd[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
+    const int b_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
+
+    f32x16 acc[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+    };
+    zero_acc();
+
+    i32x4 wq[2];
+    unsigned wsc[2];
+    typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
+    auto scale_of = [&](unsigned raw) {
+        const uint16_t h = (uint16_t)raw;
+        T sv;
+        __builtin_memcpy(&sv, &h, 2);
+        return MM::scale_pair(&sv, true);
+    };
+    auto dequant_store = [&](int set, int buf, int s, scale_t sc) {
+        const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+        *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 1024) = f;
+    };
+    u32x4 fa[2][4], fb[2][2];
+    auto read_frags = [&](int buf, int s, u32x4 (&xa)[4], u32x4 (&xb)[2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 4096 + s * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + mt * 4096 + a_rd[s]);
+    };
+    // the cursors' moves (wave-uniform): the weight cursor looks the next tile up, the others follow it one / four iterations later
+    auto advance_w = [&]() {
+        if (++wk < ksteps) return;
+        wk = 0;
+        more = id_nx < (unsigned)total;
+        if (more) {
+            tile_nx = tile_of(id_nx);
+            id_nx += grid;
+            set_w(tile_nx.x);
+        }                                              // no tile left: this tile's first K tiles again (never read; the queue counts stay fixed)
+    };
+    auto advance_a = [&]() {
+        if (++ak < ksteps) return;
+        ak = 0;
+        if (more) set_a(tile_nx.y);
+    };
+
+    // ---- prologue of the FIRST tile: A(0), W(0), W(1) requested; W(0) dequantised into B[0]; then what every barrier is followed by ----
+    {
+        const unsigned long long b0 = sgpr64(a_base);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(n * 1024), a_off[n], b0);
+        gload16(wq[0], w_voff, w_base);
+        gload2(wsc[0], s_voff, s_base);
+        gload16(wq[1], w_voff, sgpr64(w_base + 1024ull));
+        gload2(wsc[1], s_voff, sgpr64(s_base + 64ull * sizeof(T)));
+        vm_wait_imm<2>(wq[0], wsc[0]);
+        const scale_t sc = scale_of(wsc[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dequant_store(0, 0, s, sc);
+        lds_barrier();
+        const unsigned long long b1 = sgpr64(a_base + 128ull);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(kG256ABuf + n * 1024), a_off[n], b1);
+        gload16(wq[0], w_voff, sgpr64(w_base + 2048ull));
+        gload2(wsc[0], s_voff, sgpr64(s_base + 128ull * sizeof(T)));
+        read_frags(0, 0, fa[0], fb[0]);
+        ak = 2;
+        wk = 3;
+    }
+
+    // ---- one K tile (w4_gemm256_kernel's, with the cursors in place of kt): NSW / NSA = the store instructions of an epilogue that
+    // stand between the awaited load and this wait ---------------------------------------------------------------------------------------
+    auto k_tile = [&](auto curc, auto nswc, auto nsac, auto lastc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1, NSW = decltype(nswc)::value, NSA = decltype(nsac)::value;
+        constexpr bool LAST = decltype(lastc)::value != 0;   // a tile's last K tile: the next tile's first fragments are read BEHIND the epilogue (24 registers it needs)
+        vm_wait_imm<6 + NSW>(wq[nxt], wsc[nxt]);      // W(+1) has landed
+        const scale_t sc = scale_of(wsc[nxt]);
+        static_for<3>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
+                                          __builtin_bit_cast(typename MM::frag, fb[s & 1][nt]), acc[mt][nt]);
+            dequant_store(nxt, nxt, s, sc);
+            if constexpr (s == 2) dequant_store(nxt, nxt, 3, sc);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, s == 2 ? 4 : 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, s == 2 ? 2 : 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        vm_wait_imm<2 + NSA>();                        // A(+1) has landed
+        lds_barrier();                                 // B(+1), A(+1) complete; the fragments of the last sub-step are in registers
+        if constexpr (!LAST) read_frags(nxt, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ak * 128ull);
+            const unsigned long long wb = sgpr64(w_base + (unsigned long long)wk * 1024ull);
+            const unsigned long long sb = sgpr64(s_base + (unsigned long long)wk * (64ull * sizeof(T)));
+            static_for<8>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
+                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
+                if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
+                else if constexpr (q == 4) gload16(wq[nxt], w_voff, wb);
+                else if constexpr (q == 5) gload2(wsc[nxt], s_voff, sb);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        advance_a();
+        advance_w();
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, kG256PStores> IS;
+
+    T* lds_wave = reinterpret_cast<T*>(smem + kG256Lds) + wave * 1024;
+    bool behind_stores = false;                        // the epilogue in front of this tile issued its kG256PStores stores for sure
+    for (;;) {
+        int kt = 2;
+        if (behind_stores) {
+            k_tile(I0{}, IS{}, IS{}, I0{});
+            k_tile(I1{}, IS{}, I0{}, I0{});
+            kt = 4;
+        }
+        for (; kt < ksteps; kt += 2) {
+            k_tile(I0{}, I0{}, I0{}, I0{});
+            k_tile(I1{}, I0{}, I0{}, I0{});
+        }
+        k_tile(I0{}, I0{}, I0{}, I0{});
+        k_tile(I1{}, I0{}, I0{}, I1{});
+        // ---- epilogue of `tile` (ql_common.h: rounded 32 x 32 sub-tiles through 2 KB of LDS per wave, 16-byte row chunks, non-temporal)
+        const int m0 = tile.y * 256, n0 = tile.x * 256;
+        const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if constexpr (GATE)
+                    store_tile_32x32_gated<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else if (resid)
+                    store_tile_32x32_resid<T, 0, true>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+                else
+                    store_tile_32x32<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
+        if (!more) break;
+        behind_stores = m0 + 256 <= M && n0 + 256 <= N;
+        tile = tile_nx;
+        zero_acc();
+        read_frags(0, 0, fa[0], fb[0]);
+    }
+    vm_wait_imm<0>(wq[0], wsc[0]);                     // the queue is empty before the registers go out of scope
+    vm_wait_imm<0>(wq[1], wsc[1]);
+}
+
 // ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
 // int8 kernel from 1.81 to 2.07 POP/s (w8a8_gemm256.hip) applied to the weight-only GEMM.  Measured at 8192 rows, qkv / o / w_in / w_out,
 // TFLOP/s (tools/gemm_yardstick.py, profiles/r04_gemm_power.txt): kernel above 987 / 1 145 / 1 147 / 1 185; ring, 8 waves, jobs between the
@@ -858,6 +1105,23 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
         return finish_launch(QL_K_W4_GEMM256);
     }
 #endif
+    // one persistent workgroup per CU over all of its tiles (w4_gemm256p_kernel) whenever a workgroup gets more than one tile and the
+    // shape meets its rules: whole pairs of K tiles, the 16-byte-chunk epilogue
+    const int total = nbx * nby, cus = cu_count();
+    const bool wide = GATE || ((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0)));
+    const int pgrid = QL_TUNE("QLINEAR_G256_PGRID", 0);             // developer build: a smaller persistent grid (tests: many tiles per workgroup at small shapes)
+    const int grid_p = pgrid > 0 ? pgrid : (cus & ~7);
+    if (QL_TUNE("QLINEAR_G256_PERSIST", 1) && total > grid_p && grid_p >= 8 && K % 128 == 0 && K >= 1024 && wide) {
+        static bool attr_p = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256p_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kG256PLds) == hipSuccess;
+        }();
+        (void)attr_p;
+        w4_gemm256p_kernel<T, GATE><<<(unsigned)grid_p, 512, kG256PLds, st>>>(
+            (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
+            super ? sy : 0, total, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
+        return finish_launch(QL_K_W4_GEMM256);
+    }
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);

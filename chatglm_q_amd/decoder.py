@@ -257,6 +257,52 @@ class DecodeSession:
         return self.logits
 
 
+class SentencePieceIds:
+    """Token ids the way the reference's tokenizer produces them (chatglm_q/tokenizer.py:24-64), nothing else: the sentencepiece
+    vocabulary followed by the five special tokens, ``encode`` = "[gMASK]" "<sop>" + pieces, ``decode`` drops every id past the
+    sentencepiece vocabulary, ``tok[name]`` resolves special tokens and pieces.  The chat template and the punctuation fix-ups of
+    the reference's text pipeline are out of scope."""
+    SPECIAL = ("[MASK]", "[gMASK]", "[sMASK]", "<sop>", "<eop>")
+
+    def __init__(self, model_file):
+        import sentencepiece
+        self.model_file = str(model_file)
+        self.sp = sentencepiece.SentencePieceProcessor(model_file=self.model_file)
+        self.n_pieces = len(self.sp)
+
+    def __len__(self):
+        return self.n_pieces + len(self.SPECIAL)
+
+    def __getitem__(self, token: str) -> int:
+        if token in self.SPECIAL:
+            return self.n_pieces + self.SPECIAL.index(token)
+        pid = self.sp.piece_to_id(token)
+        if pid == self.sp.unk_id() and self.sp.id_to_piece(pid) != token:
+            raise KeyError(token)
+        return pid
+
+    def encode(self, text: str, add_special_tokens: bool = True):
+        ids = list(self.sp.encode(text))
+        return [self["[gMASK]"], self["<sop>"]] + ids if add_special_tokens else ids
+
+    def decode(self, ids) -> str:
+        return self.sp.decode([int(i) for i in ids if int(i) < self.n_pieces])
+
+
+def tok_file_of(tokenizer):
+    """The sentencepiece file a tokenizer object was built from, when it says so (this module's wrapper: ``model_file``; the
+    reference's ChatGLM2Tokenizer: ``vocab_file``)."""
+    for attr in ("model_file", "vocab_file"):
+        f = getattr(tokenizer, attr, None)
+        if f is not None:
+            return f
+    return None
+
+
+def _existing(p):
+    return p if p.exists() else None
+
+
 class ChatGLMDecoder:
     def __init__(self, config, model: ChatGLM2Model, tokenizer=None, eos_token_id: Optional[int] = None, device=None,
                  max_sequence_length: Optional[int] = None, time_log: bool = False):
@@ -287,38 +333,45 @@ class ChatGLMDecoder:
         config, model = load_model(path, torch_dtype, device)
         model.eval()
         eos_id = None
+        tokenizer_path = None
         if tokenizer is None:
             tok_file = path / config.tokenizer_file
             if tok_file.exists():
                 try:
-                    import sentencepiece
-                    sp = sentencepiece.SentencePieceProcessor(model_file=str(tok_file))
-
-                    class _SP:
-                        def encode(self, text):
-                            return sp.encode(text)
-
-                        def decode(self, ids):
-                            return sp.decode(list(ids))
-                    tokenizer = _SP()
-                    pid = sp.piece_to_id(eos_token)
-                    eos_id = pid if pid != sp.unk_id() else None
-                except Exception:      # unreadable model file / no sentencepiece: token ids only
-                    tokenizer = None
+                    tokenizer = SentencePieceIds(tok_file)
+                except (ImportError, OSError) as e:      # no sentencepiece module / unreadable model file: token ids only
+                    import warnings
+                    warnings.warn(f"{tok_file}: no tokenizer built ({e}); generate() takes and yields token ids only")
+                else:
+                    tokenizer_path = tok_file
+                    try:
+                        eos_id = tokenizer[eos_token]
+                    except KeyError:
+                        eos_id = None
         elif hasattr(tokenizer, "__getitem__"):
             try:
                 eos_id = tokenizer[eos_token]               # the reference tokenizer's lookup (chatglm_q/decoder.py:44)
             except (KeyError, TypeError):
                 eos_id = None
-        return ChatGLMDecoder(config, model, tokenizer, eos_token_id=eos_id, device=device,
-                              max_sequence_length=config.model_config.max_sequence_length, time_log=time_log)
+        dec = ChatGLMDecoder(config, model, tokenizer, eos_token_id=eos_id, device=device,
+                             max_sequence_length=config.model_config.max_sequence_length, time_log=time_log)
+        dec.tokenizer_file = tokenizer_path if tokenizer_path is not None else (tok_file_of(tokenizer) or _existing(path / config.tokenizer_file))
+        return dec
 
-    def save_pretrained(self, path, shard: bool = True):
-        """chatglm_q/decoder.py:60-61: the folder ``from_pretrained`` (here or in the reference) reads back."""
+    def save_pretrained(self, path, shard: bool = True, tokenizer_file=None):
+        """chatglm_q/decoder.py:60-61: the folder ``from_pretrained`` (here or in the reference) reads back - ``config.json``, the
+        safetensors shards and the sentencepiece file (``tokenizer_file``, default: the one ``from_pretrained`` loaded from; the
+        reference's loader opens it unconditionally, chatglm_q/loader.py:85-88).  Without one the folder holds the model only and
+        a warning says so."""
         from .loader import ChatGLMLoadConfig, save_model
         if not isinstance(self.config, ChatGLMLoadConfig):
             raise TypeError("save_pretrained needs the ChatGLMLoadConfig the decoder was built with")
-        save_model(path, self.config, self.model, shard=shard)
+        tok = tokenizer_file if tokenizer_file is not None else getattr(self, "tokenizer_file", None)
+        if tok is None:
+            import warnings
+            warnings.warn("save_pretrained: no tokenizer file known (pass tokenizer_file=): the folder will hold the model only and the "
+                          "reference's load_model_and_tokenizer will not open it")
+        save_model(path, self.config, self.model, shard=shard, tokenizer_file=tok)
 
     def _session_for(self, capacity: int, use_graph: Optional[bool]) -> DecodeSession:
         """One DecodeSession (cache + captured HIP graph) is kept and reused while the requested capacity fits and the

@@ -245,6 +245,18 @@ def disable_mlp_experiments():
     _set_hook(None)
 
 
+def enable_w4a8():
+    """Install the W4A8 route as the forward of int4 modules whose ``act_quant`` is set (the product raises without it)."""
+    from ..int4 import qlinear as _q4
+    _lib.get_dev_lib()
+    _q4.ACT_QUANT_FORWARD = w4a8_module_forward
+
+
+def disable_w4a8():
+    from ..int4 import qlinear as _q4
+    _q4.ACT_QUANT_FORWARD = None
+
+
 def w4a8_module_forward(mod, input: Tensor) -> Tensor | None:
     """``DynamicQuantizeLinear.forward`` of an int4 module whose ``act_quant`` is set (False | True | "per_tensor"): activation
     quantiser + W4A8 GEMM through the developer library.  None when the shape is not served (the caller continues on the

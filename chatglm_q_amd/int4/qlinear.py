@@ -28,6 +28,10 @@ DEFAULT_GROUP_SIZE = 32  # chatglm_q/int4/qlinear.py:5
 # "hip" when the C-ABI library is loadable, "none" otherwise (the reference's values are
 # "triton" / "none", chatglm_q/int4/qlinear.py:13,17).
 KERNEL_IMPL = "hip" if _lib.available() else "none"
+# forward of an int4 module whose ``act_quant`` is set: None in the product; ``chatglm_q_amd.dev.experiments.enable_w4a8()`` installs
+# the developer library's W4A8 route here (a recorded experiment: the product's forward never imports ``chatglm_q_amd.dev``)
+ACT_QUANT_FORWARD = None
+
 if KERNEL_IMPL == "none":
     print("libqlinear_hip.so not found: GPU tensors will raise; CPU tensors use the dense torch formula.")
 
@@ -267,9 +271,11 @@ class DynamicQuantizeLinear(nn.Module):
                 if self.bias is not None:
                     out = out + self.bias      # not in place: the Function's output may be a view
                 return out
-            if self.act_quant:            # W4A8: a recorded experiment, served by the developer library only (chatglm_q_amd/dev/)
-                from ..dev import experiments
-                out = experiments.w4a8_module_forward(self, input)
+            if self.act_quant:            # W4A8: a recorded experiment of the developer library; the product never imports it
+                if ACT_QUANT_FORWARD is None:
+                    raise RuntimeError("int4 DynamicQuantizeLinear.act_quant (W4A8) is served by the developer library only: call "
+                                       "chatglm_q_amd.dev.experiments.enable_w4a8() first, or leave act_quant = False")
+                out = ACT_QUANT_FORWARD(self, input)
                 if out is not None:
                     return out
             rows = input.numel() // max(input.shape[-1], 1)

@@ -165,6 +165,10 @@ def test_w4a8_vs_oracle(M, K, N, dt):
     layer.apply_weights_(qw, sc, bias)
     layer = layer.to(DEV)
     layer.act_quant = True
+    X.disable_w4a8()
+    with pytest.raises(RuntimeError), torch.no_grad():             # the product alone does not serve (or import) the experiment
+        layer(a.to(DEV))
+    X.enable_w4a8()
     with torch.no_grad():
         assert torch.equal(layer(a.to(DEV)), out)
     layer.act_quant = "per_tensor"
