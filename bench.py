@@ -6,12 +6,15 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON 
   step      one QLinear forward over one batch: int4g32, 1 x 4096 -> 4096, fp16 (BASELINE.json
             configs[1], the configuration the metric is quoted on).  Every step uses a DIFFERENT weight
             set out of a rotation larger than the 256 MB Infinity Cache, so weights really come from HBM.
-  value     whole-job algorithmic GB/s = n_gpus * steps * bytes_per_step / wall time of the timed region
-            (inputs resident in HBM; barrier + synchronize on both sides; max over ranks).
+  value     whole-job algorithmic GB/s = n_gpus * steps * bytes_per_step / time of the timed region, taken from HIP events
+            recorded inside the barrier + synchronize bracket (inputs resident in HBM; max over ranks); the host's
+            perf_counter around the same bracket is reported as ms_per_step_wall_clock.
   roofline  its own leg, independent of --steps: ROOF_LAUNCHES (1440) launches over the same rotation captured in graphs
             of 144, every graph replayed ROOF_REPLAYS times with HIP events on the launch stream -> per-launch time as
             median / p10 / p90 over the replays; achieved = algorithmic bytes / median, against the 8 TB/s HBM3E peak and
-            against the 6.29 TB/s measured copy ceiling (MI355X_MICROARCH.md).  kernel_span: the kernel's OWN duration
+            against the copy rate measured in the same run.  roofline.floor: the same protocol on an EMPTY kernel and on a
+            PURE STREAMING READ of the same bytes (probe kernels of the span library): what one dependent launch of this size
+            costs at the least on this box; frac_of_pure_read = pure read time / kernel time.  kernel_span: the kernel's OWN duration
             (first wave start -> last wave's sums complete, s_memrealtime stamps of the span-probe build), i.e. without
             the dependent-launch boundary every HIP-event / rocprofv3 figure contains.
   cpu_baseline  the module's CPU branch (the reference's fallback formula A @ unpack_int4(B, s),
@@ -286,6 +289,101 @@ def kernel_span_leg(torch, layers, x, n=96):
                     "weights rotated"}
 
 
+def floor_leg(torch, x, stream, bytes_per_launch, n_sets):
+    """What ONE dependent launch of the headline kernel's size costs at the least, measured here under roofline_leg's protocol
+    (graphs of ROOF_GRAPH strictly sequential launches, ROOF_REPLAYS replays between HIP events on the launch stream) with the
+    probe kernels of the span / probe library (csrc/probe_kernels.hip; never part of the product library):
+      empty_us      an empty kernel: the launch boundary alone;
+      pure_read_us  a pure streaming read of the same number of bytes per launch, regions rotated through a buffer as large as the
+                    weight rotation (so they come from HBM): boundary + one HBM round trip + the bytes, no arithmetic, no staging;
+      copy_GBps     the device copy rate of a 16-byte-per-thread kernel over 1 GiB (read + written bytes / time).
+    None when the probe library is not built."""
+    path = os.path.join(ROOT, "chatglm_q_amd", "csrc", "libqlinear_hip_span.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    if not hasattr(lib, "qlinear_probe_read"):
+        return None
+    lib.qlinear_probe_empty.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.qlinear_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.qlinear_probe_read_waves.restype = ctypes.c_int64
+    lib.qlinear_probe_read_waves.argtypes = [ctypes.c_int64]
+    lib.qlinear_probe_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    dev = x.device
+    region = (bytes_per_launch + 255) // 256 * 256
+    buf = torch.empty(region * n_sets, dtype=torch.uint8, device=dev)
+    buf.random_(0, 256)
+    sink = torch.zeros(int(lib.qlinear_probe_read_waves(bytes_per_launch)) + 64, dtype=torch.int32, device=dev)
+    st = stream.cuda_stream
+
+    def timed(launch):
+        n_graphs = ROOF_LAUNCHES // ROOF_GRAPH
+        samples = []
+        with torch.cuda.stream(stream):
+            graphs = []
+            for gi in range(n_graphs):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for i in range(ROOF_GRAPH):
+                        if launch(gi * ROOF_GRAPH + i) != 0:
+                            raise RuntimeError("probe launch failed")
+                graphs.append(g)
+            for g in graphs:
+                g.replay()
+            stream.synchronize()
+            for _ in range(ROOF_REPLAYS):
+                for g in graphs:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    g.replay()
+                    e1.record(stream)
+                    stream.synchronize()
+                    samples.append(e0.elapsed_time(e1) * 1e3 / ROOF_GRAPH)
+        samples.sort()
+        return {"median_us": round(_pct(samples, 0.5), 4), "p10_us": round(_pct(samples, 0.1), 4), "p90_us": round(_pct(samples, 0.9), 4),
+                "launches_timed": len(samples) * ROOF_GRAPH}
+
+    empty = timed(lambda i: lib.qlinear_probe_empty(256, st))
+    read = timed(lambda i: lib.qlinear_probe_read(buf.data_ptr() + (i % n_sets) * region, bytes_per_launch, sink.data_ptr(), st))
+    # device copy ceiling: 1 GiB -> 1 GiB (4 x the 256 MB memory-side cache), best of 5
+    n_copy = 1 << 30
+    src = torch.empty(n_copy, dtype=torch.uint8, device=dev)
+    dst = torch.empty(n_copy, dtype=torch.uint8, device=dev)
+    src.random_(0, 256)
+    best, per_variant = None, {}
+    with torch.cuda.stream(stream):
+        for variant in range(4):
+            vbest = None
+            for r in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                if lib.qlinear_probe_copy(dst.data_ptr(), src.data_ptr(), n_copy, variant, st) != 0:
+                    raise RuntimeError("probe copy failed")
+                e1.record(stream)
+                stream.synchronize()
+                ms = e0.elapsed_time(e1)
+                if r > 0 and (vbest is None or ms < vbest):
+                    vbest = ms
+            per_variant[variant] = round(2.0 * n_copy / (vbest * 1e-3) / 1e9, 1)
+            best = vbest if best is None or vbest < best else best
+        # the runtime's own device-to-device copy (what hipMemcpyAsync picks on this box), same bytes
+        for r in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dst.copy_(src, non_blocking=True)
+            e1.record(stream)
+            stream.synchronize()
+            if r > 0:
+                per_variant["runtime_memcpy"] = max(per_variant.get("runtime_memcpy", 0.0), round(2.0 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1))
+    del src, dst, buf
+    return {"empty_us": empty["median_us"], "pure_read_us": read["median_us"], "copy_GBps": round(2.0 * n_copy / (best * 1e-3) / 1e9, 1),
+            "copy_GBps_per_variant": per_variant,
+            "empty": empty, "pure_read": read, "pure_read_bytes": bytes_per_launch,
+            "protocol": f"graphs of {ROOF_GRAPH} sequential launches x {ROOF_REPLAYS} replays, HIP events on the launch stream; probe kernels of "
+                        "libqlinear_hip_span.so (csrc/probe_kernels.hip); pure read: regions rotated through a buffer of the weight rotation's size; "
+                        "copy: 1 GiB -> 1 GiB, four loop shapes of a 16-byte-per-lane copy kernel (best of 5 each, the best shape is reported) beside the runtime's own memcpy, read + written bytes"}
+
+
 def max_over_ranks(values, dist, device):
     """Replica aggregation used by the N > 1 run: every rank contributes its own timings, the job's time is
     the slowest rank's (all_reduce MAX).  No data-path collective exists - this is the only exchange."""
@@ -409,15 +507,24 @@ def main():
     if graph is None:
         assert _lib.launch_count() - launches_before >= args.steps, "steps did not go through the HIP library"
 
-    ms_per_step = wall_s * 1e3 / args.steps
+    # the timed region's own HIP events (recorded inside the barrier + synchronize bracket, max over ranks) are the clock: the
+    # host's perf_counter around the same bracket adds the two synchronize() round trips to a region that lasts ~6 ms at the
+    # default --steps and drifts with host noise; it is kept beside the event figure
+    ms_per_step = ev_ms / args.steps
+    ms_per_step_wall = wall_s * 1e3 / args.steps
     us_per_launch_ev = ev_ms * 1e3 / args.steps
-    value = whole_job_gbps(world, args.steps, bytes_per_step, wall_s)
+    value = whole_job_gbps(world, args.steps, bytes_per_step, ev_ms * 1e-3)
     # roofline: its own >= 1440-launch measurement on every rank (the slowest rank's median is reported)
     roof = roofline_leg(torch, layers, x, stream)
     roof_med, roof_p10, roof_p90 = max_over_ranks([roof["median_us"], roof["p10_us"], roof["p90_us"]], dist, device)
     achieved = bytes_per_step / (roof_med * 1e-6) / 1e9
     span = kernel_span_leg(torch, layers, x) if rank == 0 else None
     hot = hot_in_cache_leg(torch, layers, x, stream) if rank == 0 else None
+    try:
+        floor = floor_leg(torch, x, stream, bytes_per_step, args.sets) if rank == 0 else None
+    except Exception as e:                              # a probe never invalidates the headline
+        floor = {"error": repr(e)}
+    copy_ceiling = floor.get("copy_GBps") if isinstance(floor, dict) else None
 
     traffic, traffic_src = pmc_traffic()
     prof, prof_src = rocprof_duration()
@@ -429,6 +536,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6),
+        "ms_per_step_wall_clock": round(ms_per_step_wall, 6),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -455,8 +563,14 @@ def main():
             "frac_rocprof": (round(bytes_per_step / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4) if prof else None),
             "rocprof_kernel_avg_ns": prof["avg_ns"] if prof else None,
             "rocprof_source": prof_src,
-            "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBPS, 4),
-            "measured_copy_ceiling": HBM_COPY_CEILING_GBPS,
+            # the floor of ONE dependent launch of this size, measured in this run (floor_leg): empty launch, pure streaming read of the
+            # same bytes, device copy rate
+            "floor": floor,
+            "frac_of_pure_read": (round(floor["pure_read_us"] / roof_med, 4)
+                                  if isinstance(floor, dict) and floor.get("pure_read_us") else None),
+            "frac_of_measured_copy_ceiling": round(achieved / copy_ceiling, 4) if copy_ceiling else None,
+            "measured_copy_ceiling": copy_ceiling,
+            "guide_copy_ceiling": HBM_COPY_CEILING_GBPS,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": bytes_per_step,

@@ -15,7 +15,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # QLINEAR_LIB_PATH: developer override (tools/: ablation builds of the same library); the package default is the in-tree build
 LIB_PATH = os.environ.get("QLINEAR_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip.so")
-DEV_LIB_PATH = os.path.join(_HERE, "csrc", "libqlinear_hip_dev.so")    # product + experiments + tuning knobs as environment variables
+# product + experiments + tuning knobs as environment variables; QLINEAR_DEV_LIB_PATH: another developer build (tools/ab/)
+DEV_LIB_PATH = os.environ.get("QLINEAR_DEV_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip_dev.so")
 ABI_VERSION = 2
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -60,6 +61,7 @@ EXPORTS = {
     "qlinear_last_dispatch": (c_uint64, []),
     "qlinear_dispatch_reset": (None, []),
     "qlinear_dispatch_reload": (None, []),
+    "qlinear_dispatch_flags": (ctypes.c_uint, []),
     "qlinear_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
     "qlinear_w4g32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                   c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
@@ -72,6 +74,7 @@ EXPORTS = {
     "qlinear_w4g32_gemv_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_tiled_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_repack_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "qlinear_w4g32_unpack_gemv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_tile": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_fwd_tiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
                                         c_int64, c_int, c_void_p, c_size_t, c_void_p]),

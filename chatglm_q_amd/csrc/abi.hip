@@ -26,6 +26,7 @@ static unsigned parse_dispatch_env() {
     if (!e) return v;
     if (strstr(e, "no256")) v |= QL_D_NO256;
     if (strstr(e, "nopeel")) v |= QL_D_NOPEEL;
+    if (strstr(e, "nopersist")) v |= QL_D_NOPERSIST;
     if (strstr(e, "nofewrow")) v |= QL_D_NOFEWROW;
     if (strstr(e, "norows4")) v |= QL_D_NOROWS4;
     if (strstr(e, "nogroupattn")) v |= QL_D_NOGROUPATTN;
@@ -177,6 +178,15 @@ int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int6
     return w4_repack_gemv(dtype, Wq, S, gemv, N, K, (hipStream_t)stream);
 }
 
+int qlinear_w4g32_unpack_gemv(const void* gemv, uint8_t* Wq, void* S, int64_t N, int64_t K, int64_t group, int dtype, void* stream) {
+    if (!Wq || !S || !gemv) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(N) || !fits_i32(K) || N <= 0 || K <= 0 || (K & 1)) return QL_ERR_BAD_SHAPE;
+    if (group != 32 || K % 32 != 0) return QL_ERR_BAD_GROUP;
+    if (!aligned(gemv, 16)) return QL_ERR_MISALIGNED;
+    return w4_unpack_gemv(dtype, gemv, Wq, S, N, K, (hipStream_t)stream);
+}
+
 int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int64_t group, int dtype, void* stream) {
     if (!gemv || !tiled) return QL_ERR_NULL_POINTER;
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
@@ -237,9 +247,13 @@ int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int 
     return w4_rows_use_gemm(M, N, K) && !w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0) ? 1 : 0;
 }
 
+unsigned qlinear_dispatch_flags(void) { return dispatch_flags() & 0x7FFFFFFFu; }
+
 int qlinear_gated_serves(int64_t M, int64_t N, int64_t K, int dtype, int weight_bits) {
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return 0;
     if (M <= 0 || N <= 0 || K <= 0 || N % 32 != 0) return 0;
+    // weight_bits 88: int8 ACTIVATIONS x int8 weights (qlinear_w8a8_fwd_tiled_gated) - the ring kernel's own rule (contiguous 16-byte aligned rows assumed)
+    if (weight_bits == 88) return w8a8_gemm256_supported(dtype, M, N, K, nullptr) ? 1 : 0;
     // the 256 x 256-tile GEMM's SiLU * gate epilogue (contiguous 16-byte aligned rows assumed: the entry points re-check the operands)
     if (w4_gemm256_supported(M, N, K, K, nullptr, 2)) return 1;
     if (weight_bits != 4 || K % 32 != 0) return 0;

@@ -64,6 +64,7 @@ int w4_canon(int dtype, const void* A, const uint8_t* Wq, const void* S, const v
              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc, hipStream_t st);
 int w4_repack(int dtype, const uint8_t* Wq, const void* S, void* packed, int64_t N, int64_t K, hipStream_t st);   // both parts, one buffer
 int w4_repack_gemv(int dtype, const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st);     // part 1 only
+int w4_unpack_gemv(int dtype, const void* gemv, uint8_t* Wq, void* S, int64_t N, int64_t K, hipStream_t st);           // part 1 -> canonical buffers
 int w4_tile(int dtype, const void* gemv, void* tiled, int64_t N, int64_t K, hipStream_t st);                          // part 2 from part 1
 int w4_tiled(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
              int64_t lda, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);   // any row count on part 2 (fp16 / bf16)
@@ -165,6 +166,7 @@ inline size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t ksteps) {
 bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 bool w4_gemm256_can_run(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);
 int64_t w4_gemm256_rows(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize);   // w4_gemm.hip: 0 / peel / M
+bool w4_gemm256_tail_in_kernel(int64_t blocks, int64_t K);   // the persistent launch runs its left-over tiles as half tiles: no peel
 int w4_gemm256(int dtype, const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                int64_t ldc, hipStream_t st);
 int w4_gemm256_residual(int dtype, const void* A, const void* tiled, const void* bias, const void* resid, void* C, int64_t M, int64_t N,

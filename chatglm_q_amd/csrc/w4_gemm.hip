@@ -326,6 +326,8 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
 
 
 // Prefill-sized row counts go to the 256 x 256-tile kernel (w4_gemm256.hip), which pays in whole rounds of cu_count() workgroups.
+// Since round 5 its persistent launch runs a last round that fills at most half the chip as half tiles by itself (K % 128 == 0, K >= 1024);
+// what follows is the older rule for the shapes that launch does not take.
 // When the last round would be less than 40 % full (qkv_proj at 8192 rows: 576 workgroups = 2.25 rounds at the price of 3), only
 // the row tiles that fill the whole rounds go to it and the remaining rows to the 128-row-tile kernel as a second launch (same
 // dequantised weights and fp32 sums; the two kernels add in different orders, so a row's last bit may depend on which one served
@@ -333,6 +335,7 @@ static int launch_gemm(const void* A, const void* tiled, const void* bias, void*
 int64_t w4_gemm256_rows(int64_t M, int64_t N, int64_t K, int64_t lda, const void* A, size_t esize) {
     if (!w4_gemm256_supported(M, N, K, lda, A, esize)) return 0;
     const int64_t nbx = (N + 255) / 256, nby = (M + 255) / 256, blocks = nbx * nby;
+    if (w4_gemm256_tail_in_kernel(blocks, K)) return M;     // round 5: the persistent launch splits its own last round (half tiles, bit-equal)
     const int64_t cus = cu_count(), full = blocks / cus, tail = blocks - full * cus;
     const int64_t nby_main = full * cus / nbx, m_main = nby_main * 256;
     if ((dispatch_flags() & QL_D_NOPEEL) || full < 1 || tail == 0 || tail * 10 > cus * 4 || nby_main < 1 || m_main >= M) return M;

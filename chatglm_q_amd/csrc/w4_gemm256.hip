@@ -103,22 +103,28 @@ __device__ __forceinline__ u32x4 w8_dequant_natural(u32 w0, u32 w1, float s) {
 // W8 = false: int4g32, Wt / Sp = part 2 of the derived layout (units + scales, [column tile][K tile][lane]).
 // W8 = true: int8 per channel, Wt = the tile-major copy ([column tile][K tile][half][lane][16 B]: two units per lane and K tile), Sp = S[n].
 // GATE: the weight copy is gate-interleaved (a first MLP projection) and the epilogue applies SiLU * gate: C has N / 2 columns.
-template <typename T, bool W8 = false, bool GATE = false>
-__global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
-                                                         int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
-                                                         const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
-                                                         const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+// MT: 32-row MFMA tiles per wave (round 5).  MT = 4: the 256 x 256 block tile.  MT = 2: a HALF tile, 128 rows x 256 columns (8 waves as
+// 2 x 4, wave tile 64 x 64) - the persistent kernel's tail units (w4_gemm256p_kernel): same K order per output element, so a half
+// tile's outputs are bit-equal to the whole tile's.
+// One output tile, rows m0 .. m0 + 64 MT - 1 x columns 256 tile_x ..: prologue, K loop, epilogue (block-wide; smem: kG256Lds bytes).
+template <typename T, bool W8, bool GATE, int MT>
+__device__ __forceinline__ void g256_tile_body(char* smem, const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                               int M, int N, int ksteps, int64_t lda, int tile_x, int m0,
+                                               const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                               const T* __restrict__ resid, int64_t ldr) {
+    static_assert(MT == 4 || MT == 2, "whole tile or half tile");
     typedef Mma<T> MM;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2]; reused by the epilogue
 #ifdef QL_G256_STAMPS
     const unsigned long long t_block0 = QL_G256_T();
 #endif
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    if constexpr (MT != 4) asm volatile("" : "+v"(tid));   // behind the persistent kernel's K loops: an opaque thread id, so that nothing this body
+                                                            // derives from it is computed early and kept in registers across those loops (hipcc did: spills)
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int j = lane & 31, kb = lane >> 5;
-    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
-    const int m0 = tile.y * 256, n0 = tile.x * 256;
+    const int n0 = tile_x * 256;
 
     u32 k_mask_lo, k_mask_hi, k_magic;
     asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
@@ -128,36 +134,36 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     // ---- this wave's share of the staging work -----------------------------------------------------------------------------------
     // weights: column tile `wave` of the block's 8, one 16-byte unit (+ its scale) per lane and K tile, 1 KB contiguous per wave
     const int ctiles = (N + 31) >> 5;
-    const int ct_raw = tile.x * 8 + wave;
+    const int ct_raw = tile_x * 8 + wave;
     const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;          // clamped: loads stay in bounds, stores are masked
     constexpr unsigned long long kWTile = W8 ? 2048ull : 1024ull;     // bytes of one column tile and K tile
     const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * kWTile);
     const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
     const float sc8 = W8 ? Act<T>::load(Sp + (32 * ct + j < N ? 32 * ct + j : N - 1)) : 0.f;     // the lane's output channel
     const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
-    // activations: pieces 4 wave .. 4 wave + 3 of the tile's 32 (1 KB = 8 rows each); lane -> (row, stored chunk position),
+    // activations: pieces MT wave .. MT wave + MT - 1 of the tile's 8 MT (1 KB = 8 rows each); lane -> (row, stored chunk position),
     // source chunk = position ^ swizzle(row)
-    unsigned a_off[4];
+    unsigned a_off[MT];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
+    for (int n = 0; n < MT; ++n) {
+        const int q = 64 * (MT * wave + n) + lane, r = q >> 3, cp = q & 7;
         const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
         a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
     }
     const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
-    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;    // + buffer * kG256ABuf + n * 1024
+    const unsigned a_dma = lds0 + (unsigned)(MT * wave) * 1024u;   // + buffer * kG256ABuf + n * 1024
     char* b_lds = smem + 2 * kG256ABuf;
     const int b_wr = ((wave * 4) * 64 + lane) * 16;                // + buffer * kG256BBuf + s * 1024
-    // fragment read offsets (per sub-step s): A rows 128 wr + 32 mt + (lane & 31), chunk 4 kb + s; B column tiles 2 wc + nt
+    // fragment read offsets (per sub-step s): A rows 32 MT wr + 32 mt + (lane & 31), chunk 4 kb + s; B column tiles 2 wc + nt
     int a_rd[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
+    for (int s = 0; s < 4; ++s) a_rd[s] = ((32 * MT * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
     const int b_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
 
-    f32x16 acc[4][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -168,14 +174,14 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     auto issue_a = [&](int kt, int buf) {
 #if QL_G256_ABLATE & 8                              // timing ablation: no A pieces in the loop (4 dummy loads keep the queue counts)
         if (kt > 1) {
-            for (int n = 0; n < 4; ++n) asm volatile("s_nop 0" ::: "memory");
+            for (int n = 0; n < MT; ++n) asm volatile("s_nop 0" ::: "memory");
             return;
         }
 #endif
         const int k = kt < ksteps ? kt : ksteps - 1;   // past the end: the last tile again (never read; keeps the queue counts fixed)
         const unsigned long long base = sgpr64(a_base + (unsigned long long)k * 128ull);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(buf * kG256ABuf + n * 1024), a_off[n], base);
+        for (int n = 0; n < MT; ++n) glds16(a_dma + (unsigned)(buf * kG256ABuf + n * 1024), a_off[n], base);
     };
     auto issue_w = [&](int kt, int set) {
         const int k = kt < ksteps ? kt : ksteps - 1;
@@ -215,17 +221,17 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 #endif
         *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 1024) = f;
     };
-    u32x4 fa[2][4], fb[2][2];
-    auto read_frags = [&](int buf, int s, u32x4 (&xa)[4], u32x4 (&xb)[2]) {
+    u32x4 fa[2][MT], fb[2][2];
+    auto read_frags = [&](int buf, int s, u32x4 (&xa)[MT], u32x4 (&xb)[2]) {
 #if QL_G256_ABLATE & 4                              // timing ablation: no fragment reads
         for (int nt = 0; nt < 2; ++nt) xb[nt] = u32x4{(u32)buf, (u32)s, 0x3c003c00u, (u32)nt};
-        for (int mt = 0; mt < 4; ++mt) xa[mt] = u32x4{(u32)a_rd[s], (u32)buf, 0x3c003c00u, (u32)mt};
+        for (int mt = 0; mt < MT; ++mt) xa[mt] = u32x4{(u32)a_rd[s], (u32)buf, 0x3c003c00u, (u32)mt};
         return;
 #endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 4096 + s * 1024);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + mt * 4096 + a_rd[s]);
+        for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + mt * 4096 + a_rd[s]);
     };
 
     // ---- prologue: A(0), W(0), W(1) requested; W(0) dequantised into B[0]; then the block every barrier is followed by ---------
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     // refill of them (A pieces of tile kt + 2, the unit of tile kt + 3) and the first fragment reads of tile kt + 1 go out at
     // once and their latency hides behind the 8 MFMAs of that last sub-step instead of idling the matrix pipe after every barrier
     // (first version, barrier at the end of the tile: 1 005 -> 1 048 TFLOP/s at 8192 x 4096 x 4096 with this skew).
-    // Queue: behind each barrier 4 A pieces, then unit + scale.  W(kt + 1) (requested behind the barrier of iteration kt - 2) has 6
+    // Queue: behind each barrier MT A pieces, then unit + scale.  W(kt + 1) (requested behind the barrier of iteration kt - 2) has MT + 2
     // younger loads when iteration kt dequantises it; A(kt + 1) (behind the barrier of kt - 1) has 2 when iteration kt reaches its barrier.
     auto mma_sub = [&](int s) {
 #if QL_G256_ALT_PRIO
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 #ifdef QL_G256_STAMPS
         const unsigned long long t0 = QL_G256_D();
 #endif
-        vm_wait_imm<6>(wq[nxt], wsc[nxt]);             // W(kt + 1) has landed
+        vm_wait_imm<MT + 2>(wq[nxt], wsc[nxt]);        // W(kt + 1) has landed
 #ifdef QL_G256_STAMPS
         t_w += QL_G256_D() - t0;
 #endif
@@ -298,11 +304,11 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
             mma_sub(s);
             dequant_store(nxt, nxt, s, sc);            // tile kt + 1's fragments 0..2 (3 with sub-step 2), behind these MFMAs
             if constexpr (s == 2) dequant_store(nxt, nxt, 3, sc);
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);             // the 6 fragment reads of the next sub-step first
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);        // the fragment reads of the next sub-step first
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 2 * MT; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // each MFMA with its share of the dequant VALU
-                __builtin_amdgcn_sched_group_barrier(0x002, s == 2 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (s == 2 ? 4 : 2) * (4 / MT), 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x200, s == 2 ? 2 : 1, 0);
 #if QL_G256_PIN
@@ -330,12 +336,12 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         {
             const int ka = kt + 2 < ksteps ? kt + 2 : ksteps - 1, kw = kt + 3 < ksteps ? kt + 3 : ksteps - 1;
             const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ka * 128ull);
-            static_for<8>([&](auto qc) {
+            static_for<2 * MT>([&](auto qc) {
                 constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
                 acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
-                if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
-                else if constexpr (q == 4) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile));
-                else if constexpr (q == 5) issue_w2(kw, nxt);
+                if constexpr (q < MT) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
+                else if constexpr (q == MT) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile));
+                else if constexpr (q == MT + 1) issue_w2(kw, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -367,13 +373,13 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     __syncthreads();                                   // ... and every wave is past its last fragment read
 
     // ---- epilogue: rounded 32 x 32 tiles through 2 KB of LDS per wave, 16-byte row chunks to global (ql_common.h) -------------
-    const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
+    const int mw = m0 + 32 * MT * wr, nw = n0 + 64 * wc;
     if (GATE || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)) {   // GATE: 8-byte chunks, alignment checked by the ABI
         T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 if constexpr (GATE)
                     store_tile_32x32_gated<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
                 else if (resid)                        // kernel-uniform: the residual stream is added in the row-chunk pass
@@ -391,13 +397,23 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
         if (n >= N) continue;
         const T* bn = bias ? bias + n : nullptr;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = mw + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * kb;
                 if (m < M) store_out<T>(C + (int64_t)m * ldc + n, acc[mt][nt][i], bn);
             }
     }
+}
+
+template <typename T, bool W8 = false, bool GATE = false>
+__global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                         int M, int N, int ksteps, int64_t lda, int nbx, int super_rows,
+                                                         const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                         const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2]; reused by the epilogue
+    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    g256_tile_body<T, W8, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
 }
 
 // ---- round 5: the same GEMM as ONE PERSISTENT launch -------------------------------------------------------------------------------
@@ -431,6 +447,7 @@ __device__ __forceinline__ void lds_barrier() {    // this wave's LDS writes hav
 template <typename T, bool GATE = false>
 __global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                           int M, int N, int ksteps, int64_t lda, int nbx, int super_rows, int total,
+                                                          int flat_total, int tail_rem,
                                                           const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
                                                           const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
     typedef Mma<T> MM;
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ 
     auto advance_w = [&]() {
         if (++wk < ksteps) return;
         wk = 0;
-        more = id_nx < (unsigned)total;
+        more = id_nx < (unsigned)flat_total;
         if (more) {
             tile_nx = tile_of(id_nx);
             id_nx += grid;
@@ -645,6 +662,20 @@ __global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ 
     }
     vm_wait_imm<0>(wq[0], wsc[0]);                     // the queue is empty before the registers go out of scope
     vm_wait_imm<0>(wq[1], wsc[1]);
+
+    // ---- the ragged last round as HALF tiles: tail_rem tiles (ids flat_total ..) are left over after the whole rounds and would keep
+    // tail_rem of the grid's workgroups busy for a whole tile time; as 128-row halves they occupy twice as many for half of it (same K
+    // order per output element: bit-equal to the whole tile).  Unit of workgroup b: tile 8 (b / 16) + b % 8 - its id keeps b's XCD in
+    // the tile order - half (b / 8) % 2.  One tile body of its own (prologue, loop, epilogue): once per launch.
+    if (tail_rem > 0) {
+        const unsigned b = blockIdx.x;
+        const int t = (int)(((b >> 4) << 3) | (b & 7u)), half = (int)((b >> 3) & 1u);
+        if (t < tail_rem) {
+            __syncthreads();                           // every wave is past its last use of the operand buffers
+            const TileXY tl = tile_of((unsigned)(flat_total + t));
+            g256_tile_body<T, false, GATE, 2>(smem, A, Wt, Sp, M, N, ksteps, lda, tl.x, tl.y * 256 + 128 * half, bias, C, ldc, resid, ldr);
+        }
+    }
 }
 
 // ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
@@ -1080,6 +1111,9 @@ static void launch_r4(unsigned grid, hipStream_t st, const T* A, const u32x4* Wt
 
 #endif  // QL_DEV_TUNING
 
+// whether `rem` left-over tiles of a persistent grid run as half tiles: every unit 16 (t / 8) + (t % 8) + 8 half must be a workgroup
+static inline bool g256_tail_halves(int rem, int grid) { return rem > 0 && 16 * ((rem + 7) / 8) <= grid; }
+
 template <typename T, bool GATE = false>
 static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
                           hipStream_t st, const void* resid = nullptr, int64_t ldr = 0) {
@@ -1111,7 +1145,11 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     const bool wide = GATE || ((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0)));
     const int pgrid = QL_TUNE("QLINEAR_G256_PGRID", 0);             // developer build: a smaller persistent grid (tests: many tiles per workgroup at small shapes)
     const int grid_p = pgrid > 0 ? pgrid : (cus & ~7);
-    if (QL_TUNE("QLINEAR_G256_PERSIST", 1) && total > grid_p && grid_p >= 8 && K % 128 == 0 && K >= 1024 && wide) {
+    if (QL_TUNE("QLINEAR_G256_PERSIST", 1) && !(dispatch_flags() & QL_D_NOPERSIST) && total > grid_p && grid_p >= 16 && K % 128 == 0 && K >= 1024 && wide) {
+        // the tiles left over after the whole rounds: as half tiles on twice as many workgroups when those exist (g256_tail_halves)
+        const int rem = total % grid_p;
+        const bool halves = QL_TUNE("QLINEAR_G256_TAIL", 1) && g256_tail_halves(rem, grid_p);
+        const int flat_total = halves ? total - rem : total, tail_rem = halves ? rem : 0;
         static bool attr_p = [] {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256p_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kG256PLds) == hipSuccess;
@@ -1119,7 +1157,7 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
         (void)attr_p;
         w4_gemm256p_kernel<T, GATE><<<(unsigned)grid_p, 512, kG256PLds, st>>>(
             (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
-            super ? sy : 0, total, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
+            super ? sy : 0, total, flat_total, tail_rem, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
         return finish_launch(QL_K_W4_GEMM256);
     }
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
@@ -1197,6 +1235,15 @@ bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const vo
     // round is at least ~70 % full (256 blocks +11 %, 428 +13 %, 576 +3.5 %, 856 +3 %), behind below that (288 blocks -9 %, 128 -25 %)
     const int64_t cus = cu_count(), rounds = (blocks + cus - 1) / cus;
     return blocks >= cus && blocks * 10 >= rounds * cus * 7;
+}
+
+// int4g32: whether the persistent launch serves `blocks` tiles with its left-over tiles as in-kernel half tiles (then nothing is peeled off
+// to the 128-row-tile kernel: w4_gemm.hip, w4_gemm256_rows)
+bool w4_gemm256_tail_in_kernel(int64_t blocks, int64_t K) {
+    const int grid = cu_count() & ~7;
+    return QL_TUNE("QLINEAR_G256_PERSIST", 1) && !(dispatch_flags() & QL_D_NOPERSIST) && QL_TUNE("QLINEAR_G256_TAIL", 1) &&
+           QL_TUNE("QLINEAR_G256_PGRID", 0) == 0 && grid >= 16 &&
+           blocks > grid && K % 128 == 0 && K >= 1024 && g256_tail_halves((int)(blocks % grid), grid);
 }
 
 // what the kernel itself needs (the dispatch heuristic above is a speed choice on top of this)

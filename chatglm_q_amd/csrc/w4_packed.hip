@@ -52,6 +52,27 @@ __global__ __launch_bounds__(256) void w4_repack_kernel(const uint8_t* __restric
     Act<T>::store(Sp + ((int64_t)(n >> 2) * G + g) * 4 + (n & 3), sc);
 }
 
+// The inverse (round 5): part 1 -> the canonical buffers, byte for byte (the repack is a bijection on the N real columns: padded
+// columns and their zero scales are dropped).  Lets a host that keeps only derived layouts resident serve state_dict() / checkpoints
+// (chatglm_q/loader.py:90-104's buffer contract) - qlinear_w4g32_unpack_gemv.
+template <typename T>
+__global__ __launch_bounds__(256) void w4_unpack_kernel(const u32x4* __restrict__ Wt, const T* __restrict__ Sp, uint8_t* __restrict__ Wq,
+                                                        T* __restrict__ S, int N, int G) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (n >= N) return;
+    const u32x4 unit = Wt[(int64_t)n * G + g];
+    const u32 words[4] = {unit[0], unit[1], unit[2], unit[3]};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k0 = 2 * r, k1 = 2 * r + 1;
+        const u32 lo = (words[k0 >> 3] >> (4 * packed_pos(k0 & 7))) & 0xFu;
+        const u32 hi = (words[k1 >> 3] >> (4 * packed_pos(k1 & 7))) & 0xFu;
+        Wq[((int64_t)g * 16 + r) * N + n] = (uint8_t)(lo | (hi << 4));
+    }
+    S[(int64_t)g * N + n] = Sp[((int64_t)(n >> 2) * G + g) * 4 + (n & 3)];
+}
+
 // part 2 of the derived layout (launch.h): tile-major copy for the MFMA kernels, built from part 1
 template <typename T>
 __global__ __launch_bounds__(256) void w4_tile_kernel(const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
@@ -723,6 +744,16 @@ static int launch_w4_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, i
     return finish_launch();
 }
 
+template <typename T>
+static int launch_w4_unpack_gemv(const void* gemv, uint8_t* Wq, void* S, int64_t N, int64_t K, hipStream_t st) {
+    const int64_t G = K / 32, Npad = (N + 3) & ~(int64_t)3;
+    const u32x4* Wt = (const u32x4*)gemv;
+    const T* Sp = (const T*)((const char*)gemv + Npad * G * 16);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)G);
+    w4_unpack_kernel<T><<<grid, 256, 0, st>>>(Wt, Sp, Wq, (T*)S, (int)N, (int)G);
+    return finish_launch();
+}
+
 // part 2 (tile-major) from part 1: the two may be one buffer (tiled = gemv + off_wm) or two allocations
 template <typename T>
 static int launch_w4_tile(const void* gemv, void* tiled, int64_t N, int64_t K, hipStream_t st) {
@@ -970,6 +1001,15 @@ int w4_packed_fused(int dtype, int kind, bool gate_epilogue, bool strict, const 
     if (dtype == QL_DTYPE_F16) return strict ? w4_packed_fused_t<f16, true>(kind, p, pro) : w4_packed_fused_t<f16, false>(kind, p, pro);
     if (dtype == QL_DTYPE_BF16) return strict ? w4_packed_fused_t<__bf16, true>(kind, p, pro) : w4_packed_fused_t<__bf16, false>(kind, p, pro);
     return QL_ERR_BAD_DTYPE;
+}
+
+int w4_unpack_gemv(int dtype, const void* gemv, uint8_t* Wq, void* S, int64_t N, int64_t K, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w4_unpack_gemv<float>(gemv, Wq, S, N, K, st);
+    case QL_DTYPE_F16: return launch_w4_unpack_gemv<f16>(gemv, Wq, S, N, K, st);
+    case QL_DTYPE_BF16: return launch_w4_unpack_gemv<__bf16>(gemv, Wq, S, N, K, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
 }
 
 int w4_repack_gemv(int dtype, const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, hipStream_t st) {

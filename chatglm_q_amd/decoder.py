@@ -55,8 +55,12 @@ class DecodeSession:
     """One sequence batch on one device: preallocated cache, eager (chunked) prefill, graph-replayed decode."""
 
     def __init__(self, model: ChatGLM2Model, batch: int, capacity: int, use_graph: Optional[bool] = None,
-                 decode_only: bool = False):
+                 decode_only: bool = False, low_footprint: bool = False):
         self.model = model
+        # low_footprint (round 5): once the derived layouts a phase reads exist, the canonical GPU buffers of every int4 module are
+        # dropped (DynamicQuantizeLinear.drop_canonical: state_dict() / save_pretrained rebuild them byte for byte from part 1) -
+        # ChatGLM2-6B int4g32: ~8.5 GB resident for prefill + decode, ~3.5 GB with decode_only (the reference's "6G+", readme.md:72)
+        self.low_footprint = low_footprint
         # decode_only: before the decode step is captured, free the derived layouts only prefill / batched rows use (part 2 of
         # every int4 layer, the un-gated part 1 of w_in once its gate-interleaved copy exists): ~10.8 -> ~6.6 GB resident for
         # ChatGLM2-6B int4g32.  A later prefill rebuilds what it needs (and the graph is re-captured).
@@ -139,6 +143,8 @@ class DecodeSession:
         self.mask.fill_(-1e10)
         self.mask[:, :, : self.length + 1] = 0.0                # incl. the position the next step writes
         self.mask.masked_fill_(self.pad_cols[:, None, :], -1e10)
+        if self.low_footprint:
+            self.drop_canonical()                               # the layouts this prefill read exist now: the canonical copies can go
         return logits[:, -1]
 
     # -- one decode step -------------------------------------------------------------------------------
@@ -155,6 +161,14 @@ class DecodeSession:
         self.write_index.add_(1)
         self.pos.add_(1)
         self.mask.index_fill_(2, torch.clamp(self.write_index, max=self.capacity - 1), 0.0)
+
+    def drop_canonical(self) -> int:
+        """Low-footprint mode: free the canonical buffers of every int4 module that can serve without them; returns the bytes freed."""
+        freed = 0
+        for m in self.model.modules():
+            if hasattr(m, "drop_canonical"):
+                freed += m.drop_canonical()
+        return freed
 
     def release_prefill_layouts(self) -> int:
         """Free the derived layouts a one-row decode step never reads; returns the bytes released."""
@@ -212,6 +226,8 @@ class DecodeSession:
             # and the step runs once more so that every pre-bound launch exists before the capture
             if self.decode_only and self.release_prefill_layouts():
                 self._step_body(greedy)
+            if self.low_footprint and self.drop_canonical():
+                self._step_body(greedy)                         # the pre-bound launches re-validate against the stand-in buffers
         torch.cuda.current_stream(self.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -123,9 +123,10 @@ def decode_attention(q: Tensor, k_cache: Tensor, v_cache: Tensor, mask: Tensor, 
 
 
 def group_attention() -> bool:
-    """False when QLINEAR_DISPATCH (include/qlinear_hip.h) turns the grouped MFMA decode attention off."""
-    return "nogroupattn" not in os.environ.get("QLINEAR_DISPATCH", "")
-
+    """False when QLINEAR_DISPATCH (include/qlinear_hip.h) turns the grouped MFMA decode attention off - asked of the library, which
+    parses the variable once (``qlinear_dispatch_reload`` parses again): the split / workspace choice made here and the kernel the
+    library launches cannot disagree after an environment change."""
+    return not (_lib.get_lib().qlinear_dispatch_flags() & 16)
 
 
 PREFETCH_NEXT = os.environ.get("QLINEAR_ATTENTION_PREFETCH", "1") != "0"   # spare workgroups warm the next linear's weights

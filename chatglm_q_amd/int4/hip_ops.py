@@ -138,6 +138,21 @@ def repack_w4g32_gemv(b: Tensor, b_scale: Tensor) -> Tensor:
     return _repack("qlinear_w4g32_repack_gemv", gemv_nbytes(N, K, b_scale.dtype, K // b_scale.shape[0]), b, b_scale)
 
 
+def unpack_w4g32_gemv(gemv: Tensor, N: int, K: int, dtype: torch.dtype) -> tuple[Tensor, Tensor]:
+    """The inverse of ``repack_w4g32_gemv``: part 1 of the derived layout -> the canonical ``(weight (K / 2, N) uint8, weight_scale
+    (K / 32, N) dtype)`` buffers, byte for byte (``qlinear_w4g32_unpack_gemv``)."""
+    lib = _lib.get_lib()
+    if gemv.numel() < gemv_nbytes(N, K, dtype):
+        raise AssertionError(f"unpack_w4g32_gemv: buffer of {gemv.numel()} bytes is no part 1 of a ({K}, {N}) weight")
+    w = torch.empty((K // 2, N), dtype=torch.uint8, device=gemv.device)
+    sc = torch.empty((K // 32, N), dtype=dtype, device=gemv.device)
+    with torch.cuda.device(gemv.device):
+        st = lib.qlinear_w4g32_unpack_gemv(gemv.data_ptr(), w.data_ptr(), sc.data_ptr(), N, K, 32, _lib.dtype_code(dtype),
+                                           _lib.stream_ptr(gemv.device))
+    _lib.check(st, "qlinear_w4g32_unpack_gemv")
+    return w, sc
+
+
 def tile_w4g32(gemv: Tensor, N: int, K: int, dtype: torch.dtype) -> Tensor:
     """Part 2 (tile-major, fp16 / bf16) built from part 1: what the modules build on their first forward with more rows."""
     lib = _lib.get_lib()

@@ -134,14 +134,93 @@ class DynamicQuantizeLinear(nn.Module):
         # with the weight-only path (activation quantisation error ~1e-2 relative) and, since round 4, a developer experiment:
         # it needs libqlinear_hip_dev.so (include/qlinear_hip_dev.h; measured behind the weight-only GEMM at every shape)
         self.act_quant = False
+        # low-footprint mode (round 5): drop_canonical() frees the canonical GPU buffers and keeps serving from the derived layouts;
+        # part 1 (or the gate-interleaved part 1) is then the copy state_dict() is rebuilt from.  None = canonical buffers resident.
+        self._dropped_key = None
 
     # -- derived layout -----------------------------------------------------------------------
     def _canonical_key(self):
+        if self._dropped_key is not None:            # dropped: nobody can have written the canonical buffers since
+            return self._dropped_key
         return _lib.buffer_key(self.weight, self.weight_scale)
+
+    # -- low-footprint mode -------------------------------------------------------------------
+    @property
+    def canonical_dropped(self) -> bool:
+        return self.__dict__.get("_dropped_key") is not None
+
+    @torch.no_grad()
+    def drop_canonical(self):
+        """Free the canonical ``weight`` / ``weight_scale`` GPU buffers (the reference's 6 GB-class footprint, readme.md:72: with
+        them AND the derived layouts resident a ChatGLM2-6B int4g32 model holds the weights 2 - 3.5 times).  The module keeps
+        serving every GPU call from its derived layouts; the buffers become shape-only stand-ins (one element of storage), and
+        ``state_dict()`` / ``save_pretrained`` rebuild the canonical tensors byte for byte from part 1 - the repack is a bijection
+        (``qlinear_w4g32_unpack_gemv``) - so checkpoints are unchanged (chatglm_q/loader.py:90-104).  Whatever needs the canonical
+        data itself (backward, the canonical-layout kernel for fp32 rows > 4, ``.to()``, loading) restores it first
+        (``restore_canonical``).  Returns the bytes freed (0 when nothing was resident or the layout is not supported)."""
+        if self.canonical_dropped or not self._packed_supported():
+            return 0
+        if self._packed is None and self._gated is None:
+            self._build_part1()
+        elif self._packed is not None and self._packed_key != self._canonical_key():
+            self._build_part1()                      # a stale part 1 must not become the only copy
+        freed = self.weight.numel() * self.weight.element_size() + self.weight_scale.numel() * self.weight_scale.element_size()
+        key = self._canonical_key()
+        dev, sdt = self.weight.device, self.weight_scale.dtype
+        shape_w, shape_s = tuple(self.weight.shape), tuple(self.weight_scale.shape)
+        self.weight = torch.empty(1, dtype=torch.uint8, device=dev).expand(shape_w)
+        self.weight_scale = torch.empty(1, dtype=sdt, device=dev).expand(shape_s)
+        self._dropped_key = key
+        return freed
+
+    @torch.no_grad()
+    def _rebuild_canonical(self):
+        """(weight, weight_scale) as fresh tensors from the resident derived layout."""
+        K, N, dt = self.in_features, self.out_features, self.weight_scale.dtype
+        if self._packed is not None:
+            return hip_ops.unpack_w4g32_gemv(self._packed, N, K, dt)
+        if self._gated is not None:                  # a first MLP projection whose plain part 1 was released: undo the column order
+            perm = hip_ops.gate_interleave(N // 2, self._gated[0].device)
+            w, sc = hip_ops.unpack_w4g32_gemv(self._gated[0], N, K, dt)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(N, device=perm.device)
+            return w.index_select(1, inv), sc.index_select(1, inv)
+        raise RuntimeError("canonical buffers were dropped and no part 1 is resident to rebuild them from")
+
+    @torch.no_grad()
+    def restore_canonical(self):
+        """Undo ``drop_canonical``: the canonical buffers are rebuilt from part 1 and resident again (derived layouts stay valid)."""
+        if not self.canonical_dropped:
+            return self
+        w, sc = self._rebuild_canonical()
+        key_before = self._dropped_key
+        self._dropped_key = None
+        self.weight, self.weight_scale = w, sc
+        # the derived layouts were built from exactly these bytes: re-key them to the new buffers instead of rebuilding
+        key = self._canonical_key()
+        for part in ("packed", "tiled", "a8"):
+            if getattr(self, "_" + part) is not None and getattr(self, "_" + part + "_key") == key_before:
+                setattr(self, "_" + part + "_key", key)
+        if self._gated is not None and self._gated_key[0] == key_before:
+            same = self._gated_tiled_key == self._gated_key
+            self._gated_key = (key, self._gated_key[1])
+            if same:
+                self._gated_tiled_key = self._gated_key
+        return self
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if not self.canonical_dropped:
+            return super()._save_to_state_dict(destination, prefix, keep_vars)
+        w, sc = self._rebuild_canonical()            # temporaries: the module stays in low-footprint mode
+        destination[prefix + "weight"] = w
+        destination[prefix + "weight_scale"] = sc
+        if self.bias is not None:
+            destination[prefix + "bias"] = self.bias if keep_vars else self.bias.detach()
 
     def invalidate(self):
         """Drop every derived layout; the next GPU forward rebuilds them from the canonical buffers.  Needed only
         after a write the version counter cannot see (``weight.data.copy_``, raw pointers, inference tensors)."""
+        self.restore_canonical()                    # low-footprint mode: part 1 is the only copy - the canonical buffers come back first
         self._packed, self._packed_key = None, None
         self._tiled, self._tiled_key = None, None
         self._gated, self._gated_key = None, None
@@ -156,6 +235,9 @@ class DynamicQuantizeLinear(nn.Module):
         ``parts``: any of "packed" (part 1, the GEMVs), "tiled" (part 2, the MFMA kernels), "gated" (gate-interleaved part 1 of
         a first MLP projection), "gated_tiled", "a8" (W4A8 copy).  E.g. a decode-only session keeps "packed" for
         qkv_proj / o_proj / w_out / lm_head and only "gated" for w_in: ``w_in.release("packed", "tiled", "gated_tiled")``."""
+        if self.canonical_dropped and not any(getattr(self, "_" + p) is not None and p not in parts for p in ("packed", "gated")):
+            raise ValueError("canonical buffers are dropped: part 1 (or the gate-interleaved part 1) is the only copy of the weights; "
+                             "restore_canonical() first")
         for part in parts:
             if part not in ("packed", "tiled", "gated", "gated_tiled", "a8"):
                 raise ValueError(f"unknown derived layout {part!r}")
@@ -171,7 +253,7 @@ class DynamicQuantizeLinear(nn.Module):
             t = t[0] if isinstance(t, tuple) else t
             return 0 if t is None else t.numel() * t.element_size()
         out = {k: nb(getattr(self, "_" + k)) for k in ("packed", "tiled", "gated", "gated_tiled", "a8")}
-        out["canonical"] = nb(self.weight) + nb(self.weight_scale)
+        out["canonical"] = 0 if self.canonical_dropped else nb(self.weight) + nb(self.weight_scale)
         return out
 
     def __setattr__(self, name, value):
@@ -181,14 +263,18 @@ class DynamicQuantizeLinear(nn.Module):
             _lib.bump_layout_epoch()
 
     def _load_from_state_dict(self, *args, **kwargs):
+        self.restore_canonical()                # real buffers to copy into (a partial load keeps the rest of the data)
         super()._load_from_state_dict(*args, **kwargs)
         self.invalidate()
 
     def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): new storage (whose address may be a reused one)
+        self.restore_canonical()                # the derived layouts do not travel: the canonical data must
         self.invalidate()
         return super()._apply(fn, *args, **kwargs)
 
     def _packed_supported(self) -> bool:
+        if self.canonical_dropped:              # only a supported layout can have been dropped
+            return True
         return (W4_LAYOUT != "canonical" and self.group_size == 32 and self.weight.is_cuda
                 and self.weight.is_contiguous() and self.weight_scale.is_contiguous())
 
@@ -209,7 +295,9 @@ class DynamicQuantizeLinear(nn.Module):
     def _build_part1(self):
         key = self._canonical_key()
         if self._packed is None or self._packed_key != key:
-            self._packed = hip_ops.repack_w4g32_gemv(self.weight, self.weight_scale)
+            # low-footprint mode with only the gate-interleaved part 1 resident: the canonical bytes are rebuilt as temporaries
+            w, sc = self._rebuild_canonical() if self.canonical_dropped else (self.weight, self.weight_scale)
+            self._packed = hip_ops.repack_w4g32_gemv(w, sc)
             self._packed_key = key
             self._plans, self._fast = {}, {}
             _lib.bump_layout_epoch()
@@ -236,6 +324,12 @@ class DynamicQuantizeLinear(nn.Module):
             raise ValueError("gated layout needs a supported (K, 2 * hidden) int4g32 weight")
         key = (self._canonical_key(), _lib.buffer_key(self.bias))
         if getattr(self, "_gated", None) is None or self._gated_key != key:
+            if self.canonical_dropped:              # the permuted copy is built from the canonical columns: bring them back for the build
+                self.restore_canonical()
+                try:
+                    return self.gated_packed(hidden)
+                finally:
+                    self.drop_canonical()
             perm = hip_ops.gate_interleave(hidden, self.weight.device)
             packed = hip_ops.repack_w4g32_gemv(self.weight.index_select(1, perm), self.weight_scale.index_select(1, perm))
             bias = self.bias.index_select(0, perm) if self.bias is not None else None
@@ -267,6 +361,7 @@ class DynamicQuantizeLinear(nn.Module):
                 return out
         if check_input(input):
             if input.requires_grad and torch.is_grad_enabled():
+                self.restore_canonical()        # the autograd function saves (and its backward reads) the canonical buffers
                 out = dynamic_quant_matmul(input, self.weight, self.weight_scale)
                 if self.bias is not None:
                     out = out + self.bias      # not in place: the Function's output may be a view
@@ -288,6 +383,8 @@ class DynamicQuantizeLinear(nn.Module):
                     packed = self.prepare()._packed
             # bias is added inside the kernel epilogue AFTER the rounding to the output dtype,
             # i.e. the same two roundings as "out = matmul(); out += bias" (qlinear.py:90-94)
+            if packed is None and tiled is None:
+                self.restore_canonical()        # the canonical-layout kernel (fp32 rows > 4, odd shapes) reads the canonical buffers
             plan_out = [] if (packed is not None or tiled is not None) and rows > 0 and not self.act_quant else None
             out = hip_ops.w4_forward(input, self.weight, self.weight_scale, self.bias, packed, tiled=tiled, plan_out=plan_out)
             if plan_out and plan_out[0] is not None:
@@ -302,6 +399,7 @@ class DynamicQuantizeLinear(nn.Module):
 
     @torch.no_grad()
     def apply_weights_(self, q_weight: Tensor, scale: Tensor, bias: Tensor = None):
+        self.restore_canonical()
         self.weight.copy_(q_weight)
         self.weight_scale.copy_(scale)
         if bias is not None:

@@ -136,7 +136,7 @@ class DynamicQuantizeLinear(nn.Module):
         from .. import _lib
         if (self.out_features != 2 * hidden or hidden % 2 or self.in_features % 128 or self.in_features < 256 or
                 not _lib.get_lib().qlinear_gated_serves(a_q.shape[0], self.out_features, self.in_features,
-                                                        _lib.dtype_code(self.weight_scale.dtype), 8)):
+                                                        _lib.dtype_code(self.weight_scale.dtype), 88)):
             return None
         tiled, s_perm, b_perm = self.gated_tiled(hidden)
         return hip_ops.w8a8_gemm_tiled_gated(a_q, a_scale, tiled, self.out_features, s_perm, b_perm)

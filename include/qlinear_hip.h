@@ -111,13 +111,16 @@ uint64_t qlinear_launch_count(void);
 #define QL_K_W8A8_TILED 16      /* w8a8.hip: 64 / 128-row tiles, tile-major copy */
 #define QL_K_W8A8_GEMM256 17    /* w8a8_gemm256.hip */
 #define QL_K_ACT_QUANT 18
-#define QL_K_W4_STREAMK_FIXUP 19 /* w4_gemm256.hip: sums the fp32 partial tiles of a stream-K tail */
 uint64_t qlinear_last_dispatch(void);
 void qlinear_dispatch_reset(void);
 void qlinear_dispatch_reload(void);   /* parse QLINEAR_DISPATCH again (it is read once, at the first dispatch decision) */
+/* The parsed QLINEAR_DISPATCH switches as the library holds them (bit 0 no256, 1 nopeel, 2 nofewrow, 3 norows4, 4 nogroupattn,
+ * 5 nopersist): a host that sizes a workspace or picks an entry point by one of them asks here instead of parsing the variable again. */
+unsigned qlinear_dispatch_flags(void);
 
 /* Environment variables read by THIS library (chatglm_q_amd/csrc/tune.h): exactly one,
- *   QLINEAR_DISPATCH = comma list of kernel families the dispatch must not use: no256, nopeel, nofewrow, norows4, nogroupattn
+ *   QLINEAR_DISPATCH = comma list of kernel families the dispatch must not use: no256, nopeel, nofewrow, norows4, nogroupattn,
+ *   nopersist (the persistent launch of the int4g32 256-tile GEMM and its half-tile last round: one tile per workgroup instead)
  * (every family has a slower fallback computing the same function; for A/B measurements and triage).  The host package reads
  * QLINEAR_LIB_PATH (another build of this library) and QLINEAR_STRICT (0 / 1 / auto: the per-weight rounding policy, see
  * QL_FLAG_STRICT_ROUNDING) - chatglm_q_amd/_lib.py.  Every other tuning value is a compile-time constant with its measurement
@@ -179,7 +182,8 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * qlinear_w4g32_fwd_tiled), 0 when part 1 does: one or two rows (GEMV), 2..4 rows in the default arithmetic on the 4x4x4
  * matrix instruction while the staged rows stay within 64 KB (w4_rows4.hip), fp32 at any row count. */
 int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags);
-/* 1 when qlinear_w4g32_fwd_tiled_gated (weight_bits 4) / qlinear_w8_fwd_tiled_gated (weight_bits 8) serves M rows of a first MLP
+/* 1 when qlinear_w4g32_fwd_tiled_gated (weight_bits 4) / qlinear_w8_fwd_tiled_gated (weight_bits 8) / qlinear_w8a8_fwd_tiled_gated
+ * (weight_bits 88: int8 activations x int8 weights, the ring kernel's own rule) serves M rows of a first MLP
  * projection (N = 2 * hidden outputs) with SiLU * gate in its epilogue, 0 when it would return QL_ERR_UNSUPPORTED for the shape:
  * lets a host ask BEFORE it builds the gate-interleaved tile-major copy (~120 MB per ChatGLM2-6B layer). */
 int qlinear_gated_serves(int64_t M, int64_t N, int64_t K, int dtype, int weight_bits);
@@ -187,6 +191,10 @@ size_t qlinear_w4g32_gemv_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 size_t qlinear_w4g32_tiled_bytes(int64_t N, int64_t K, int64_t group, int dtype);
 int qlinear_w4g32_repack_gemv(const uint8_t* Wq, const void* S, void* gemv, int64_t N, int64_t K, int64_t group, int dtype,
                               void* stream);
+/* The inverse of qlinear_w4g32_repack_gemv (round 5): part 1 -> the canonical buffers Wq (K / 2, N) uint8 and S (K / 32, N), byte for
+ * byte.  A host that keeps only derived layouts resident (chatglm_q_amd: DynamicQuantizeLinear.drop_canonical) serves state_dict()
+ * and checkpoints - the reference's buffer contract, chatglm_q/loader.py:90-104 - through it. */
+int qlinear_w4g32_unpack_gemv(const void* gemv, uint8_t* Wq, void* S, int64_t N, int64_t K, int64_t group, int dtype, void* stream);
 int qlinear_w4g32_tile(const void* gemv, void* tiled, int64_t N, int64_t K, int64_t group, int dtype, void* stream);
 int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                             int64_t group, int64_t lda, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
@@ -352,7 +360,7 @@ int qlinear_w8a8_fwd_tiled256(const int8_t* Aq, const float* a_scale, const void
                               int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
 /* int8 ACTIVATIONS x the gate-interleaved tile-major copy of a first MLP projection (round 4): the many-row ring kernel with SiLU * gate
  * (chatglm_q/model.py:200-201) in its epilogue, C (M, N / 2) with 8-byte aligned rows; bit-equal to qlinear_w8a8_fwd_tiled followed by
- * qlinear_silu_mul.  QL_ERR_UNSUPPORTED when the 256 x 256-tile kernel does not serve the row count (qlinear_gated_serves(.., 8)). */
+ * qlinear_silu_mul.  QL_ERR_UNSUPPORTED when the 256 x 256-tile kernel does not serve the row count (qlinear_gated_serves(.., 88)). */
 int qlinear_w8a8_fwd_tiled_gated(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
                                  int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* stream);
 /* Both steps of the int8-activation linear in ONE call (two launches): quantise A (M, K) row-wise (or per tensor:

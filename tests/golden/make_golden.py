@@ -15,7 +15,7 @@ Two independent reference routes are recorded for every matmul case:
 
 bf16 arrays are stored as uint16 bit patterns (numpy has no bf16); key suffix ``_bf16bits``.
 
-Every generator pins ``torch.set_num_threads`` (1 for the small fixtures, a fixed count for the real-dimension ones), so that the
+Every generator pins ``torch.set_num_threads`` (1 for the small fixtures, 8 for the real-dimension model fixtures), so that the
 fp16 outputs of torch's CPU GEMM - whose summation order follows the thread split - regenerate byte for byte.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
@@ -244,10 +244,10 @@ def gen_quantizers():
 
 
 def gen_w8a8():
-    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """Exact-integer stage of the W8A8 semantic (SURVEY.md 8a-A7): quantize_int8 on activations
     (fp32 arithmetic) composed with an integer matmul; plus the reference's W8A16 output on the
     same inputs so the quantisation error can be reported."""
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     d = {}
     torch.manual_seed(4000)
     M, K, N = 16, 512, 256
@@ -296,10 +296,10 @@ def gen_embedding():
 
 
 def gen_model():
-    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """Tiny-config int4g32 ChatGLM2 (hidden 128, FFN 224 = 7 groups, 2 layers, vocab 256): every buffer, the ids, prefill
     logits, one cached decode step, and the sampler's output on fixed logits.  Pins the build's own
     model graph / decode loop (harness for BASELINE configs 4 and 5)."""
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     from chatglm_q import model as refm
     from chatglm_q import loader as refl
     from chatglm_q.decoder import top_p_sampling
@@ -529,10 +529,61 @@ def gen_model_r3():
     np.savez_compressed(os.path.join(OUT, "model_r3.npz"), **d)
 
 
+def gen_model_full():
+    """Round 5 (tests/golden/model_full.npz): the WHOLE ChatGLM2-6B geometry - 28 layers, hidden 4096, FFN 13696, 32 heads x 128,
+    2 groups, vocabulary 65024 (chatglm_q/model.py:17-33 defaults) - int4g32, fp16, through the reference model on CPU
+    (chatglm_q/decoder.py:65-108's call pattern: one prefill, then cached one-token steps).  Weights from tests/_golden.py::fill_seeded_
+    (a pure function of the state_dict keys: nothing of the 3.4 GB is stored).  Stored: 32 prompt ids, 4 teacher-forced next ids, the
+    last-position logits of the prefill and of every decode step (fp16, 65024 each), the reference's own greedy choice per step and
+    four cache rows of the LAST layer."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import time
+    import _golden as G
+    from chatglm_q import model as refm
+    from chatglm_q import loader as refl
+    torch.set_num_threads(8)
+    cfg = refm.ChatGLM2Config(**G.FULL_CONFIG)
+    t0 = time.time()
+    m = refl.create_quant_int4_model(cfg, dtype=torch.float16)
+    G.fill_seeded_(m.state_dict(), seed=G.FULL_SEED)
+    m.eval()
+    print("model filled in", round(time.time() - t0, 1), "s")
+    d = {}
+    gen = torch.Generator().manual_seed(8500)
+    V = cfg.vocab_size
+    ids = torch.randint(0, V, (1, 32), generator=gen)
+    nxt = torch.randint(0, V, (4,), generator=gen)
+    d["ids"] = ids.numpy().astype(np.int32); d["next_ids"] = nxt.numpy().astype(np.int32)
+    t0 = time.time()
+    with torch.no_grad():
+        _, lg, kv = m(input_ids=ids)
+    print("prefill", round(time.time() - t0, 1), "s")
+    put(d, "prefill_last_logits", lg[:, -1])
+    greedy = [int(lg[0, -1].float().argmax())]
+    for t in range(4):
+        t0 = time.time()
+        with torch.no_grad():
+            _, lg, kv = m(input_ids=nxt[t].view(1, 1), past_key_values=kv)
+        put(d, f"decode_logits_{t}", lg[:, -1])
+        greedy.append(int(lg[0, -1].float().argmax()))
+        print("decode", t, round(time.time() - t0, 1), "s")
+    d["greedy_ids"] = np.array(greedy, dtype=np.int32)
+    pos = torch.tensor([0, 15, 31, 35])
+    d["kv_positions"] = pos.numpy()
+    L = cfg.num_layers - 1
+    put(d, "kv_last_k", kv[L][0][:, pos]); put(d, "kv_last_v", kv[L][1][:, pos])
+    d["config"] = np.array([G.FULL_CONFIG[k] for k in ("hidden_size", "inner_hidden_size", "head_hidden_size",
+                                                       "num_multi_query_groups", "num_attention_heads", "num_layers",
+                                                       "vocab_size", "max_sequence_length")])
+    d["seed"] = np.array([G.FULL_SEED])
+    np.savez_compressed(os.path.join(OUT, "model_full.npz"), **d)
+
+
 def gen_backward():
-    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     """grad_A of both quantized matmuls through the reference's own autograd functions (CPU route:
     chatglm_q/int4/qlinear.py:53-64, chatglm_q/int8/qlinear.py:41-52)."""
+    torch.set_num_threads(1)                 # byte-reproducible: torch's fp16 CPU GEMM changes its summation order with the thread split
     d = {}
     names = []
     cases = [("i4_f16_m5", 4, (5, 256), 256, 192, "f16"), ("i4_bf16_m3", 4, (3, 128), 128, 64, "bf16"),
@@ -585,11 +636,11 @@ def gen_loader():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "model_r3", "backward", "loader"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "model_r3", "model_full", "backward", "loader"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "model_r3": gen_model_r3, "backward": gen_backward, "loader": gen_loader}[w]()
+         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "model_r3": gen_model_r3, "model_full": gen_model_full, "backward": gen_backward, "loader": gen_loader}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

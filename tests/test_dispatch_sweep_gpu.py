@@ -32,7 +32,8 @@ from chatglm_q_amd.int8 import qlinear as q8  # noqa: E402
 DEV = "cuda:0"
 # (K, N, bias, role)   chatglm_q/model.py:111 (qkv_proj, bias), :112 (o_proj), :194 (w_in -> SiLU * gate), :195 (w_out -> + residual)
 SHAPES = {"qkv_proj": (4096, 4608, True, None), "o_proj": (4096, 4096, False, "residual"),
-          "w_in": (4096, 27392, False, "gated"), "w_out": (13696, 4096, False, "residual")}
+          "w_in": (4096, 27392, False, "gated"), "w_out": (13696, 4096, False, "residual"),
+          "lm_head": (4096, 65024, False, None)}            # chatglm_q/model.py:262-263,382: 254 column tiles of 256
 K_OTHER, K_W4_GEMV, K_W4_ROWS4, K_W4_FEWROW, K_W4_GEMM128, K_W4_GEMM256 = 1, 2, 3, 4, 5, 6
 K_SPLITK, K_W8_GEMV, K_W8_FEWROW, K_W8_GEMM128, K_W8_GEMM256 = 9, 10, 11, 12, 13
 M_MAX = 8192
@@ -98,6 +99,9 @@ def sample_cols(N, role):
     """All columns of the narrow layers; for w_in 64-column runs spread over the matrix (first, last and ragged 256-tile included)."""
     if N <= 8192:
         return None
+    if role != "gated":                                       # lm_head: runs over the whole width, both ends and the last 256-tile
+        starts = sorted({0, 192, N - 256, N - 64} | set(range(1000, N - 64, 3391)))
+        return torch.unique(torch.cat([torch.arange(s, s + 64) for s in starts]))
     hidden = N // 2
     starts = sorted({0, 192, 4096 - 32, hidden - 64, hidden - 256 + 32} | set(range(1000, hidden - 64, 1709)))
     cols = torch.cat([torch.arange(s, s + 64) for s in starts])
@@ -254,8 +258,6 @@ def test_dispatch_boundaries_fp16(name, bits):
     seen = run_sweep(name, bits, torch.float16)
     if bits == 4:
         need = {(K_W4_GEMV,), (K_W4_ROWS4,), (K_W4_FEWROW,), (K_W4_GEMM128,), (K_W4_GEMM256,)}
-        if name in ("qkv_proj", "w_in"):
-            need.add((K_W4_GEMM256, K_W4_GEMM128))          # the peel exists at these widths
     else:
         need = {(K_W8_GEMV,), (K_W8_FEWROW,), (K_W8_GEMM128,), (K_W8_GEMM256,)}
     assert need <= seen, f"{name}: kernel families never reached: {need - seen}"
@@ -266,6 +268,32 @@ def test_dispatch_boundaries_bf16(bits):
     """One bf16 pass (strict per-weight rounding by policy: no 4x4x4-MFMA kernel, GEMV for 1..2 rows)."""
     seen = run_sweep("o_proj", bits, torch.bfloat16)
     assert ((K_W4_GEMM256,) if bits == 4 else (K_W8_GEMM256,)) in seen
+
+
+def test_last_round_half_tiles_replace_the_peel_where_the_persistent_launch_runs():
+    """Round 5: the persistent 256-tile launch runs a last round that fills at most half the chip as in-kernel half tiles (K % 128 == 0,
+    K >= 1024: every ChatGLM2-6B layer shape), so the dispatch table no longer peels there - one launch, one summation order for all
+    rows.  The older peel (last row tiles on the 128-row-tile kernel) still serves the K the persistent launch does not take."""
+    M, N = 8192, 4608                                       # 576 tiles of 256 x 256 = 2.25 rounds of 256 workgroups
+    fam, first = table(4, M, N, 4096)
+    assert fam == K_W4_GEMM256 and first == M               # no peel: qkv_proj at config 5's row count is ONE launch
+    fam, first = table(4, M, N, 4160)                       # 65 K tiles: an odd count, not the persistent launch's
+    assert fam == K_W4_GEMM256 and 0 < first < M
+    g = torch.Generator().manual_seed(77)
+    for K, want in ((4096, [K_W4_GEMM256]), (4160, [K_W4_GEMM256, K_W4_GEMM128])):
+        qw = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8, generator=g)
+        sc = (torch.rand((K // 32, N), generator=g) * 0.02 + 0.002).half()
+        mod = q4.DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16)
+        mod.apply_weights_(qw, sc, None)
+        mod = mod.to(DEV)
+        x = torch.randn((M, K), generator=g).half()
+        _lib.get_lib().qlinear_dispatch_reset()
+        with torch.no_grad():
+            y = mod(x.to(DEV))
+        assert families() == want, (K, families())
+        rows = torch.tensor([0, 255, 4095, 7167, 7168, 7295, 7296, 7423, 7424, 8191])     # both halves of the last round's tiles
+        ref = O.w4_matmul(t2n(x[rows]), qw.numpy(), t2n(sc), None, dtype="f16")
+        assert O.rel_l2(t2n(y[rows.to(DEV)]), ref) <= 1.5e-4
 
 
 def test_dispatch_override_switches_families(monkeypatch):

@@ -68,3 +68,59 @@ def test_checkpoint_folder_to_graph_decode_and_reload_into_same_model(tmp_path):
     for got, want in zip(outs_b, want_b):
         assert torch.equal(got, want)                                               # same weights, same kernels: bit for bit
     assert O.rel_l2(t2n(outs_b[0]), f32("b1/prefill_logits")[:, -1]) > 0.1          # ... and no longer model A's logits
+
+
+def test_low_footprint_mode_drops_the_canonical_copy_and_round_trips_byte_for_byte(tmp_path):
+    """Round 5: ``DecodeSession(low_footprint=True)`` drops the canonical GPU buffers of every int4 module once
+    the derived layouts exist; decode and prefill keep producing the same bits, ``state_dict()`` / ``save_model`` rebuild the
+    canonical tensors from part 1 (the gate-interleaved part 1 for a first MLP projection whose plain copy a decode-only session
+    released) byte for byte, a reload of the saved folder equals the original checkpoint (chatglm_q/loader.py:90-104)."""
+    from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear as Q4
+    from chatglm_q_amd.loader import load_model, save_model
+    config, model = L.load_model(_folder(tmp_path, int(R["seed"][0]) + 7, "orig"))
+    want = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    _, m = load_model(tmp_path / "orig", device=DEV)
+    m.eval()
+    ids = torch.randint(0, config.model_config.vocab_size, (1, 12), generator=torch.Generator().manual_seed(5))
+    ref = DecodeSession(m, 1, 32, use_graph=True)
+    ref_last = ref.prefill(ids).clone()
+    ref.capture(greedy=True)
+    ref_steps = [ref.decode_step().clone() for _ in range(3)]
+    resident_before = sum(sum(q.derived_nbytes().values()) for q in m.modules() if isinstance(q, Q4))
+
+    _, m2 = load_model(tmp_path / "orig", device=DEV)
+    m2.eval()
+    low = DecodeSession(m2, 1, 32, use_graph=True, decode_only=True, low_footprint=True)
+    assert torch.equal(low.prefill(ids), ref_last)
+    low.capture(greedy=True)
+    for want_logits in ref_steps:
+        assert torch.equal(low.decode_step(), want_logits)
+    q4s = [q for q in m2.modules() if isinstance(q, Q4)]
+    assert q4s and all(q.canonical_dropped and q.derived_nbytes()["canonical"] == 0 for q in q4s)
+    resident_low = sum(sum(q.derived_nbytes().values()) for q in q4s)
+    canonical = sum(v.numel() * v.element_size() for k, v in want.items() if k.endswith(("weight", "weight_scale")) and "ln" not in k
+                    and "word_embedding" not in k)
+    assert resident_low <= 1.1 * canonical < resident_before           # one copy of the weights instead of two to three and a half
+    got = m2.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    for k, v in want.items():
+        assert torch.equal(got[k].cpu(), v), k                     # incl. modules whose only resident copy is gate-interleaved
+    save_model(tmp_path / "low", config, m2)
+    _, m3 = load_model(tmp_path / "low", device="cpu")
+    for k, v in m3.state_dict().items():
+        assert torch.equal(v, want[k]), k
+    assert all(q.canonical_dropped for q in q4s)                   # serving the state_dict did not bring the copies back
+    # a second prefill in low-footprint mode rebuilds what the decode-only session released, without the canonical copy
+    low2 = DecodeSession(m2, 1, 32, use_graph=False, low_footprint=True)
+    assert torch.equal(low2.prefill(ids), ref_last)
+    # loading new weights into a dropped module: the buffers come back, the data is the new data
+    q = q4s[0]
+    sd = {k: v.clone() for k, v in q.state_dict().items()}
+    sd["weight"] = (sd["weight"] ^ 0x11)
+    q.load_state_dict(sd)
+    assert not q.canonical_dropped and torch.equal(q.weight, sd["weight"])
+    x = torch.randn(2, q.in_features, device=DEV, dtype=q.weight_scale.dtype)
+    y = q(x)
+    q.drop_canonical()
+    assert torch.equal(q(x), y) and torch.equal(q.state_dict()["weight"], sd["weight"])
+    assert q.to("cpu").weight.shape == sd["weight"].shape and not q.canonical_dropped and torch.equal(q.weight, sd["weight"].cpu())

@@ -218,6 +218,47 @@ def test_int4_gemm256_vs_oracle(M, K, N, dt, has_bias):
         h4.w4_gemm256(a.to(DEV)[:, :32].contiguous(), tiled, N)                      # K = 32: not served
 
 
+@pytest.mark.parametrize("M,K,N,kind", [(8192, 4096, 4096, "plain"), (8192, 4096, 4608, "bias"), (8192, 4096, 4096, "residual"),
+                                         (4096, 4096, 27392, "gated"), (8100, 1024, 4600, "plain"), (8192, 13696, 4096, "plain")])
+def test_int4_persistent_launch_equals_one_tile_per_workgroup(M, K, N, kind, monkeypatch):
+    """Round 5: the 256-tile GEMM as ONE persistent launch (w4_gemm256p_kernel: a workgroup per CU walks its tiles as one stream of K
+    tiles; a last round that fills at most half the chip runs as 128-row half tiles) against the one-tile-per-workgroup launch
+    (QLINEAR_DISPATCH=nopersist): bit for bit - every output element keeps its K order.  2 rounds (o_proj), 2.25 rounds with a half-tile
+    tail (qkv_proj, bias), the residual and SiLU * gate epilogues (w_in at 4096 rows: 1 712 tiles = 6.69 rounds), ragged M and N,
+    K = 13696 (214 K tiles)."""
+    lib = _lib.get_lib()
+    qw, sc = _rand_w4(K, N, "f16", seed=K * 5 + N)
+    g = torch.Generator().manual_seed(M + 3)
+    a = torch.randn((M, K), generator=g).half().to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).half().to(DEV) if kind == "bias" else None
+    resid = torch.randn((M, N), generator=g).half().to(DEV) if kind == "residual" else None
+    tiled = h4.tile_w4g32(h4.repack_w4g32_gemv(qw.to(DEV), sc.to(DEV)), N, K, torch.float16)
+
+    def run():
+        if kind == "residual":
+            return h4.w4_forward_tiled_residual(a, tiled, N, bias, resid)
+        if kind == "gated":
+            return h4.w4_forward_gated(a, tiled, N, bias)       # any copy serves as a "gate-interleaved" one: same arithmetic
+        return h4.w4_gemm256(a, tiled, N, bias)
+
+    got = run()
+    assert got is not None
+    try:
+        monkeypatch.setenv("QLINEAR_DISPATCH", "nopersist")
+        lib.qlinear_dispatch_reload()
+        want = run()
+    finally:
+        monkeypatch.delenv("QLINEAR_DISPATCH")
+        lib.qlinear_dispatch_reload()
+    assert want is not None and torch.equal(got, want)
+    if kind in ("plain", "bias"):                               # ... and both against the oracle on a row sample
+        rows = torch.unique(torch.cat([torch.arange(0, M, 211), torch.tensor([M - 129, M - 128, M - 1])]))
+        cols = torch.unique(torch.cat([torch.arange(0, N, 37), torch.tensor([N - 1])]))
+        ref = O.w4_matmul(t2n(a[rows.to(DEV)]), np.ascontiguousarray(qw[:, cols].numpy()), np.ascontiguousarray(t2n(sc[:, cols])),
+                          None if bias is None else t2n(bias[cols.to(DEV)]), dtype="f16")
+        assert O.rel_l2(t2n(got[rows.to(DEV)][:, cols.to(DEV)]), ref) <= 1.5e-4
+
+
 @pytest.mark.parametrize("layout", ["packed", "packed_strict"])
 @pytest.mark.parametrize("M,K,N", [(8192, 4096, 4096), (8192, 13696, 4096)])
 def test_int4_config5_gemm_shapes(M, K, N, layout):
@@ -235,6 +276,88 @@ def test_int4_config5_gemm_shapes(M, K, N, layout):
     assert_close(got, ref, "f16", f"{M}x{K}x{N}")
     assert O.rel_l2(got, ref) <= 1.5e-4, O.rel_l2(got, ref)        # the MFMA GEMM keeps the reference's per-weight rounding
     assert torch.isfinite(out).all()
+
+
+# ---- lm_head: 4096 -> 65024 (chatglm_q/model.py:262-263,382), the fifth ChatGLM2-6B layer shape -------------------------------------
+# 254 column tiles of 256 = 16 256 column quads: its own grid and tile-order regime in every kernel family.  The GPU computes all
+# 65 024 columns; the fp64 oracle checks a column sample (columns are independent): both ends, the last 256-tile, the boundaries of
+# the XCD ranges of the tile order and runs spread over the matrix - the CPU side stays at seconds.
+LM_K, LM_N = 4096, 65024
+
+
+def _lm_head_cols():
+    starts = {0, 256 - 32, LM_N - 256, LM_N - 64} | set(range(1000, LM_N - 64, 2731)) | {LM_N // 8 * i - 32 for i in range(1, 8)}
+    cols = torch.unique(torch.cat([torch.arange(s, s + 64) for s in sorted(starts)]))
+    return cols[cols < LM_N]
+
+
+@pytest.mark.parametrize("layout", ["packed", "packed_strict"])
+@pytest.mark.parametrize("M,dt", [(1, "f16"), (2, "f16"), (8, "f16"), (1, "bf16"), (8192, "f16")])
+def test_int4_lm_head_shape(M, dt, layout):
+    """int4g32 at lm_head size for 1, 2, 8 rows (GEMV / 4x4x4-MFMA kernel / few-row MFMA kernel) and a prefill pass of 8192 rows (the
+    256-tile kernel: 8 128 tiles, 31.75 rounds of the persistent grid; every 29th row + both ends checked)."""
+    if M > 64 and layout.endswith("strict"):
+        pytest.skip("the many-row kernels have one arithmetic (the reference's rounding): covered by the default layout")
+    qw, sc = _rand_w4(LM_K, LM_N, dt, seed=LM_K * 7 + LM_N)
+    g = torch.Generator().manual_seed(M + 13)
+    a = torch.randn((M, LM_K), generator=g).to(TDT[dt])
+    bias = (torch.randn(LM_N, generator=g) * 0.1).to(TDT[dt]) if M == 2 else None
+    qd, sd = qw.to(DEV), sc.to(DEV)
+    out = h4.w4_forward(a.to(DEV), qd, sd, None if bias is None else bias.to(DEV), h4.repack_w4g32(qd, sd), strict=layout.endswith("strict"))
+    assert out.shape == (M, LM_N) and bool(torch.isfinite(out).all())
+    cols = _lm_head_cols()
+    rows = torch.arange(M) if M <= 64 else torch.unique(torch.cat([torch.arange(0, M, 29), torch.tensor([M - 257, M - 256, M - 1])]))
+    ref = O.w4_matmul(t2n(a[rows]), np.ascontiguousarray(qw[:, cols].numpy()), np.ascontiguousarray(t2n(sc[:, cols])),
+                      None if bias is None else t2n(bias[cols]), dtype=dt)
+    got = t2n(out[rows.to(DEV)][:, cols.to(DEV)])
+    assert_close(got, ref, dt, f"lm_head {M} rows", w4_tol(dt, layout, M))
+    if dt == "f16" and (M > 4 or layout.endswith("strict")):
+        assert O.rel_l2(got, ref) <= 1.5e-4, O.rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("M", [1, 2, 8, 8192])
+def test_int8_lm_head_shape(M):
+    """int8 per-channel weights at lm_head size through the module (GEMV / few-row / 256-tile kernels on the derived copy)."""
+    g = torch.Generator().manual_seed(LM_N + M)
+    w = torch.randint(-128, 128, (LM_N, LM_K), dtype=torch.int8, generator=g)
+    sc = ((torch.rand(LM_N, generator=g) - 0.3) * 0.01).half()
+    a = torch.randn((M, LM_K), generator=g).half()
+    layer = q8.DynamicQuantizeLinear(LM_K, LM_N, bias=False, dtype=torch.float16)
+    layer.apply_weights_(w, sc, None)
+    layer = layer.to(DEV)
+    with torch.no_grad():
+        out = layer(a.to(DEV))
+    assert out.shape == (M, LM_N) and bool(torch.isfinite(out).all())
+    cols = _lm_head_cols()
+    rows = torch.arange(M) if M <= 64 else torch.unique(torch.cat([torch.arange(0, M, 29), torch.tensor([M - 257, M - 256, M - 1])]))
+    ref = O.w8_matmul(t2n(a[rows]), np.ascontiguousarray(w[cols].numpy().T), t2n(sc[cols]), None, dtype="f16")
+    got = t2n(out[rows.to(DEV)][:, cols.to(DEV)])
+    assert_close(got, ref, "f16", f"int8 lm_head {M} rows")
+
+
+@pytest.mark.parametrize("M", [8, 512, 8192])
+def test_w8a8_lm_head_shape(M):
+    """int8 activations x int8 weights at lm_head size: quantiser + tile-major GEMM (128-row tiles / the 256-tile ring kernel);
+    bit-equal to the reference's epilogue formula on the exact integer sums of the sampled columns."""
+    g = torch.Generator().manual_seed(LM_N + 3 * M)
+    w = torch.randint(-127, 128, (LM_N, LM_K), dtype=torch.int8, generator=g)
+    sc = (torch.rand(LM_N, generator=g) * 0.01 + 0.001).half()
+    a = torch.randn((M, LM_K), generator=g).half()
+    wd = w.to(DEV)
+    tiled = h8.tile_w8(wd)
+    out = h8.w8a8_forward_tiled(a.to(DEV), tiled, LM_N, sc.to(DEV), None)
+    assert out.shape == (M, LM_N) and bool(torch.isfinite(out).all())
+    cols = _lm_head_cols()
+    rows = torch.arange(M) if M <= 64 else torch.unique(torch.cat([torch.arange(0, M, 29), torch.tensor([M - 257, M - 256, M - 1])]))
+    ref = O.w8a8_matmul(t2n(a[rows]), w[cols].numpy(), t2n(sc[cols]), None, dtype="f16")
+    got = out[rows.to(DEV)][:, cols.to(DEV)].cpu()
+    assert O.rel_l2(t2n(got), ref) <= 3e-4
+    a_q, a_s = h8.act_quant_rowwise(a.to(DEV))
+    acc_exact = (a_q.cpu()[rows].double() @ w[cols].double().t()).float()
+    want_bits = (acc_exact * (a_s.cpu()[rows][:, None] * sc[cols].float()[None, :])).half()
+    assert (got != want_bits).float().mean().item() <= 1e-3         # the 128-row-tile kernel differs from the formula in rounding ties only
+    if M >= 8192:
+        assert torch.equal(got, want_bits)                          # the 256-tile kernel: bit for bit
 
 
 def test_int4_group_sizes_other_than_32():

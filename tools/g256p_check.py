@@ -16,14 +16,16 @@ dev = torch.device("cuda:0")
 mode = sys.argv[1]
 path = os.environ.get("G256P_FILE", "/tmp/g256p_ref.pt")
 CASES = [  # kind, M, K, N, dtype, bias
-    ("plain", 2048, 1024, 4608, torch.float16, True),
+    ("plain", 2048, 1024, 4608, torch.float16, True),       # 144 tiles
+    ("plain", 3000, 1024, 2000, torch.bfloat16, False),     # 96 tiles, ragged M and N
     ("plain", 1000, 4096, 1000, torch.bfloat16, False),
     ("plain", 777, 1024, 264, torch.float16, True),
-    ("plain", 1536, 2048, 2048, torch.float16, False),
-    ("resid", 2048, 1024, 1024, torch.float16, True),
-    ("resid", 1100, 1024, 520, torch.bfloat16, False),
-    ("gated", 1024, 1024, 2048, torch.float16, True),
-    ("gated", 900, 2048, 1056, torch.bfloat16, False),
+    ("plain", 1536, 2048, 2048, torch.float16, False),      # 48 tiles
+    ("plain", 2900, 1152, 1288, torch.float16, True),       # 72 tiles, 18 K tiles, ragged: the last row tile's second half holds 84 rows
+    ("resid", 2048, 1024, 1024, torch.float16, True),       # 32 tiles
+    ("resid", 2200, 1024, 1544, torch.bfloat16, False),     # 63 tiles, ragged
+    ("gated", 1024, 1024, 2048, torch.float16, True),       # 32 tiles
+    ("gated", 2500, 2048, 1056, torch.bfloat16, False),     # 50 tiles, ragged
 ]
 out = {}
 for i, (kind, M, K, N, dt, has_bias) in enumerate(CASES):

@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench_extras import _graph_time, _w4_layer  # noqa: E402
 from chatglm_q_amd import _lib  # noqa: E402
 from chatglm_q_amd.int4 import hip_ops as H4  # noqa: E402
+from chatglm_q_amd.dev import experiments as X  # noqa: E402  (recorded experiments: developer library)
 
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(3)
@@ -30,8 +31,8 @@ gated = [l.gated_packed(HID) for l in ins]
 packed_out = [l.prepare()._packed for l in outs]
 ln = (1 + 0.1 * torch.randn(K, device=dev, generator=gen)).to(dtype)
 h = torch.randn(1, 1, K, device=dev, generator=gen).to(dtype)
-ws = H4.mlp_engine_workspace(2 * HID, dev)
-print("engine supported:", H4.mlp_engine_supported(2 * HID, K, K), "| dtype", dtype, "| strict", _lib.strict_for(dtype))
+ws = X.mlp_engine_workspace(2 * HID, dev)
+print("engine supported:", X.mlp_engine_supported(2 * HID, K, K), "| dtype", dtype, "| strict", _lib.strict_for(dtype))
 
 
 def two(i, x):
@@ -42,7 +43,7 @@ def two(i, x):
 
 def one(i, x):
     gp, gb = gated[i]
-    return H4.w4_mlp_engine(x, ln, 1e-5, gp, gb, 2 * HID, packed_out[i], None, K, ws)
+    return X.w4_mlp_engine(x, ln, 1e-5, gp, gb, 2 * HID, packed_out[i], None, K, ws)
 
 
 if "--no-check" not in sys.argv:
@@ -52,7 +53,7 @@ if "--no-check" not in sys.argv:
             a, b = two(i, x), one(i, x)
             assert b is not None, "engine did not serve the shape"
             torch.cuda.synchronize()
-            assert H4.mlp_engine_error(ws) == 0, f"a bounded wait gave up (code {H4.mlp_engine_error(ws)})"
+            assert X.mlp_engine_error(ws) == 0, f"a bounded wait gave up (code {X.mlp_engine_error(ws)})"
             assert torch.equal(a, b), (rep, i, (a.float() - b.float()).abs().max().item(), int((a != b).sum()))
     print("bit-equal on", NL, "weight sets x 3 inputs")
 
@@ -69,7 +70,7 @@ for name, f in (("two launches", two), ("one persistent launch", one), ("two lau
     ms = _graph_time(torch, dev, chain_plain(f))
     print(f"{name}: {ms / (3 * NL) * 1e3:.2f} us per MLP")
 torch.cuda.synchronize()
-print("error word:", H4.mlp_engine_error(ws))
+print("error word:", X.mlp_engine_error(ws))
 
 # ---- timeline (trace build only) -------------------------------------------------------------------------------------------
 lib = _lib.get_lib()

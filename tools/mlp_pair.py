@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench_extras import _graph_time, _w4_layer  # noqa: E402
 from chatglm_q_amd import _lib  # noqa: E402
 from chatglm_q_amd.int4 import hip_ops as H4  # noqa: E402
+from chatglm_q_amd.dev import experiments as X  # noqa: E402  (recorded experiments: developer library)
 
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(3)
@@ -30,14 +31,14 @@ def two(i, x):
 
 def one(i, x):
     gp, gb = gated[i]
-    return H4.w4_mlp_pair(x, ln, 1e-5, gp, gb, 2 * HID, outs[i].prepare()._packed, None, K, x)
+    return X.w4_mlp_pair(x, ln, 1e-5, gp, gb, 2 * HID, outs[i].prepare()._packed, None, K, x)
 
 
 for i in range(0 if not os.environ.get("PAIR_NOCHECK") else NL, NL):
     a, b = two(i, h), one(i, h)
     assert b is not None, "pair not served"
     torch.cuda.synchronize()
-    assert not H4.mlp_pair_timed_out(dev), "a consumer gave up waiting"
+    assert not X.mlp_pair_timed_out(dev), "a consumer gave up waiting"
     assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
 print("bit-equal on", NL, "weight sets")
 
@@ -63,4 +64,4 @@ for name, f in (("two launches", two), ("one launch", one)):
     ms = _graph_time(torch, dev, chain_plain(f))
     print(f"{name}: {ms / (3 * NL) * 1e3:.2f} us per MLP")
 torch.cuda.synchronize()
-print("timed out:", H4.mlp_pair_timed_out(dev))
+print("timed out:", X.mlp_pair_timed_out(dev))
