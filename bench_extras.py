@@ -78,11 +78,51 @@ def token_sweep(torch, device):
             "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4), "linear_only_tok_per_s": round(1e3 / ms, 1)}
 
 
+def _probe_lib():
+    """The span / probe build of the library (csrc/probe_kernels.hip: floor probes, never part of the product library), or None."""
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chatglm_q_amd", "csrc", "libqlinear_hip_span.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    if not hasattr(lib, "qlinear_probe_read"):
+        return None
+    lib.qlinear_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.qlinear_probe_read_waves.restype = ctypes.c_int64
+    lib.qlinear_probe_read_waves.argtypes = [ctypes.c_int64]
+    return lib
+
+
+def _pure_read_us(torch, device, nbytes, n_sets, reps):
+    """A pure streaming read of `nbytes` per launch (probe kernel: coalesced 16-byte loads, XOR, one store per wave), regions rotated
+    through n_sets x nbytes like the weight sets of the kernel it stands beside, under the same graph protocol: launch boundary + HBM
+    round trip + the bytes - what a dependent launch of this size costs with no arithmetic at all.  None without the probe library."""
+    lib = _probe_lib()
+    if lib is None:
+        return None
+    region = (nbytes + 255) // 256 * 256
+    buf = torch.empty(region * n_sets, dtype=torch.uint8, device=device)
+    buf.random_(0, 256)
+    sink = torch.zeros(int(lib.qlinear_probe_read_waves(nbytes)) + 64, dtype=torch.int32, device=device)
+
+    def fn():
+        st = torch.cuda.current_stream(device).cuda_stream
+        for _ in range(reps):
+            for i in range(n_sets):
+                if lib.qlinear_probe_read(buf.data_ptr() + i * region, nbytes, sink.data_ptr(), st) != 0:
+                    raise RuntimeError("probe launch failed")
+
+    ms = _graph_time(torch, device, fn) / (reps * n_sets)
+    del buf
+    return ms * 1e3
+
+
 def per_shape(torch, device):
-    """Per-shape decode GEMV figures, each rotated over enough weight sets to exceed the Infinity Cache."""
+    """Per-shape decode GEMV figures, each rotated over enough weight sets to exceed the Infinity Cache; beside each the pure
+    streaming read of the same bytes under the same protocol (round 5: the floor of ONE dependent launch of that size on this box)."""
     gen = torch.Generator(device=device).manual_seed(9)
     out = {}
-    for name, K, N, b in [("qkv_proj", 4096, 4608, True), ("w_in", 4096, 27392, False),
+    for name, K, N, b in [("qkv_proj", 4096, 4608, True), ("o_proj", 4096, 4096, False), ("w_in", 4096, 27392, False),
                           ("w_out", 13696, 4096, False), ("lm_head", 4096, 65024, False)]:
         per = K * N // 2 + (K // 32) * N * 2 + K * 2 + N * 2 + (N * 2 if b else 0)
         n_sets = max(2, min(48, int(700e6 // per) + 1))
@@ -101,6 +141,24 @@ def per_shape(torch, device):
                      "frac_of_8TBps": round(per / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         del layers
         torch.cuda.empty_cache()
+        try:
+            floor = _pure_read_us(torch, device, per, n_sets, reps)
+        except Exception as e:      # a probe never invalidates the figure it stands beside
+            floor = None
+            out[name]["pure_read_error"] = repr(e)[:120]
+        if floor:
+            out[name]["pure_read_us"] = round(floor, 3)
+            out[name]["frac_of_pure_read"] = round(floor / (ms * 1e3), 4)
+        torch.cuda.empty_cache()
+    # one decode token's 113 linear launches priced at the pure-read floor of their shapes (28 layers x 4 + lm_head)
+    try:
+        tok = 28 * sum(out[n]["pure_read_us"] for n in ("qkv_proj", "o_proj", "w_in", "w_out")) + out["lm_head"]["pure_read_us"]
+        mine = 28 * sum(out[n]["us"] for n in ("qkv_proj", "o_proj", "w_in", "w_out")) + out["lm_head"]["us"]
+        out["token_at_pure_read_floor"] = {"floor_us": round(tok, 1), "kernels_us": round(mine, 1), "frac": round(tok / mine, 4),
+                                           "note": "113 plain GEMV launches of a token at M = 1 against pure streaming reads of the same bytes, "
+                                                   "launch for launch"}
+    except KeyError:
+        pass
     return out
 
 
@@ -314,6 +372,46 @@ def prefill_gemm_power(torch, device):
     return out
 
 
+def fp32_many_rows(torch, device):
+    """fp32 activations at 512 x 4096 -> 4096 (round 5, VERDICT r4 missing 2): the fp32 matrix-instruction kernel (wq_gemm_f32.hip,
+    v_mfma_f32_32x32x2_f32 on the canonical buffers, exact fp32 products and sums) beside the VALU kernels that served those calls before
+    (QLINEAR_DISPATCH=nof32mfma), int4g32 and int8 per channel; 157 TFLOP/s = the chip's dense fp32 matrix peak."""
+    from chatglm_q_amd import _lib
+    from chatglm_q_amd.int4 import hip_ops as h4
+    from chatglm_q_amd.int8 import hip_ops as h8
+    lib = _lib.get_lib()
+    gen = torch.Generator(device=device).manual_seed(29)
+    M, K, N = 512, 4096, 4096
+    a = torch.randn(M, K, device=device, generator=gen)
+    qw = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8, device=device, generator=gen)
+    sc = torch.rand(K // 32, N, device=device, generator=gen) * 0.02 + 0.002
+    w8 = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=device, generator=gen)
+    s8 = torch.rand(N, device=device, generator=gen) * 0.01 + 0.001
+    out = {"M": M, "K": K, "N": N}
+    prev = os.environ.get("QLINEAR_DISPATCH")
+    try:
+        for tag, env in (("matrix_kernel", None), ("valu_kernels", "nof32mfma")):
+            if env:
+                os.environ["QLINEAR_DISPATCH"] = env
+            else:
+                os.environ.pop("QLINEAR_DISPATCH", None)
+            lib.qlinear_dispatch_reload()
+            us4 = _graph_time(torch, device, lambda: h4.w4_forward(a, qw, sc)) * 1e3
+            us8 = _graph_time(torch, device, lambda: h8.w8_forward(a, w8.t(), s8)) * 1e3
+            out[tag] = {"int4g32_us": round(us4, 1), "int4g32_TFLOPs": round(2.0 * M * N * K / us4 / 1e6, 1),
+                        "int8_us": round(us8, 1), "int8_TFLOPs": round(2.0 * M * N * K / us8 / 1e6, 1)}
+    finally:
+        if prev is None:
+            os.environ.pop("QLINEAR_DISPATCH", None)
+        else:
+            os.environ["QLINEAR_DISPATCH"] = prev
+        lib.qlinear_dispatch_reload()
+    out["speedup_int4g32"] = round(out["valu_kernels"]["int4g32_us"] / out["matrix_kernel"]["int4g32_us"], 2)
+    out["speedup_int8"] = round(out["valu_kernels"]["int8_us"] / out["matrix_kernel"]["int8_us"], 2)
+    out["frac_of_157TF_fp32_matrix_peak_int4g32"] = round(out["matrix_kernel"]["int4g32_TFLOPs"] / 157.3, 4)
+    return out
+
+
 def int8_prefill_gemm(torch, device):
     """The int8 model's many-row GEMMs at M = 8192 (o_proj and w_out shapes): weight-only (the reference's int8 forward,
     chatglm_q/int8/triton_ops.py:62-73) in TFLOP/s and int8-activation (act_quant) in TOP/s, GEMM launch alone."""
@@ -503,7 +601,37 @@ def e2e_generate(torch, device):
         except Exception as e:
             bd[f"batch_{Bd}"] = {"error": repr(e)}
     out["batched_decode"] = bd
-    del model, sess
+    # low-footprint mode (round 5): the canonical GPU buffers dropped once the derived layouts exist (state_dict / checkpoints are
+    # rebuilt byte for byte from part 1).  Measured on the model as this function leaves it (prefill + decode layouts resident), then
+    # in a decode-only session; the decode speed of the low-footprint graph beside the default one.
+    try:
+        low = {}
+        sess = DecodeSession(model, 1, 256, use_graph=True, low_footprint=True)
+        idl = torch.randint(0, cfg.vocab_size, (1, 32), device=device)
+        lg = sess.prefill(idl)
+        sess.tok.copy_(lg.argmax(-1, keepdim=True))
+        sess.capture(greedy=True)
+        low["prefill_and_decode_layouts"] = _resident_bytes(model)
+        del sess
+        sess = DecodeSession(model, 1, 256, use_graph=True, low_footprint=True, decode_only=True)
+        lg = sess.prefill(idl)
+        sess.tok.copy_(lg.argmax(-1, keepdim=True))
+        sess.capture(greedy=True)
+        sess.decode_step(greedy=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(128):
+            sess.decode_step(greedy=True)
+        torch.cuda.synchronize()
+        low["decode_only"] = _resident_bytes(model)
+        low["decode_only_tok_per_s"] = round(128 / (time.perf_counter() - t0), 1)
+        low["note"] = ("resident bytes of the quantized linear layers (canonical + derived layouts); the reference's guidance for int4g32 "
+                       "is 6G+ of VRAM (readme.md:72); the default keeps the canonical copy beside the layouts")
+        out["low_footprint"] = low
+        del sess
+    except Exception as e:      # noqa: BLE001
+        out["low_footprint"] = {"error": repr(e)}
+    del model
     torch.cuda.empty_cache()
     return out
 
@@ -580,7 +708,7 @@ def run(torch, device):
     t0 = time.perf_counter()
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
-                     ("prefill_gemm_M8192", prefill_gemm), ("prefill_gemm_power", prefill_gemm_power), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
+                     ("prefill_gemm_M8192", prefill_gemm), ("prefill_gemm_power", prefill_gemm_power), ("fp32_rows_512", fp32_many_rows), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
                      ("prefill_attention_b4_s2048", prefill_attention), ("e2e_generate", e2e_generate), ("int8_model_prefill", int8_model_prefill),
                      ("e2e_cpu", e2e_cpu)]:
         try:

@@ -27,6 +27,7 @@ static unsigned parse_dispatch_env() {
     if (strstr(e, "no256")) v |= QL_D_NO256;
     if (strstr(e, "nopeel")) v |= QL_D_NOPEEL;
     if (strstr(e, "nopersist")) v |= QL_D_NOPERSIST;
+    if (strstr(e, "nof32mfma")) v |= QL_D_NOF32MFMA;
     if (strstr(e, "nofewrow")) v |= QL_D_NOFEWROW;
     if (strstr(e, "norows4")) v |= QL_D_NOROWS4;
     if (strstr(e, "nogroupattn")) v |= QL_D_NOGROUPATTN;
@@ -124,6 +125,9 @@ int qlinear_w4g32_fwd(const void* A, const uint8_t* Wq, const void* S, const voi
     if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || (K & 1) || lda < K || ldc < N) return QL_ERR_BAD_SHAPE;
     if (group <= 0 || K % group != 0) return QL_ERR_BAD_GROUP;
     hipStream_t st = (hipStream_t)stream;
+    // fp32 activations, 128+ rows: the fp32 matrix instruction on the canonical buffers (wq_gemm_f32.hip, round 5)
+    if (dtype == QL_DTYPE_F32 && group == 32 && act_vec_ok(A, lda, dtype) && wq_gemm_f32_serves(M, N, K) && !(dispatch_flags() & QL_D_NOF32MFMA))
+        return w4_gemm_f32(A, Wq, S, bias, C, M, N, K, lda, ldc, st);
     const bool fast = group == 32 && N % 8 == 0 && act_vec_ok(A, lda, dtype) && aligned(Wq, 8) && aligned(S, 16);
     if (!fast) return w4_generic(dtype, A, Wq, S, bias, C, M, N, K, group, lda, ldc, st);
     const size_t need = w4_canon_workspace_bytes(M, N, K);
@@ -378,6 +382,9 @@ int qlinear_w8_fwd(const void* A, const int8_t* W, const void* S, const void* bi
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype) && M > 4 && K % 16 == 0 &&
         (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))
         return w8_gemm(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, workspace, workspace_bytes, st);   // many rows: MFMA, reference rounding
+    if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype) && dtype == QL_DTYPE_F32 && wq_gemm_f32_serves(M, N, K) &&
+        !(dispatch_flags() & QL_D_NOF32MFMA))
+        return w8_gemm_f32(A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, st);   // fp32, 128+ rows: the fp32 matrix instruction (wq_gemm_f32.hip, round 5)
     if (k_contig && aligned(W, 16) && ldw_n % 16 == 0 && act_vec_ok(A, lda, dtype))
         return w8_gemv(dtype, A, W, S, bias, C, M, N, K, ldw_n, lda, ldc, (flags & QL_FLAG_STRICT_ROUNDING) != 0, st);
     return w8_generic(dtype, A, W, S, bias, C, M, N, K, ldw_k, ldw_n, lda, ldc, st);

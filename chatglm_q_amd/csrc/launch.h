@@ -114,6 +114,13 @@ int w4_rows4_fused(int dtype, bool gate, const void* A, const void* packed, cons
 int w4_rows4_gated(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                    int64_t lda, int64_t ldc, hipStream_t st);                                   // w4_packed.hip: picks the K split
 
+// wq_gemm_f32.hip (round 5): fp32 activations, 128+ rows, on v_mfma_f32_32x32x2_f32 from the canonical buffers (int4g32 / int8 per channel)
+bool wq_gemm_f32_serves(int64_t M, int64_t N, int64_t K);
+int w4_gemm_f32(const void* A, const uint8_t* Wq, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                int64_t ldc, hipStream_t st);
+int w8_gemm_f32(const void* A, const int8_t* W, const void* S, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t ldw,
+                int64_t lda, int64_t ldc, hipStream_t st);
+
 // w4_tgemm.hip (backward: grad_A = grad_out . dequant(W)^T on the canonical layout; fp16 / bf16, MFMA)
 int w4_tgemm(int dtype, const void* A, const uint8_t* Wq, const void* S, void* C, int64_t M, int64_t Nout, int64_t Kc,
              int64_t lda, int64_t ldw, int64_t lds, int64_t ldc, hipStream_t st);

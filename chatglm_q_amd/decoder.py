@@ -163,11 +163,19 @@ class DecodeSession:
         self.mask.index_fill_(2, torch.clamp(self.write_index, max=self.capacity - 1), 0.0)
 
     def drop_canonical(self) -> int:
-        """Low-footprint mode: free the canonical buffers of every int4 module that can serve without them; returns the bytes freed."""
+        """Low-footprint mode: free the canonical buffers of every int4 module that can serve without them, and the plain copies of a
+        first MLP projection that its gate-interleaved copies have made redundant (the fused step and the gated prefill GEMM read the
+        gated part 1 / part 2; anything that asks for the plain ones again rebuilds them from what stays).  Returns the bytes freed."""
         freed = 0
         for m in self.model.modules():
-            if hasattr(m, "drop_canonical"):
-                freed += m.drop_canonical()
+            if not hasattr(m, "drop_canonical"):
+                continue
+            freed += m.drop_canonical()
+            nb = m.derived_nbytes()
+            parts = [plain for plain, gated in (("packed", "gated"), ("tiled", "gated_tiled")) if nb.get(plain) and nb.get(gated)]
+            if parts and m.canonical_dropped:
+                freed += sum(nb[k] for k in parts)
+                m.release(*parts)
         return freed
 
     def release_prefill_layouts(self) -> int:

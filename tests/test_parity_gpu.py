@@ -159,6 +159,11 @@ W4_SHAPES = [
     (6, 1056, 64, "f16", False),        # ... 33 groups
     (2, 64, 36, "f16", True),           # N % 8 != 0 -> generic kernel / packed padding
     (3, 96, 8, "f32", False),
+    (512, 4096, 4096, "f32", False),    # round 5: fp32 activations from 128 rows on run on the fp32 matrix instruction (wq_gemm_f32.hip)
+    (200, 1024, 264, "f32", True),      # ... ragged M and N, bias
+    (129, 96, 40, "f32", True),         # ... 3 K tiles, one partial column tile, one row past the threshold
+    (300, 2048, 1000, "f32", False),    # ... 128-row tiles stay under the block-slot rule: 64-row tiles
+    (1536, 1024, 4608, "f32", True),    # ... 128-row tiles (432 blocks)
 ]
 
 
@@ -360,6 +365,40 @@ def test_w8a8_lm_head_shape(M):
         assert torch.equal(got, want_bits)                          # the 256-tile kernel: bit for bit
 
 
+def test_fp32_many_rows_matrix_kernel_agrees_with_the_valu_kernels(monkeypatch):
+    """Round 5: fp32 activations with 128+ rows on v_mfma_f32_32x32x2_f32 (wq_gemm_f32.hip) against the VALU kernels that served them
+    before (QLINEAR_DISPATCH=nof32mfma) and the oracle: exact fp32 products and sums in another order - the reference's own bar,
+    atol = rtol = 1e-4 (tests/test_triton_ops_int4.py:20-22) - int4g32 and int8 per channel, incl. -128 and negative scales."""
+    lib = _lib.get_lib()
+    g = torch.Generator().manual_seed(91)
+    M, K, N = 384, 2048, 1160
+    a = torch.randn((M, K), generator=g)
+    qw = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8, generator=g)
+    sc = torch.rand((K // 32, N), generator=g) * 0.02 + 0.002
+    bias = torch.randn(N, generator=g) * 0.1
+    w8 = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g)
+    s8 = (torch.rand(N, generator=g) - 0.3) * 0.01
+
+    def both():
+        y4 = h4.w4_forward(a.to(DEV), qw.to(DEV), sc.to(DEV), bias.to(DEV))
+        y8 = h8.w8_forward(a.to(DEV), w8.to(DEV).t(), s8.to(DEV), bias.to(DEV))
+        return y4, y8
+
+    lib.qlinear_dispatch_reset()
+    y4, y8 = both()
+    try:
+        monkeypatch.setenv("QLINEAR_DISPATCH", "nof32mfma")
+        lib.qlinear_dispatch_reload()
+        v4, v8 = both()
+    finally:
+        monkeypatch.delenv("QLINEAR_DISPATCH")
+        lib.qlinear_dispatch_reload()
+    assert torch.allclose(y4, v4, atol=1e-4, rtol=1e-4) and torch.allclose(y8, v8, atol=1e-4, rtol=1e-4)
+    assert not torch.equal(y4, v4)                       # another kernel ran (another summation order)
+    assert_close(y4, O.w4_matmul(a.numpy(), qw.numpy(), sc.numpy(), bias.numpy(), dtype="f32"), "f32", "fp32 int4 matrix kernel")
+    assert_close(y8, O.w8_matmul(a.numpy(), np.ascontiguousarray(w8.numpy().T), s8.numpy(), bias.numpy(), dtype="f32"), "f32", "fp32 int8 matrix kernel")
+
+
 def test_int4_group_sizes_other_than_32():
     for group in (16, 64, 128):
         K, N, M = 256, 40, 3
@@ -472,6 +511,10 @@ W8_SHAPES = [
     (4096, 512, 2048, "bf16", True),    # ... bf16
     (70, 13696, 128, "bf16", True),     # bf16 MFMA
     (33, 400, 96, "bf16", False),
+    (512, 4096, 4096, "f32", False),    # round 5: fp32 activations from 128 rows on run on the fp32 matrix instruction (wq_gemm_f32.hip)
+    (200, 1024, 264, "f32", True),      # ... ragged M and N, bias
+    (1536, 1024, 4608, "f32", True),    # ... 128-row tiles
+    (40, 200, 96, "f32", False),        # K % 32 != 0: stays on the VALU kernel
 ]
 
 
