@@ -26,7 +26,7 @@ static unsigned parse_dispatch_env() {
     if (!e) return v;
     if (strstr(e, "no256")) v |= QL_D_NO256;
     if (strstr(e, "nopeel")) v |= QL_D_NOPEEL;
-    if (strstr(e, "nopersist")) v |= QL_D_NOPERSIST;
+    if (strstr(e, "nohalf")) v |= QL_D_NOHALF;
     if (strstr(e, "nof32mfma")) v |= QL_D_NOF32MFMA;
     if (strstr(e, "nofewrow")) v |= QL_D_NOFEWROW;
     if (strstr(e, "norows4")) v |= QL_D_NOROWS4;

@@ -22,9 +22,9 @@ inline int tune_env(const char* name, int dflt) {
 // QLINEAR_DISPATCH: comma-separated kernel families the dispatch must NOT use (every one has a slower fallback that computes
 // the same function): "no256" (256 x 256-tile GEMMs), "nopeel" (qkv_proj's second launch on the 128-row-tile kernel),
 // "nofewrow" (3..32-row kernels), "norows4" (4x4x4-MFMA kernel for 2..4 rows), "nogroupattn" (grouped MFMA decode attention),
-// "nopersist" (round 5: the persistent launch of the int4g32 256-tile GEMM and its half-tile last round; one tile per workgroup instead -
-// bit-equal outputs), "nof32mfma" (round 5: the fp32 matrix-instruction kernel for fp32 activations with 128+ rows; the VALU kernels instead).
-enum : unsigned { QL_D_NO256 = 1, QL_D_NOPEEL = 2, QL_D_NOFEWROW = 4, QL_D_NOROWS4 = 8, QL_D_NOGROUPATTN = 16, QL_D_NOPERSIST = 32,
+// "nohalf" (round 5: the half-tile last round of the int4g32 256-tile GEMM's launch; whole tiles only, the older peel where it applies -
+// the rows both serve are bit-equal), "nof32mfma" (round 5: the fp32 matrix-instruction kernel for fp32 activations with 128+ rows; the VALU kernels instead).
+enum : unsigned { QL_D_NO256 = 1, QL_D_NOPEEL = 2, QL_D_NOFEWROW = 4, QL_D_NOROWS4 = 8, QL_D_NOGROUPATTN = 16, QL_D_NOHALF = 32,
                   QL_D_NOF32MFMA = 64 };
 unsigned dispatch_flags();     // abi.hip: parsed once; qlinear_dispatch_reload() parses again (tests, A/B tools)
 

@@ -416,106 +416,100 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     g256_tile_body<T, W8, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
 }
 
-// ---- round 5: the same GEMM as ONE PERSISTENT launch -------------------------------------------------------------------------------
-// Why (profiles/r04_gemm_power.txt, LABNOTES 4c): per 256 x 256 tile the kernel above spends ~3.5 k shader cycles in its prologue (the
-// first operand tiles' round trip with nothing to hide it behind) and ~8.7 k in its epilogue (every CU writes its 128 KB at the same
-// moment: the rounds of a grid run in lockstep, 32 MB per burst) beside ~166 k of K loop at K = 4096 - and the vendor's dense kernel,
-// which runs one workgroup per CU over all of its tiles, does not.  Here:
-//   * grid = one workgroup per CU; workgroup b computes the tiles b, b + grid, b + 2 grid, ... of the SAME XCD-aware tile order (the
-//     id -> XCD relation of a 1-D grid is id mod 8 and grid % 8 == 0, so a workgroup's tiles keep its XCD's panel sharing);
-//   * the K loops of a workgroup's tiles are ONE stream of K tiles: the loads of the last iterations of a tile (two A tiles, three
-//     weight units ahead) already address the NEXT tile - where the kernel above re-requests its last K tile "past the end" to keep
-//     the queue counts fixed - so the next tile's first fragments are in registers when the epilogue starts: no prologue after
-//     the first tile, the queue never drains;
-//   * the epilogue's stores are fire-and-forget: they drain while the next tile's MFMAs run.  vmcnt retires in issue order, so
-//     the two K tiles behind an epilogue wait with the epilogue's store count added to their immediates (k_tile<.., NSW, NSA>: a
-//     wait for a load OLDER than the stores must not wait for them) - the count is the least a wave can issue, kG256PStores on a
-//     full tile (ragged tiles: 0, an over-wait); the barriers are raw s_barrier (a __syncthreads() would drain the compiler-visible
-//     stores with vmcnt(0));
-//   * the epilogue's row-chunk transposition has its own 16 KB of LDS behind the four operand buffers (144 KB in all): the A / B
-//     buffers hold the next tile by then.
-// Requires whole PAIRS of 64-deep K tiles (K % 128 == 0, K >= 1024: the buffer parity of a tile's first K tile is then fixed and
-// the three cursors - weights, activations, compute - change tile in that order without overtaking) and the 16-byte-chunk epilogue.
-constexpr int kG256PEpi = 8 * 2048;
-constexpr int kG256PLds = kG256Lds + kG256PEpi;
-constexpr int kG256PStores = 16;                   // vector-memory instructions one wave's epilogue issues on a FULL tile (8 sub-tiles x 2 row-chunk passes)
+// ---- round 5: the int4g32 tile body on v_mfma_f32_16x16x32 (what the product runs for int4g32; the 32x32x16 body above serves int8 weights) -----------
+// Why: the GEMM sits at the board's power cap (profiles/r05_g256_power_cap.txt), MFMA-only loops sustain 12 - 17 % more on the 16x16 shapes than
+// on 32x32 under that cap (1 KB of accumulators in and out per 16 K MACs instead of 4 KB per 32 K) and the vendor's dense kernel uses 16x16.
+// Round 4 tried the shape in a ring of 32-deep stages only (a barrier per 32 k); here the SHIPPED loop keeps everything else: two LDS buffers per
+// operand, one barrier per 64-deep K tile in front of its last quarter, the same LDS-DMA A image (its swizzle is conflict-free for the new
+// fragment reads too), the same one-unit-per-thread dequant.  What changes:
+//   * wave tile 128 x 64 = 8 x 4 tiles of 16 x 16 (128 accumulator registers as before); a K tile = 2 MFMA k-steps u (32 k = one int4 group);
+//     lane (c = lane & 15, kq = lane >> 4) holds k = 32 u + 8 kq .. + 7: word kq of group u - the unit's words in natural order;
+//   * B image: [16-column tile n16][step u][lane 16 kq + c]: the thread holding the unit of column j (of its wave's 32), group kb writes word s
+//     to tile 2 wave + (j >> 4), step kb, lane 16 s + (j & 15) - 256-byte runs per 16 lanes, conflict-free;
+//   * a K tile runs as four QUARTERS (u, h) of 16 MFMAs: m-tiles 4 h .. 4 h + 3 x the 4 n-tiles; per quarter 4 A fragment reads (+ the 4 B
+//     fragments of the next step in front of h = 0) - 24 ds_read_b128 per K tile as before, 64 MFMAs of 16 cycles instead of 32 of 32.
+// Output element K order differs from the 32x32 body (another contraction grouping): NOT bit-equal to it, same tolerance against the oracle.
+// Measured (profiles/r05_g256_mi16_ab.txt, one tile per workgroup, 8192 rows, interleaved A/B, qkv / o / w_in / w_out TFLOP/s): 16x16x32 886 - 966 /
+// 1 195 - 1 200 / 1 209 - 1 210 / 1 235 - 1 253 against 32x32x16 935 - 985 / 1 114 - 1 119 / 1 140 - 1 146 / 1 187 - 1 199: +7 / +6 / +4.5 % at the same 1 400 W.
+// MT = 4: the 256 x 256 tile; MT = 2: a 128-row half tile (wave tile 64 x 64; the persistent launch's last round) - same K order per element.
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<__bf16> {
+    static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
 
-__device__ __forceinline__ void lds_barrier() {    // this wave's LDS writes have landed, then the block barrier; no vmcnt
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <typename T, bool GATE = false>
-__global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
-                                                          int M, int N, int ksteps, int64_t lda, int nbx, int super_rows, int total,
-                                                          int flat_total, int tail_rem,
-                                                          const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
-                                                          const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+template <typename T, bool GATE, int MT, bool OPAQUE = false>
+__device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                 int M, int N, int ksteps, int64_t lda, int tile_x, int m0,
+                                                 const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                 const T* __restrict__ resid, int64_t ldr) {
+    static_assert(MT == 4 || MT == 2, "whole tile or half tile");
     typedef Mma<T> MM;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // A[2] | B[2] | epilogue scratch
-    const int tid = threadIdx.x, lane = tid & 63;
+    typedef Mma16<T> M16;
+    constexpr int MQ = MT;                             // 16-row tiles per quarter (a wave holds 2 MQ x 4 of them)
+    int tid = threadIdx.x;
+    if constexpr (OPAQUE) asm volatile("" : "+v"(tid));    // inside the persistent kernel's tile loop: an opaque thread id, so that nothing this body
+                                                            // derives from it is hoisted out of that loop and kept in registers across the K loops
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int j = lane & 31, kb = lane >> 5;
-    const unsigned grid = gridDim.x;
-    auto tile_of = [&](unsigned id) {
-        return super_rows ? xcd_tile_super(id, (unsigned)total, nbx, super_rows) : xcd_tile(id, (unsigned)total, nbx);
-    };
+    const int j = lane & 31, kb = lane >> 5;           // staging: column j of the wave's column tile, group kb of the K tile
+    const int c16 = lane & 15, kq = lane >> 4;         // MFMA: tile index, k quarter
+    const int n0 = tile_x * 256;
 
     u32 k_mask_lo, k_mask_hi, k_magic;
     asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
     asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
     asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
 
-    // ---- the three cursors.  Weights (3 K tiles ahead of the MFMAs), activations (2 ahead), compute. ------------------------------
     const int ctiles = (N + 31) >> 5;
+    const int ct_raw = tile_x * 8 + wave;
+    const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
+    const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
     const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
-    unsigned long long w_base, s_base;                 // of the weight cursor's tile: this wave's column tile
-    auto set_w = [&](int tx) {
-        const int ct_raw = tx * 8 + wave;
-        const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;      // clamped: loads stay in bounds, stores are masked
-        w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
-        s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
-    };
-    unsigned a_off[4];                                 // of the activation cursor's tile: lane -> (row, stored chunk position)
-    auto set_a = [&](int ty) {
+    unsigned a_off[MT];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int q = 64 * (4 * wave + n) + lane, r = q >> 3, cp = q & 7;
-            const int row = (ty * 256 + r < M) ? (ty * 256 + r) : (M - 1);
-            a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
-        }
-    };
-    TileXY tile = tile_of(blockIdx.x);                 // the compute cursor's tile
-    TileXY tile_nx = tile;                             // the tile the load cursors move / have moved to (valid while more = true)
-    unsigned id_nx = blockIdx.x + grid;
-    bool more = false;                                 // the weight cursor found another tile (latched for the other two)
-    int wk, ak;                                        // next K tile each load cursor requests
-    set_w(tile.x);
-    set_a(tile.y);
-
+    for (int n = 0; n < MT; ++n) {
+        const int q = 64 * (MT * wave + n) + lane, r = q >> 3, cp = q & 7;
+        const int row = (m0 + r < M) ? (m0 + r) : (M - 1);
+        a_off[n] = (unsigned)row * (unsigned)(lda * (int64_t)sizeof(T)) + (unsigned)((cp ^ ((r >> 1) & 7)) * 16);
+    }
     const unsigned long long a_base = sgpr64((unsigned long long)(uintptr_t)A);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)smem);
-    const unsigned a_dma = lds0 + (unsigned)(4 * wave) * 1024u;    // + buffer * kG256ABuf + n * 1024
+    const unsigned a_dma = lds0 + (unsigned)(MT * wave) * 1024u;
     char* b_lds = smem + 2 * kG256ABuf;
-    const int b_wr = ((wave * 4) * 64 + lane) * 16;                // + buffer * kG256BBuf + s * 1024
-    int a_rd[4];
+    const int b_wr = (((2 * wave + (j >> 4)) * 2 + kb) * 64 + (j & 15)) * 16;      // + buffer * kG256BBuf + s * 256 (word s -> lanes 16 s ..)
+    int a_rd[2];                                       // per step u: row 32 MT wr + c16 (+ 16 per m-tile), chunk 4 u + kq
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a_rd[s] = ((128 * wr + j) * 8 + ((4 * kb + s) ^ ((j >> 1) & 7))) * 16;
-    const int b_rd = ((2 * wc) * 4 * 64 + lane) * 16;              // + nt * 4096 + s * 1024
+    for (int u = 0; u < 2; ++u) a_rd[u] = ((32 * MT * wr + c16) * 8 + ((4 * u + kq) ^ ((c16 >> 1) & 7))) * 16;
+    const int b_rd = ((4 * wc) * 2 * 64 + lane) * 16;  // + nt * 2048 + u * 1024
 
-    f32x16 acc[4][2];
-    auto zero_acc = [&]() {
+    f32x4 acc[2 * MQ][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 2 * MQ; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-    };
-    zero_acc();
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     i32x4 wq[2];
     unsigned wsc[2];
+    auto issue_a = [&](int kt, int buf) {
+        const int k = kt < ksteps ? kt : ksteps - 1;
+        const unsigned long long base = sgpr64(a_base + (unsigned long long)k * 128ull);
+#pragma unroll
+        for (int n = 0; n < MT; ++n) glds16(a_dma + (unsigned)(buf * kG256ABuf + n * 1024), a_off[n], base);
+    };
+    auto issue_w = [&](int kt, int set) {
+        const int k = kt < ksteps ? kt : ksteps - 1;
+        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * 1024ull));
+        gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
+    };
     typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
     auto scale_of = [&](unsigned raw) {
         const uint16_t h = (uint16_t)raw;
@@ -525,157 +519,170 @@ __global__ __launch_bounds__(512) void w4_gemm256p_kernel(const T* __restrict__ 
     };
     auto dequant_store = [&](int set, int buf, int s, scale_t sc) {
         const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
-        *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 1024) = f;
+        *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 256) = f;
     };
-    u32x4 fa[2][4], fb[2][2];
-    auto read_frags = [&](int buf, int s, u32x4 (&xa)[4], u32x4 (&xb)[2]) {
+    // fragments: A double-buffered per quarter; B ONE set per step, refilled in place - the second quarter of a step runs its MFMAs n-tile by
+    // n-tile and requests the next step's fragment of an n-tile right behind that n-tile's last MFMA (16 registers instead of 32: with two sets
+    // the persistent kernel spilled)
+    u32x4 fa[2][MQ], fb[4];
+    auto read_a = [&](int buf, int qd, u32x4 (&xa)[MQ]) {
+        const int u = qd >> 1, h = qd & 1;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) xb[nt] = *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 4096 + s * 1024);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xa[mt] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + mt * 4096 + a_rd[s]);
+        for (int i = 0; i < MQ; ++i) xa[i] = *reinterpret_cast<const u32x4*>(smem + buf * kG256ABuf + (MQ * h + i) * 2048 + a_rd[u]);
     };
-    // the cursors' moves (wave-uniform): the weight cursor looks the next tile up, the others follow it one / four iterations later
-    auto advance_w = [&]() {
-        if (++wk < ksteps) return;
-        wk = 0;
-        more = id_nx < (unsigned)flat_total;
-        if (more) {
-            tile_nx = tile_of(id_nx);
-            id_nx += grid;
-            set_w(tile_nx.x);
-        }                                              // no tile left: this tile's first K tiles again (never read; the queue counts stay fixed)
-    };
-    auto advance_a = [&]() {
-        if (++ak < ksteps) return;
-        ak = 0;
-        if (more) set_a(tile_nx.y);
+    auto read_b1 = [&](int buf, int u, int nt) {
+        return *reinterpret_cast<const u32x4*>(b_lds + buf * kG256BBuf + b_rd + nt * 2048 + u * 1024);
     };
 
-    // ---- prologue of the FIRST tile: A(0), W(0), W(1) requested; W(0) dequantised into B[0]; then what every barrier is followed by ----
+    issue_a(0, 0);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    vm_wait_imm<2>(wq[0], wsc[0]);
     {
-        const unsigned long long b0 = sgpr64(a_base);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(n * 1024), a_off[n], b0);
-        gload16(wq[0], w_voff, w_base);
-        gload2(wsc[0], s_voff, s_base);
-        gload16(wq[1], w_voff, sgpr64(w_base + 1024ull));
-        gload2(wsc[1], s_voff, sgpr64(s_base + 64ull * sizeof(T)));
-        vm_wait_imm<2>(wq[0], wsc[0]);
         const scale_t sc = scale_of(wsc[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) dequant_store(0, 0, s, sc);
-        lds_barrier();
-        const unsigned long long b1 = sgpr64(a_base + 128ull);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) glds16(a_dma + (unsigned)(kG256ABuf + n * 1024), a_off[n], b1);
-        gload16(wq[0], w_voff, sgpr64(w_base + 2048ull));
-        gload2(wsc[0], s_voff, sgpr64(s_base + 128ull * sizeof(T)));
-        read_frags(0, 0, fa[0], fb[0]);
-        ak = 2;
-        wk = 3;
     }
+    __syncthreads();
+    issue_a(1, 1);
+    issue_w(2, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) fb[nt] = read_b1(0, 0, nt);
+    read_a(0, 0, fa[0]);
 
-    // ---- one K tile (w4_gemm256_kernel's, with the cursors in place of kt): NSW / NSA = the store instructions of an epilogue that
-    // stand between the awaited load and this wait ---------------------------------------------------------------------------------------
-    auto k_tile = [&](auto curc, auto nswc, auto nsac, auto lastc) {
-        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1, NSW = decltype(nswc)::value, NSA = decltype(nsac)::value;
-        constexpr bool LAST = decltype(lastc)::value != 0;   // a tile's last K tile: the next tile's first fragments are read BEHIND the epilogue (24 registers it needs)
-        vm_wait_imm<6 + NSW>(wq[nxt], wsc[nxt]);      // W(+1) has landed
+    auto k_tile = [&](int kt, auto curc) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+        vm_wait_imm<MT + 2>(wq[nxt], wsc[nxt]);        // W(kt + 1) has landed
         const scale_t sc = scale_of(wsc[nxt]);
-        static_for<3>([&](auto sc_) {
-            constexpr int s = decltype(sc_)::value;
-            read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        // quarters (u, 0): m-tile by m-tile on the step's B fragments; quarters (u, 1): n-tile by n-tile, each n-tile's fragment of the NEXT
+        // step requested behind its last MFMA
+        static_for<2>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            read_a(cur, 2 * u + 1, fa[1]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int i = 0; i < MQ; ++i)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[s & 1][mt]),
-                                          __builtin_bit_cast(typename MM::frag, fb[s & 1][nt]), acc[mt][nt]);
-            dequant_store(nxt, nxt, s, sc);
-            if constexpr (s == 2) dequant_store(nxt, nxt, 3, sc);
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                for (int nt = 0; nt < 4; ++nt) acc[i][nt] = M16::mma(fa[0][i], fb[nt], acc[i][nt]);
+            dequant_store(nxt, nxt, 2 * u, sc);
+            if constexpr (u == 1) dequant_store(nxt, nxt, 3, sc);
+            __builtin_amdgcn_sched_group_barrier(0x100, MQ, 0);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4 * MQ; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, s == 2 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (u == 1 ? 2 : 1) * (4 / MQ), 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x200, s == 2 ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, u == 1 ? 2 : 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (u == 0) {
+                read_a(cur, 2, fa[0]);
+                static_for<4>([&](auto ntc) {
+                    constexpr int nt = decltype(ntc)::value;
+#pragma unroll
+                    for (int i = 0; i < MQ; ++i) acc[MQ + i][nt] = M16::mma(fa[1][i], fb[nt], acc[MQ + i][nt]);
+                    fb[nt] = read_b1(cur, 1, nt);
+                    if constexpr (nt == 1) dequant_store(nxt, nxt, 1, sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         });
-        vm_wait_imm<2 + NSA>();                        // A(+1) has landed
-        lds_barrier();                                 // B(+1), A(+1) complete; the fragments of the last sub-step are in registers
-        if constexpr (!LAST) read_frags(nxt, 0, fa[0], fb[0]);
+        vm_wait_imm<2>();                              // A(kt + 1) has landed
+        __syncthreads();
+        read_a(nxt, 0, fa[0]);
         __builtin_amdgcn_sched_barrier(0);
         {
-            const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ak * 128ull);
-            const unsigned long long wb = sgpr64(w_base + (unsigned long long)wk * 1024ull);
-            const unsigned long long sb = sgpr64(s_base + (unsigned long long)wk * (64ull * sizeof(T)));
-            static_for<8>([&](auto qc) {
-                constexpr int q = decltype(qc)::value, mt = q >> 1, nt = q & 1;
-                acc[mt][nt] = MM::mma(__builtin_bit_cast(typename MM::frag, fa[1][mt]), __builtin_bit_cast(typename MM::frag, fb[1][nt]), acc[mt][nt]);
-                if constexpr (q < 4) glds16(a_dma + (unsigned)(cur * kG256ABuf + q * 1024), a_off[q], abase_k);
-                else if constexpr (q == 4) gload16(wq[nxt], w_voff, wb);
-                else if constexpr (q == 5) gload2(wsc[nxt], s_voff, sb);
+            const int ka = kt + 2 < ksteps ? kt + 2 : ksteps - 1, kw = kt + 3 < ksteps ? kt + 3 : ksteps - 1;
+            const unsigned long long abase_k = sgpr64(a_base + (unsigned long long)ka * 128ull);
+            static_for<4>([&](auto ntc) {              // quarter (1, 1): n-tile by n-tile; behind each: the next K tile's B fragment, requests
+                constexpr int nt = decltype(ntc)::value;
+#pragma unroll
+                for (int i = 0; i < MQ; ++i) acc[MQ + i][nt] = M16::mma(fa[1][i], fb[nt], acc[MQ + i][nt]);
+                fb[nt] = read_b1(nxt, 0, nt);
+                if constexpr (MT == 4) {
+                    if constexpr (nt < 2) {
+                        glds16(a_dma + (unsigned)(cur * kG256ABuf + (2 * nt) * 1024), a_off[2 * nt], abase_k);
+                        glds16(a_dma + (unsigned)(cur * kG256ABuf + (2 * nt + 1) * 1024), a_off[2 * nt + 1], abase_k);
+                    }
+                } else {
+                    if constexpr (nt < 2) glds16(a_dma + (unsigned)(cur * kG256ABuf + nt * 1024), a_off[nt], abase_k);
+                }
+                if constexpr (nt == 2) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * 1024ull));
+                if constexpr (nt == 3) gload2(wsc[nxt], s_voff, sgpr64(s_base + (unsigned long long)kw * (64ull * sizeof(T))));
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        advance_a();
-        advance_w();
     };
-    typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, kG256PStores> IS;
-
-    T* lds_wave = reinterpret_cast<T*>(smem + kG256Lds) + wave * 1024;
-    bool behind_stores = false;                        // the epilogue in front of this tile issued its kG256PStores stores for sure
-    for (;;) {
-        int kt = 2;
-        if (behind_stores) {
-            k_tile(I0{}, IS{}, IS{}, I0{});
-            k_tile(I1{}, IS{}, I0{}, I0{});
-            kt = 4;
-        }
-        for (; kt < ksteps; kt += 2) {
-            k_tile(I0{}, I0{}, I0{}, I0{});
-            k_tile(I1{}, I0{}, I0{}, I0{});
-        }
-        k_tile(I0{}, I0{}, I0{}, I0{});
-        k_tile(I1{}, I0{}, I0{}, I1{});
-        // ---- epilogue of `tile` (ql_common.h: rounded 32 x 32 sub-tiles through 2 KB of LDS per wave, 16-byte row chunks, non-temporal)
-        const int m0 = tile.y * 256, n0 = tile.x * 256;
-        const int mw = m0 + 128 * wr, nw = n0 + 64 * wc;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                if constexpr (GATE)
-                    store_tile_32x32_gated<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
-                else if (resid)
-                    store_tile_32x32_resid<T, 0, true>(lds_wave, C, ldc, resid, ldr, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
-                else
-                    store_tile_32x32<T, 0, true>(lds_wave, C, ldc, mw + mt * 32, nw + 32 * nt, M, N, bias, lane, [&](int i) { return acc[mt][nt][i]; });
-        if (!more) break;
-        behind_stores = m0 + 256 <= M && n0 + 256 <= N;
-        tile = tile_nx;
-        zero_acc();
-        read_frags(0, 0, fa[0], fb[0]);
+    int kt = 0;
+    for (; kt + 1 < ksteps; kt += 2) {
+        k_tile(kt, std::integral_constant<int, 0>{});
+        k_tile(kt + 1, std::integral_constant<int, 1>{});
     }
-    vm_wait_imm<0>(wq[0], wsc[0]);                     // the queue is empty before the registers go out of scope
+    if (kt < ksteps) k_tile(kt, std::integral_constant<int, 0>{});
+    vm_wait_imm<0>(wq[0], wsc[0]);
     vm_wait_imm<0>(wq[1], wsc[1]);
+    __syncthreads();
 
-    // ---- the ragged last round as HALF tiles: tail_rem tiles (ids flat_total ..) are left over after the whole rounds and would keep
-    // tail_rem of the grid's workgroups busy for a whole tile time; as 128-row halves they occupy twice as many for half of it (same K
-    // order per output element: bit-equal to the whole tile).  Unit of workgroup b: tile 8 (b / 16) + b % 8 - its id keeps b's XCD in
-    // the tile order - half (b / 8) % 2.  One tile body of its own (prologue, loop, epilogue): once per launch.
-    if (tail_rem > 0) {
-        const unsigned b = blockIdx.x;
-        const int t = (int)(((b >> 4) << 3) | (b & 7u)), half = (int)((b >> 3) & 1u);
-        if (t < tail_rem) {
-            __syncthreads();                           // every wave is past its last use of the operand buffers
-            const TileXY tl = tile_of((unsigned)(flat_total + t));
-            g256_tile_body<T, false, GATE, 2>(smem, A, Wt, Sp, M, N, ksteps, lda, tl.x, tl.y * 256 + 128 * half, bias, C, ldc, resid, ldr);
+    // ---- epilogue: 32 x 32 blocks of 2 x 2 tiles through the wave's 2 KB of LDS (ql_common.h, LAYOUT 1), 16-byte row chunks ----
+    const int mw = m0 + 32 * MT * wr, nw = n0 + 64 * wc;
+    if (!GATE && !((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
+        // rows of C that are not 16-byte aligned (ldc % 8 != 0): element by element from the accumulator layout - tile (mt, nt) register r is
+        // row 16 mt + 4 kq + r, column 16 nt + c16 (no residual here: that entry point requires aligned rows)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = nw + 16 * nt + c16;
+            if (n >= N) continue;
+            const T* bn = bias ? bias + n : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < 2 * MQ; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mw + 16 * mt + 4 * kq + r;
+                    if (m < M) store_out<T>(C + (int64_t)m * ldc + n, acc[mt][nt][r], bn);
+                }
         }
+        return;
     }
+    T* lds_wave = reinterpret_cast<T*>(smem) + wave * 1024;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MT; ++mb) {
+            auto val = [&](int i) { return acc[2 * mb + (i >> 3)][2 * nb + ((i >> 2) & 1)][i & 3]; };
+            if constexpr (GATE)
+                store_tile_32x32_gated<T, 1, true>(lds_wave, C, ldc, mw + mb * 32, nw + 32 * nb, M, N, bias, lane, val);
+            else if (resid)
+                store_tile_32x32_resid<T, 1, true>(lds_wave, C, ldc, resid, ldr, mw + mb * 32, nw + 32 * nb, M, N, bias, lane, val);
+            else
+                store_tile_32x32<T, 1, true>(lds_wave, C, ldc, mw + mb * 32, nw + 32 * nb, M, N, bias, lane, val);
+        }
+}
+
+// The int4g32 launch.  Workgroups 0 .. whole - 1 compute the tiles of that id in the XCD-aware order (`total` tiles in all).  The tiles
+// whole .. total - 1 - what is left over after the whole rounds of one workgroup per CU - run as HALF tiles on the workgroups behind:
+// 128 rows x 256 columns each, the same K order per output element (bit-equal to a whole tile), so that the last round keeps twice as
+// many CUs busy for half a tile time instead of a ragged round (or a second launch on the 128-row-tile kernel: the older peel).  Unit
+// u = id - whole: tile whole + 8 (u / 16) + u % 8 - its id keeps the workgroup's XCD (id % 8, whole % 8 == 0) in the tile order - half
+// (u / 8) % 2.  The hardware hands workgroups out in id order as CUs free up: the half tiles are the launch's last round by themselves.
+// History (LABNOTES 4d): a PERSISTENT form on the 32x32x16 body (one workgroup per CU walking its tiles as ONE stream of K tiles: no
+// prologue after the first tile, epilogue stores draining behind the next tile's MFMAs) measured +3 - 4 % on o_proj / w_in at the board's
+// power cap; the 16x16x32 body is worth +5 - 7 % by itself and needs 16 more fragment registers - around it the stream's two-tile state
+// no longer fitted 256 registers (hipcc spilled accumulators and registers with loads in flight), and what was left of the persistent
+// launch without the stream - the half-tile last round - needs no persistence.
+template <typename T, bool GATE = false>
+__global__ __launch_bounds__(512) void w4_gemm256x16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                            int M, int N, int ksteps, int64_t lda, int nbx, int super_rows, int total, int whole,
+                                                            const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
+                                                            const T* __restrict__ resid = nullptr, int64_t ldr = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < whole) {
+        const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, (unsigned)total, nbx, super_rows) : xcd_tile(blockIdx.x, (unsigned)total, nbx);
+        g256_tile_body16<T, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
+        return;
+    }
+    const unsigned u = blockIdx.x - (unsigned)whole;
+    const unsigned t = (unsigned)whole + (((u >> 4) << 3) | (u & 7u));
+    if (t >= (unsigned)total) return;
+    const TileXY tile = super_rows ? xcd_tile_super(t, (unsigned)total, nbx, super_rows) : xcd_tile(t, (unsigned)total, nbx);
+    g256_tile_body16<T, GATE, 2>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256 + 128 * (int)((u >> 3) & 1u), bias, C, ldc, resid, ldr);
 }
 
 // ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
@@ -1120,11 +1127,6 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const u32x4* Wt = (const u32x4*)tiled;
     const T* Sp = (const T*)((const char*)tiled + (L.off_sm - L.off_wm));
-    static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, false, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kG256Lds) == hipSuccess;
-    }();
-    (void)attr_set;
     const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
     const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);      // 32 blocks in flight per XCD: 8 columns x 4 rows share 12 operand panels
@@ -1139,31 +1141,37 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
         return finish_launch(QL_K_W4_GEMM256);
     }
 #endif
-    // one persistent workgroup per CU over all of its tiles (w4_gemm256p_kernel) whenever a workgroup gets more than one tile and the
-    // shape meets its rules: whole pairs of K tiles, the 16-byte-chunk epilogue
+    // int4g32: the 16x16x32 body, the tiles left over after the whole rounds as half tiles behind the whole ones (w4_gemm256x16_kernel); the
+    // developer build's QLINEAR_G256_MI16=0 selects the 32x32x16 body (A/B partner, profiles/r05_g256_mi16_ab.txt)
     const int total = nbx * nby, cus = cu_count();
-    const bool wide = GATE || ((ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && (!resid || ((ldr & 7) == 0 && ((uintptr_t)resid & 15) == 0)));
-    const int pgrid = QL_TUNE("QLINEAR_G256_PGRID", 0);             // developer build: a smaller persistent grid (tests: many tiles per workgroup at small shapes)
-    const int grid_p = pgrid > 0 ? pgrid : (cus & ~7);
-    if (QL_TUNE("QLINEAR_G256_PERSIST", 1) && !(dispatch_flags() & QL_D_NOPERSIST) && total > grid_p && grid_p >= 16 && K % 128 == 0 && K >= 1024 && wide) {
-        // the tiles left over after the whole rounds: as half tiles on twice as many workgroups when those exist (g256_tail_halves)
-        const int rem = total % grid_p;
-        const bool halves = QL_TUNE("QLINEAR_G256_TAIL", 1) && g256_tail_halves(rem, grid_p);
-        const int flat_total = halves ? total - rem : total, tail_rem = halves ? rem : 0;
-        static bool attr_p = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256p_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kG256PLds) == hipSuccess;
+    if (QL_TUNE("QLINEAR_G256_MI16", 1)) {
+        const int grid_p = QL_TUNE("QLINEAR_G256_PGRID", 0) > 0 ? QL_TUNE("QLINEAR_G256_PGRID", 0) : (cus & ~7);   // workgroups per round (developer build: tests)
+        const int rem = total > grid_p && grid_p >= 16 ? total % grid_p : 0;
+        const bool halves = QL_TUNE("QLINEAR_G256_TAIL", 1) && !(dispatch_flags() & QL_D_NOHALF) && g256_tail_halves(rem, grid_p);
+        const int whole = halves ? total - rem : total, units = halves ? 16 * ((rem + 7) / 8) : 0;
+        static bool attr16 = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256x16_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kG256Lds) == hipSuccess;
         }();
-        (void)attr_p;
-        w4_gemm256p_kernel<T, GATE><<<(unsigned)grid_p, 512, kG256PLds, st>>>(
+        (void)attr16;
+        w4_gemm256x16_kernel<T, GATE><<<(unsigned)(whole + units), 512, kG256Lds, st>>>(
             (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
-            super ? sy : 0, total, flat_total, tail_rem, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
+            super ? sy : 0, total, whole, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
         return finish_launch(QL_K_W4_GEMM256);
     }
+#ifdef QL_DEV_TUNING                                 // QLINEAR_G256_MI16=0: round 4's 32x32x16 body on the int4g32 weights (the product keeps that body for int8 weights only)
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, false, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kG256Lds) == hipSuccess;
+    }();
+    (void)attr_set;
     w4_gemm256_kernel<T, false, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
     return finish_launch(QL_K_W4_GEMM256);
+#else
+    return QL_ERR_UNSUPPORTED;                         // unreachable: the product's QLINEAR_G256_MI16 is the constant 1
+#endif
 }
 
 template <typename T, bool GATE = false>
@@ -1237,13 +1245,13 @@ bool w4_gemm256_supported(int64_t M, int64_t N, int64_t K, int64_t lda, const vo
     return blocks >= cus && blocks * 10 >= rounds * cus * 7;
 }
 
-// int4g32: whether the persistent launch serves `blocks` tiles with its left-over tiles as in-kernel half tiles (then nothing is peeled off
-// to the 128-row-tile kernel: w4_gemm.hip, w4_gemm256_rows)
+// int4g32: whether the launch runs the tiles left over after the whole rounds as half tiles of its own (then nothing is peeled off to the
+// 128-row-tile kernel: w4_gemm.hip, w4_gemm256_rows)
 bool w4_gemm256_tail_in_kernel(int64_t blocks, int64_t K) {
     const int grid = cu_count() & ~7;
-    return QL_TUNE("QLINEAR_G256_PERSIST", 1) && !(dispatch_flags() & QL_D_NOPERSIST) && QL_TUNE("QLINEAR_G256_TAIL", 1) &&
-           QL_TUNE("QLINEAR_G256_PGRID", 0) == 0 && grid >= 16 &&
-           blocks > grid && K % 128 == 0 && K >= 1024 && g256_tail_halves((int)(blocks % grid), grid);
+    (void)K;
+    return QL_TUNE("QLINEAR_G256_MI16", 1) && !(dispatch_flags() & QL_D_NOHALF) && QL_TUNE("QLINEAR_G256_TAIL", 1) &&
+           QL_TUNE("QLINEAR_G256_PGRID", 0) == 0 && grid >= 16 && blocks > grid && g256_tail_halves((int)(blocks % grid), grid);
 }
 
 // what the kernel itself needs (the dispatch heuristic above is a speed choice on top of this)

@@ -115,12 +115,12 @@ uint64_t qlinear_last_dispatch(void);
 void qlinear_dispatch_reset(void);
 void qlinear_dispatch_reload(void);   /* parse QLINEAR_DISPATCH again (it is read once, at the first dispatch decision) */
 /* The parsed QLINEAR_DISPATCH switches as the library holds them (bit 0 no256, 1 nopeel, 2 nofewrow, 3 norows4, 4 nogroupattn,
- * 5 nopersist, 6 nof32mfma): a host that sizes a workspace or picks an entry point by one of them asks here instead of parsing the variable again. */
+ * 5 nohalf, 6 nof32mfma): a host that sizes a workspace or picks an entry point by one of them asks here instead of parsing the variable again. */
 unsigned qlinear_dispatch_flags(void);
 
 /* Environment variables read by THIS library (chatglm_q_amd/csrc/tune.h): exactly one,
  *   QLINEAR_DISPATCH = comma list of kernel families the dispatch must not use: no256, nopeel, nofewrow, norows4, nogroupattn,
- *   nopersist (the persistent launch of the int4g32 256-tile GEMM and its half-tile last round: one tile per workgroup instead),
+ *   nohalf (the half-tile last round inside the int4g32 256-tile GEMM's launch: whole tiles only, the older peel where it applies),
  *   nof32mfma (the fp32 matrix-instruction kernel that serves fp32 activations from 128 rows on: the VALU kernels instead)
  * (every family has a slower fallback computing the same function; for A/B measurements and triage).  The host package reads
  * QLINEAR_LIB_PATH (another build of this library) and QLINEAR_STRICT (0 / 1 / auto: the per-weight rounding policy, see

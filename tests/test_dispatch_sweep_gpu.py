@@ -270,30 +270,43 @@ def test_dispatch_boundaries_bf16(bits):
     assert ((K_W4_GEMM256,) if bits == 4 else (K_W8_GEMM256,)) in seen
 
 
-def test_last_round_half_tiles_replace_the_peel_where_the_persistent_launch_runs():
-    """Round 5: the persistent 256-tile launch runs a last round that fills at most half the chip as in-kernel half tiles (K % 128 == 0,
-    K >= 1024: every ChatGLM2-6B layer shape), so the dispatch table no longer peels there - one launch, one summation order for all
-    rows.  The older peel (last row tiles on the 128-row-tile kernel) still serves the K the persistent launch does not take."""
+def test_last_round_half_tiles_replace_the_peel(monkeypatch):
+    """Round 5: the int4g32 256-tile launch runs a last round that fills at most half the chip as half tiles of its own, so the dispatch
+    table no longer peels - one launch, one summation order for all rows (any K: 64 and 65 K tiles here).  QLINEAR_DISPATCH=nohalf brings
+    the older peel back (last row tiles on the 128-row-tile kernel)."""
+    lib = _lib.get_lib()
     M, N = 8192, 4608                                       # 576 tiles of 256 x 256 = 2.25 rounds of 256 workgroups
-    fam, first = table(4, M, N, 4096)
-    assert fam == K_W4_GEMM256 and first == M               # no peel: qkv_proj at config 5's row count is ONE launch
-    fam, first = table(4, M, N, 4160)                       # 65 K tiles: an odd count, not the persistent launch's
-    assert fam == K_W4_GEMM256 and 0 < first < M
     g = torch.Generator().manual_seed(77)
-    for K, want in ((4096, [K_W4_GEMM256]), (4160, [K_W4_GEMM256, K_W4_GEMM128])):
+    for K in (4096, 4160):
+        fam, first = table(4, M, N, K)
+        assert fam == K_W4_GEMM256 and first == M           # no peel: qkv_proj at config 5's row count is ONE launch
         qw = torch.randint(0, 256, (K // 2, N), dtype=torch.uint8, generator=g)
         sc = (torch.rand((K // 32, N), generator=g) * 0.02 + 0.002).half()
         mod = q4.DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16)
         mod.apply_weights_(qw, sc, None)
         mod = mod.to(DEV)
         x = torch.randn((M, K), generator=g).half()
-        _lib.get_lib().qlinear_dispatch_reset()
+        lib.qlinear_dispatch_reset()
         with torch.no_grad():
             y = mod(x.to(DEV))
-        assert families() == want, (K, families())
+        assert families() == [K_W4_GEMM256], (K, families())
         rows = torch.tensor([0, 255, 4095, 7167, 7168, 7295, 7296, 7423, 7424, 8191])     # both halves of the last round's tiles
         ref = O.w4_matmul(t2n(x[rows]), qw.numpy(), t2n(sc), None, dtype="f16")
         assert O.rel_l2(t2n(y[rows.to(DEV)]), ref) <= 1.5e-4
+        try:
+            monkeypatch.setenv("QLINEAR_DISPATCH", "nohalf")
+            lib.qlinear_dispatch_reload()
+            fam, first = table(4, M, N, K)
+            assert fam == K_W4_GEMM256 and 0 < first < M
+            lib.qlinear_dispatch_reset()
+            with torch.no_grad():
+                y2 = mod(x.to(DEV))
+            assert families() == [K_W4_GEMM256, K_W4_GEMM128]
+            assert torch.equal(y2[:first], y[:first])       # the rows whole tiles serve in both: the same bits
+            assert O.rel_l2(t2n(y2[rows.to(DEV)]), ref) <= 1.5e-4
+        finally:
+            monkeypatch.delenv("QLINEAR_DISPATCH")
+            lib.qlinear_dispatch_reload()
 
 
 def test_dispatch_override_switches_families(monkeypatch):

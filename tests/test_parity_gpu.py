@@ -224,13 +224,12 @@ def test_int4_gemm256_vs_oracle(M, K, N, dt, has_bias):
 
 
 @pytest.mark.parametrize("M,K,N,kind", [(8192, 4096, 4096, "plain"), (8192, 4096, 4608, "bias"), (8192, 4096, 4096, "residual"),
-                                         (4096, 4096, 27392, "gated"), (8100, 1024, 4600, "plain"), (8192, 13696, 4096, "plain")])
-def test_int4_persistent_launch_equals_one_tile_per_workgroup(M, K, N, kind, monkeypatch):
-    """Round 5: the 256-tile GEMM as ONE persistent launch (w4_gemm256p_kernel: a workgroup per CU walks its tiles as one stream of K
-    tiles; a last round that fills at most half the chip runs as 128-row half tiles) against the one-tile-per-workgroup launch
-    (QLINEAR_DISPATCH=nopersist): bit for bit - every output element keeps its K order.  2 rounds (o_proj), 2.25 rounds with a half-tile
-    tail (qkv_proj, bias), the residual and SiLU * gate epilogues (w_in at 4096 rows: 1 712 tiles = 6.69 rounds), ragged M and N,
-    K = 13696 (214 K tiles)."""
+                                         (4096, 4096, 27392, "gated"), (8192, 4096, 27392, "gated"), (8100, 1024, 4600, "plain"), (8192, 13696, 4096, "plain")])
+def test_int4_half_tile_last_round_equals_whole_tiles(M, K, N, kind, monkeypatch):
+    """Round 5: the int4g32 256-tile launch (w4_gemm256x16_kernel, 16x16x32 MFMA body) runs the tiles left over after the whole rounds of
+    one workgroup per CU as 128-row HALF tiles behind the whole ones; against whole tiles only (QLINEAR_DISPATCH=nohalf): bit for bit -
+    every output element keeps its K order.  2 rounds (o_proj: no tail), 2.25 rounds (qkv_proj, bias: 64 tiles -> 128 half tiles), the
+    residual and SiLU * gate epilogues (w_in at 4096 rows: 1 712 tiles = 6.69 rounds -> no halves, 176 > 128), ragged M and N, K = 13696."""
     lib = _lib.get_lib()
     qw, sc = _rand_w4(K, N, "f16", seed=K * 5 + N)
     g = torch.Generator().manual_seed(M + 3)
@@ -249,7 +248,7 @@ def test_int4_persistent_launch_equals_one_tile_per_workgroup(M, K, N, kind, mon
     got = run()
     assert got is not None
     try:
-        monkeypatch.setenv("QLINEAR_DISPATCH", "nopersist")
+        monkeypatch.setenv("QLINEAR_DISPATCH", "nohalf")
         lib.qlinear_dispatch_reload()
         want = run()
     finally:

@@ -1,7 +1,8 @@
-"""Developer tool (round 5): the persistent 256-tile int4 GEMM (w4_gemm256p_kernel) against the one-tile-per-workgroup kernel, bit for bit.
+"""Developer tool (round 5): the int4g32 256-tile launch with its half-tile last round (small rounds: QLINEAR_G256_PGRID) against whole tiles
+only, bit for bit; also used across MFMA bodies (QLINEAR_G256_MI16=0 / 1: close, not equal).
 
-  QLINEAR_LIB_PATH=chatglm_q_amd/csrc/libqlinear_hip_dev.so QLINEAR_GEMM_256_MIN_BLOCKS=1 QLINEAR_G256_PERSIST=0 python tools/g256p_check.py save
-  ... QLINEAR_G256_PERSIST=1 QLINEAR_G256_PGRID=8 python tools/g256p_check.py check
+  QLINEAR_LIB_PATH=chatglm_q_amd/csrc/libqlinear_hip_dev.so QLINEAR_GEMM_256_MIN_BLOCKS=1 QLINEAR_G256_TAIL=0 python tools/g256p_check.py save
+  ... QLINEAR_G256_PGRID=16 python tools/g256p_check.py check
 
 (the knobs are read once per process: two runs)."""
 import os
@@ -55,7 +56,8 @@ else:
         same = torch.equal(ref[i], out[i])
         fin = bool(torch.isfinite(out[i].float()).all())
         nd = int((ref[i] != out[i]).sum())
-        print(("OK  " if same else "DIFF"), c[:4], str(c[4]).split(".")[-1], "finite" if fin else "NONFINITE", "mismatches", nd, flush=True)
+        rel = float((ref[i].float() - out[i].float()).norm() / ref[i].float().norm())
+        print(("OK  " if same else "DIFF"), c[:4], str(c[4]).split(".")[-1], "finite" if fin else "NONFINITE", "mismatches", nd, f"rel-L2 {rel:.2e}", flush=True)
         bad += 0 if same else 1
     print("RESULT", "all bit-equal" if bad == 0 else f"{bad} cases differ")
     sys.exit(1 if bad else 0)
