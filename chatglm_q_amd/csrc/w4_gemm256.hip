@@ -431,7 +431,9 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
 // Output element K order differs from the 32x32 body (another contraction grouping): NOT bit-equal to it, same tolerance against the oracle.
 // Measured (profiles/r05_g256_mi16_ab.txt, one tile per workgroup, 8192 rows, interleaved A/B, qkv / o / w_in / w_out TFLOP/s): 16x16x32 886 - 966 /
 // 1 195 - 1 200 / 1 209 - 1 210 / 1 235 - 1 253 against 32x32x16 935 - 985 / 1 114 - 1 119 / 1 140 - 1 146 / 1 187 - 1 199: +7 / +6 / +4.5 % at the same 1 400 W.
-// MT = 4: the 256 x 256 tile; MT = 2: a 128-row half tile (wave tile 64 x 64; the persistent launch's last round) - same K order per element.
+// MT = 4: the 256 x 256 tile; MT = 2: a 128-row half tile (wave tile 64 x 64: the launch's last round) - same K order per output element: bit-equal
+// to the whole tile.  (Quarter tiles - 64 rows, four units per left-over tile - were built and measured: qkv_proj 309 - 312 us against 300 - 320 with
+// halves, profiles/r05_g256_ab.txt: no gain, removed.)
 template <typename T> struct Mma16;
 template <> struct Mma16<f16> {
     static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
@@ -449,7 +451,7 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
                                                  int M, int N, int ksteps, int64_t lda, int tile_x, int m0,
                                                  const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
                                                  const T* __restrict__ resid, int64_t ldr) {
-    static_assert(MT == 4 || MT == 2, "whole tile or half tile");
+    static_assert(MT == 4 || MT == 2, "whole or half tile");
     typedef Mma<T> MM;
     typedef Mma16<T> M16;
     constexpr int MQ = MT;                             // 16-row tiles per quarter (a wave holds 2 MQ x 4 of them)

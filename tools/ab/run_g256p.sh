@@ -5,7 +5,7 @@ export QLINEAR_LIB_PATH=chatglm_q_amd/csrc/libqlinear_hip_dev.so
 mkdir -p gpurun_out
 {
 QLINEAR_GEMM_256_MIN_BLOCKS=1 QLINEAR_G256_TAIL=0 timeout 300 python tools/g256p_check.py save
-for g in 16 24 40 64; do
+for g in 16 24 40 64 128; do
   echo "== PGRID $g"; QLINEAR_GEMM_256_MIN_BLOCKS=1 QLINEAR_G256_PGRID=$g timeout 300 python tools/g256p_check.py check
 done
 for i in 1 2 3; do
