@@ -1,6 +1,6 @@
 // int4g32 GEMM for MANY activation rows (prefill: BASELINE config 5) on 256 x 256 output tiles, gfx950 - round 3.
 //
-//   C[M,N] = A[M,K] . dequant(W)      fp16 / bf16 activations, fp32 accumulation on v_mfma_f32_32x32x16_{f16,bf16}
+//   C[M,N] = A[M,K] . dequant(W)      fp16 / bf16 activations, fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16} (round 3 - 4: 32x32x16)
 //   (the reference's contraction, chatglm_q/int4/triton_ops.py:66-80: every weight dequantised to (n - 8) * s ROUNDED to the
 //   activation dtype before the dot, :72-73)
 //
@@ -100,13 +100,9 @@ __device__ __forceinline__ u32x4 w8_dequant_natural(u32 w0, u32 w1, float s) {
     }
 }
 
-// W8 = false: int4g32, Wt / Sp = part 2 of the derived layout (units + scales, [column tile][K tile][lane]).
-// W8 = true: int8 per channel, Wt = the tile-major copy ([column tile][K tile][half][lane][16 B]: two units per lane and K tile), Sp = S[n].
-// GATE: the weight copy is gate-interleaved (a first MLP projection) and the epilogue applies SiLU * gate: C has N / 2 columns.
-// MT: 32-row MFMA tiles per wave (round 5).  MT = 4: the 256 x 256 block tile.  MT = 2: a HALF tile, 128 rows x 256 columns (8 waves as
-// 2 x 4, wave tile 64 x 64) - the persistent kernel's tail units (w4_gemm256p_kernel): same K order per output element, so a half
-// tile's outputs are bit-equal to the whole tile's.
-// One output tile, rows m0 .. m0 + 64 MT - 1 x columns 256 tile_x ..: prologue, K loop, epilogue (block-wide; smem: kG256Lds bytes).
+#ifdef QL_DEV_TUNING
+// ---- round 3 / 4: the tile body on v_mfma_f32_32x32x16 - developer library only since round 5 (QLINEAR_G256_MI16=0: the A/B partner of the
+// 16x16x32 body below, profiles/r05_g256_ab.txt, r05_w8_mi16_ab.txt); template parameters as for g256_tile_body16 -------------------------------
 template <typename T, bool W8, bool GATE, int MT>
 __device__ __forceinline__ void g256_tile_body(char* smem, const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                int M, int N, int ksteps, int64_t lda, int tile_x, int m0,
@@ -416,7 +412,15 @@ __global__ __launch_bounds__(512) void w4_gemm256_kernel(const T* __restrict__ A
     g256_tile_body<T, W8, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
 }
 
-// ---- round 5: the int4g32 tile body on v_mfma_f32_16x16x32 (what the product runs for int4g32; the 32x32x16 body above serves int8 weights) -----------
+#endif   // QL_DEV_TUNING
+
+// ---- round 5: the tile body on v_mfma_f32_16x16x32 (what the product runs, int4g32 and int8 per-channel weights) ---------------------------------
+// W8 = false: int4g32, Wt / Sp = part 2 of the derived layout (units + scales, [column tile][K tile][lane]).
+// W8 = true: int8 per channel, Wt = the tile-major copy ([column tile][K tile][half][lane][16 B]: two units per lane and K tile), Sp = S[n].
+// GATE: the weight copy is gate-interleaved (a first MLP projection) and the epilogue applies SiLU * gate: C has N / 2 columns.
+// MT = 4: the 256 x 256 block tile.  MT = 2: a HALF tile, 128 rows x 256 columns (8 waves as 2 x 4, wave tile 64 x 64) - the launch's last
+// round: same K order per output element, so a half tile's outputs are bit-equal to the whole tile's.
+// One output tile, rows m0 .. m0 + 64 MT - 1 x columns 256 tile_x ..: prologue, K loop, epilogue (block-wide; smem: kG256Lds bytes).
 // Why: the GEMM sits at the board's power cap (profiles/r05_g256_power_cap.txt), MFMA-only loops sustain 12 - 17 % more on the 16x16 shapes than
 // on 32x32 under that cap (1 KB of accumulators in and out per 16 K MACs instead of 4 KB per 32 K) and the vendor's dense kernel uses 16x16.
 // Round 4 tried the shape in a ring of 32-deep stages only (a barrier per 32 k); here the SHIPPED loop keeps everything else: two LDS buffers per
@@ -446,7 +450,7 @@ template <> struct Mma16<__bf16> {
     }
 };
 
-template <typename T, bool GATE, int MT, bool OPAQUE = false>
+template <typename T, bool W8, bool GATE, int MT>
 __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                  int M, int N, int ksteps, int64_t lda, int tile_x, int m0,
                                                  const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
@@ -455,10 +459,7 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
     typedef Mma<T> MM;
     typedef Mma16<T> M16;
     constexpr int MQ = MT;                             // 16-row tiles per quarter (a wave holds 2 MQ x 4 of them)
-    int tid = threadIdx.x;
-    if constexpr (OPAQUE) asm volatile("" : "+v"(tid));    // inside the persistent kernel's tile loop: an opaque thread id, so that nothing this body
-                                                            // derives from it is hoisted out of that loop and kept in registers across the K loops
-    const int lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int j = lane & 31, kb = lane >> 5;           // staging: column j of the wave's column tile, group kb of the K tile
@@ -473,8 +474,12 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile_x * 8 + wave;
     const int ct = ct_raw < ctiles ? ct_raw : ctiles - 1;
-    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * 1024ull);
+    // W8 (int8 per channel, the tile-major copy of qlinear_w8_tile: two 16-byte units per lane and K tile = the channel's 32 consecutive k of group
+    // kb, in natural order like the int4 unit's words): Sp = S[n], the lane's channel scale; the second unit takes the scale's place in the queue
+    constexpr unsigned long long kWTile = W8 ? 2048ull : 1024ull;
+    const unsigned long long w_base = sgpr64((unsigned long long)(uintptr_t)Wt + (unsigned long long)ct * (unsigned long long)ksteps * kWTile);
     const unsigned long long s_base = sgpr64((unsigned long long)(uintptr_t)Sp + (unsigned long long)ct * (unsigned long long)ksteps * (64ull * sizeof(T)));
+    const float sc8 = W8 ? Act<T>::load(Sp + (32 * ct + j < N ? 32 * ct + j : N - 1)) : 0.f;
     const unsigned w_voff = (unsigned)lane * 16u, s_voff = (unsigned)lane * (unsigned)sizeof(T);
     unsigned a_off[MT];
 #pragma unroll
@@ -500,7 +505,7 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     i32x4 wq[2];
-    unsigned wsc[2];
+    std::conditional_t<W8, i32x4, unsigned> wsc[2];    // int4: the unit's scale; int8: the lane's second unit
     auto issue_a = [&](int kt, int buf) {
         const int k = kt < ksteps ? kt : ksteps - 1;
         const unsigned long long base = sgpr64(a_base + (unsigned long long)k * 128ull);
@@ -509,18 +514,28 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
     };
     auto issue_w = [&](int kt, int set) {
         const int k = kt < ksteps ? kt : ksteps - 1;
-        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * 1024ull));
-        gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
+        gload16(wq[set], w_voff, sgpr64(w_base + (unsigned long long)k * kWTile));
+        if constexpr (W8) gload16(wsc[set], w_voff, sgpr64(w_base + (unsigned long long)k * kWTile + 1024ull));
+        else gload2(wsc[set], s_voff, sgpr64(s_base + (unsigned long long)k * (64ull * sizeof(T))));
     };
     typedef decltype(MM::scale_pair((const T*)nullptr, true)) scale_t;
-    auto scale_of = [&](unsigned raw) {
-        const uint16_t h = (uint16_t)raw;
-        T sv;
-        __builtin_memcpy(&sv, &h, 2);
-        return MM::scale_pair(&sv, true);
+    auto scale_of = [&](auto raw) {
+        if constexpr (W8) return MM::scale_pair((const T*)nullptr, false);          // unused: the channel scale is sc8
+        else {
+            const uint16_t h = (uint16_t)raw;
+            T sv;
+            __builtin_memcpy(&sv, &h, 2);
+            return MM::scale_pair(&sv, true);
+        }
     };
-    auto dequant_store = [&](int set, int buf, int s, scale_t sc) {
-        const u32x4 f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+    auto dequant_store = [&](int set, int buf, int s, scale_t sc) {     // word s (8 k) of the lane's 32 -> lanes 16 s .. of the step's B image
+        u32x4 f;
+        if constexpr (W8) {
+            const i32x4& unit = (s >> 1) ? wsc[set] : wq[set];
+            f = w8_dequant_natural<T>((u32)unit[2 * (s & 1)], (u32)unit[2 * (s & 1) + 1], sc8);
+        } else {
+            f = __builtin_bit_cast(u32x4, MM::dequant((u32)wq[set][s], k_mask_lo, k_mask_hi, k_magic, sc));
+        }
         *reinterpret_cast<u32x4*>(b_lds + buf * kG256BBuf + b_wr + s * 256) = f;
     };
     // fragments: A double-buffered per quarter; B ONE set per step, refilled in place - the second quarter of a step runs its MFMAs n-tile by
@@ -607,8 +622,11 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
                 } else {
                     if constexpr (nt < 2) glds16(a_dma + (unsigned)(cur * kG256ABuf + nt * 1024), a_off[nt], abase_k);
                 }
-                if constexpr (nt == 2) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * 1024ull));
-                if constexpr (nt == 3) gload2(wsc[nxt], s_voff, sgpr64(s_base + (unsigned long long)kw * (64ull * sizeof(T))));
+                if constexpr (nt == 2) gload16(wq[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile));
+                if constexpr (nt == 3) {
+                    if constexpr (W8) gload16(wsc[nxt], w_voff, sgpr64(w_base + (unsigned long long)kw * kWTile + 1024ull));
+                    else gload2(wsc[nxt], s_voff, sgpr64(s_base + (unsigned long long)kw * (64ull * sizeof(T))));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -658,7 +676,7 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
         }
 }
 
-// The int4g32 launch.  Workgroups 0 .. whole - 1 compute the tiles of that id in the XCD-aware order (`total` tiles in all).  The tiles
+// The launch (int4g32 and int8 weights).  Workgroups 0 .. whole - 1 compute the tiles of that id in the XCD-aware order (`total` tiles in all).  The tiles
 // whole .. total - 1 - what is left over after the whole rounds of one workgroup per CU - run as HALF tiles on the workgroups behind:
 // 128 rows x 256 columns each, the same K order per output element (bit-equal to a whole tile), so that the last round keeps twice as
 // many CUs busy for half a tile time instead of a ragged round (or a second launch on the 128-row-tile kernel: the older peel).  Unit
@@ -669,7 +687,7 @@ __device__ __forceinline__ void g256_tile_body16(char* smem, const T* __restrict
 // power cap; the 16x16x32 body is worth +5 - 7 % by itself and needs 16 more fragment registers - around it the stream's two-tile state
 // no longer fitted 256 registers (hipcc spilled accumulators and registers with loads in flight), and what was left of the persistent
 // launch without the stream - the half-tile last round - needs no persistence.
-template <typename T, bool GATE = false>
+template <typename T, bool W8 = false, bool GATE = false>
 __global__ __launch_bounds__(512) void w4_gemm256x16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                             int M, int N, int ksteps, int64_t lda, int nbx, int super_rows, int total, int whole,
                                                             const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
@@ -677,14 +695,14 @@ __global__ __launch_bounds__(512) void w4_gemm256x16_kernel(const T* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < whole) {
         const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, (unsigned)total, nbx, super_rows) : xcd_tile(blockIdx.x, (unsigned)total, nbx);
-        g256_tile_body16<T, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
+        g256_tile_body16<T, W8, GATE, 4>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256, bias, C, ldc, resid, ldr);
         return;
     }
     const unsigned u = blockIdx.x - (unsigned)whole;
     const unsigned t = (unsigned)whole + (((u >> 4) << 3) | (u & 7u));
     if (t >= (unsigned)total) return;
     const TileXY tile = super_rows ? xcd_tile_super(t, (unsigned)total, nbx, super_rows) : xcd_tile(t, (unsigned)total, nbx);
-    g256_tile_body16<T, GATE, 2>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256 + 128 * (int)((u >> 3) & 1u), bias, C, ldc, resid, ldr);
+    g256_tile_body16<T, W8, GATE, 2>(smem, A, Wt, Sp, M, N, ksteps, lda, tile.x, tile.y * 256 + 128 * (int)((u >> 3) & 1u), bias, C, ldc, resid, ldr);
 }
 
 // ---- round 4 EXPERIMENT (developer library only, -DQL_DEV_TUNING; QLINEAR_G256_RING=1 selects it): the structure that took the int8 x
@@ -1120,8 +1138,27 @@ static void launch_r4(unsigned grid, hipStream_t st, const T* A, const u32x4* Wt
 
 #endif  // QL_DEV_TUNING
 
-// whether `rem` left-over tiles of a persistent grid run as half tiles: every unit 16 (t / 8) + (t % 8) + 8 half must be a workgroup
+// whether `rem` left-over tiles of a round of `grid` workgroups run as half tiles: every unit 16 (t / 8) + (t % 8) + 8 half must fit a round
 static inline bool g256_tail_halves(int rem, int grid) { return rem > 0 && 16 * ((rem + 7) / 8) <= grid; }
+
+// the 16x16x32 launch of both weight formats: whole tiles, then the left-over tiles as half tiles (w4_gemm256x16_kernel)
+template <typename T, bool W8, bool GATE>
+static int launch_x16(const T* A, const u32x4* Wt, const T* Sp, int M, int N, int ksteps, int64_t lda, int nbx, int nby, int order, int sy,
+                      const T* bias, T* C, int64_t ldc, const T* resid, int64_t ldr, hipStream_t st) {
+    const int total = nbx * nby, cus = cu_count();
+    const int grid_p = QL_TUNE("QLINEAR_G256_PGRID", 0) > 0 ? QL_TUNE("QLINEAR_G256_PGRID", 0) : (cus & ~7);   // workgroups per round (developer build: tests)
+    const int rem = total > grid_p && grid_p >= 16 ? total % grid_p : 0;
+    const bool halves = QL_TUNE("QLINEAR_G256_TAIL", 1) && !(dispatch_flags() & QL_D_NOHALF) && g256_tail_halves(rem, grid_p);
+    const int whole = halves ? total - rem : total, units = halves ? 16 * ((rem + 7) / 8) : 0;
+    static bool attr16 = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256x16_kernel<T, W8, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kG256Lds) == hipSuccess;
+    }();
+    (void)attr16;
+    w4_gemm256x16_kernel<T, W8, GATE><<<(unsigned)(whole + units), 512, kG256Lds, st>>>(A, Wt, Sp, M, N, ksteps, lda, order, sy, total, whole, bias, C, ldc,
+                                                                                         resid, ldr);
+    return finish_launch(W8 ? QL_K_W8_GEMM256 : QL_K_W4_GEMM256);
+}
 
 template <typename T, bool GATE = false>
 static int launch_gemm256(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc,
@@ -1143,25 +1180,13 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
         return finish_launch(QL_K_W4_GEMM256);
     }
 #endif
-    // int4g32: the 16x16x32 body, the tiles left over after the whole rounds as half tiles behind the whole ones (w4_gemm256x16_kernel); the
-    // developer build's QLINEAR_G256_MI16=0 selects the 32x32x16 body (A/B partner, profiles/r05_g256_mi16_ab.txt)
-    const int total = nbx * nby, cus = cu_count();
-    if (QL_TUNE("QLINEAR_G256_MI16", 1)) {
-        const int grid_p = QL_TUNE("QLINEAR_G256_PGRID", 0) > 0 ? QL_TUNE("QLINEAR_G256_PGRID", 0) : (cus & ~7);   // workgroups per round (developer build: tests)
-        const int rem = total > grid_p && grid_p >= 16 ? total % grid_p : 0;
-        const bool halves = QL_TUNE("QLINEAR_G256_TAIL", 1) && !(dispatch_flags() & QL_D_NOHALF) && g256_tail_halves(rem, grid_p);
-        const int whole = halves ? total - rem : total, units = halves ? 16 * ((rem + 7) / 8) : 0;
-        static bool attr16 = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256x16_kernel<T, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kG256Lds) == hipSuccess;
-        }();
-        (void)attr16;
-        w4_gemm256x16_kernel<T, GATE><<<(unsigned)(whole + units), 512, kG256Lds, st>>>(
-            (const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5),
-            super ? sy : 0, total, whole, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
-        return finish_launch(QL_K_W4_GEMM256);
-    }
-#ifdef QL_DEV_TUNING                                 // QLINEAR_G256_MI16=0: round 4's 32x32x16 body on the int4g32 weights (the product keeps that body for int8 weights only)
+    // the 16x16x32 body, the tiles left over after the whole rounds as half tiles behind the whole ones (w4_gemm256x16_kernel); the developer
+    // build's QLINEAR_G256_MI16=0 selects round 4's 32x32x16 body (A/B partner, profiles/r05_g256_ab.txt)
+    if (QL_TUNE("QLINEAR_G256_MI16", 1))
+        return launch_x16<T, false, GATE>((const T*)A, Wt, Sp, M, N, (int)L.ksteps, lda, nbx, nby,
+                                          super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K * 0.5), super ? sy : 0, (const T*)bias, (T*)C,
+                                          ldc, (const T*)resid, ldr, st);
+#ifdef QL_DEV_TUNING                                 // QLINEAR_G256_MI16=0: round 4's 32x32x16 body (developer library only)
     static bool attr_set = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, false, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kG256Lds) == hipSuccess;
@@ -1179,11 +1204,6 @@ static int launch_gemm256(const void* A, const void* tiled, const void* bias, vo
 template <typename T, bool GATE = false>
 static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, const void* bias, void* C, int M, int N, int K, int64_t lda,
                              int64_t ldc, hipStream_t st, const void* resid = nullptr, int64_t ldr = 0) {
-    static bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, true, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kG256Lds) == hipSuccess;
-    }();
-    (void)attr_set;
     const int nbx = (N + 255) / 256, nby = (M + 255) / 256;
     const bool no_super = QL_TUNE("QLINEAR_GEMM_SUPER", 1) == 0;
     const int sy = QL_TUNE("QLINEAR_GEMM_SY", 4);
@@ -1198,10 +1218,23 @@ static int launch_gemm256_w8(const void* A, const int8_t* Wm, const void* S, con
         return finish_launch(QL_K_W8_GEMM256);
     }
 #endif
+    if (QL_TUNE("QLINEAR_G256_MI16", 1))
+        return launch_x16<T, true, GATE>((const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, nbx, nby,
+                                         super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K), super ? sy : 0, (const T*)bias, (T*)C, ldc,
+                                         (const T*)resid, ldr, st);
+#ifdef QL_DEV_TUNING
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_gemm256_kernel<T, true, GATE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kG256Lds) == hipSuccess;
+    }();
+    (void)attr_set;
     w4_gemm256_kernel<T, true, GATE><<<(unsigned)(nbx * nby), 512, kG256Lds, st>>>(
         (const T*)A, (const u32x4*)Wm, (const T*)S, M, N, K / 64, lda, super ? nbx : xcd_order(nbx, nby, (double)M * K * 2, (double)N * K),
         super ? sy : 0, (const T*)bias, (T*)C, ldc, (const T*)resid, ldr);
     return finish_launch(QL_K_W8_GEMM256);
+#else
+    return QL_ERR_UNSUPPORTED;                         // unreachable: the product's QLINEAR_G256_MI16 is the constant 1
+#endif
 }
 
 // int8 weight-only with the epilogues of the int4 kernel: SiLU * gate on a gate-interleaved copy (C (M, N / 2)), residual add

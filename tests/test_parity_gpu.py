@@ -713,6 +713,46 @@ def test_int8_gemm256_vs_oracle(M, K, N, dt, has_bias):
     assert torch.equal(got, out) and bool((wide[:, N:] == 7.0).all())
 
 
+@pytest.mark.parametrize("M,K,N,kind", [(8192, 4096, 4608, "bias"), (8192, 4096, 4608, "residual"), (4096, 4096, 27392, "gated"),
+                                         (8192, 4096, 27392, "gated"), (8100, 1024, 4600, "plain"), (8192, 13696, 4096, "plain")])
+def test_int8_half_tile_last_round_equals_whole_tiles(M, K, N, kind, monkeypatch):
+    """Round 5: int8 weight-only shares the int4g32 launch (w4_gemm256x16_kernel<W8>: 16x16x32 MFMA body, left-over tiles as 128-row half
+    tiles behind the whole ones); against whole tiles only (QLINEAR_DISPATCH=nohalf): bit for bit, plain / bias / residual / SiLU * gate,
+    ragged M and N, K = 13696; and against the oracle on a row sample."""
+    lib = _lib.get_lib()
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, generator=g)
+    sc = (torch.rand(N, generator=g) * 0.01 + 0.001).half()
+    a = torch.randn((M, K), generator=g).half().to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).half().to(DEV) if kind == "bias" else None
+    resid = torch.randn((M, N), generator=g).half().to(DEV) if kind == "residual" else None
+    tiled, scd = h8.tile_w8(w.to(DEV)), sc.to(DEV)
+
+    def run():
+        if kind == "residual":
+            return h8.w8_forward_tiled_residual(a, tiled, N, scd, bias, resid)
+        if kind == "gated":
+            return h8.w8_forward_tiled_gated(a, tiled, N, scd, bias)     # any copy serves as a "gate-interleaved" one: same arithmetic
+        return h8.w8_gemm256(a, tiled, N, scd, bias)
+
+    got = run()
+    assert got is not None
+    try:
+        monkeypatch.setenv("QLINEAR_DISPATCH", "nohalf")
+        lib.qlinear_dispatch_reload()
+        want = run()
+    finally:
+        monkeypatch.delenv("QLINEAR_DISPATCH")
+        lib.qlinear_dispatch_reload()
+    assert want is not None and torch.equal(got, want)
+    if kind in ("plain", "bias"):
+        rows = torch.unique(torch.cat([torch.arange(0, M, 211), torch.tensor([M - 129, M - 128, M - 1])]))
+        cols = torch.unique(torch.cat([torch.arange(0, N, 37), torch.tensor([N - 1])]))
+        ref = O.w8_matmul(t2n(a[rows.to(DEV)]), np.ascontiguousarray(w[cols].numpy().T), t2n(sc[cols]),
+                          None if bias is None else t2n(bias[cols.to(DEV)]), dtype="f16")
+        assert O.rel_l2(t2n(got[rows.to(DEV)][:, cols.to(DEV)]), ref) <= 1.5e-4
+
+
 I256_SHAPES = [(256, 256, 256, "f16"), (300, 384, 264, "f16"), (1000, 4096, 1000, "bf16"), (512, 13696 - 13696 % 128, 520, "f16"),
                (2048, 1024, 4608, "bf16"), (1, 256, 40, "f16"), (777, 640, 36, "f16")]
 
