@@ -486,7 +486,13 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // reads their bytes once with plain (cacheable) 16-byte loads.  Measured on attention + o_proj (int4g32 4096 x 4096,
 // capacity 256; tools/attention_prefetch.py): 10.8 us without; everything prefetched from the start 10.9 (the
 // attention's own loads queue behind 9.4 MB); started ~1.7 us late and capped at ~7 MB 10.3.
-constexpr int64_t kPrefetchBudget = 7 << 20;                  // bytes that fit in the attention's shadow
+#ifndef QL_PF_BUDGET_KB
+#define QL_PF_BUDGET_KB (7 << 10)
+#endif
+#ifndef QL_PF_SLEEP
+#define QL_PF_SLEEP 8
+#endif
+constexpr int64_t kPrefetchBudget = (int64_t)QL_PF_BUDGET_KB << 10;   // bytes that fit in the attention's shadow
 __device__ __forceinline__ void prefetch_blocks(const Prefetch& pf, int p, int np, int att_blocks) {
     const int np8 = np & ~7;
     if (p >= np8) return;
@@ -495,7 +501,7 @@ __device__ __forceinline__ void prefetch_blocks(const Prefetch& pf, int p, int n
     const int64_t fit = kPrefetchBudget / (per_block > 0 ? per_block : 1);
     const int gmax = fit < pf.blocks ? (int)fit : pf.blocks;
     // let the attention workgroups' own requests reach the memory system first
-    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(8);
+    for (int i = 0; i < QL_PF_SLEEP; ++i) __builtin_amdgcn_s_sleep(8);
     u32 x = 0;
     for (int g = q; g < gmax; g += np8) {
 #pragma unroll
@@ -518,6 +524,27 @@ __device__ __forceinline__ void prefetch_blocks(const Prefetch& pf, int p, int n
     asm volatile("" ::"v"(x));                                // the loads are the point: keep them
 }
 
+// QL_ATT_STAMPS (developer build: tools/ab/build_variant.sh attstamps decode_ops.hip -DQL_ATT_STAMPS, tools/attention_timeline.py): lane 0 of
+// the first and last wave of attention workgroup 0 records the 100 MHz wall clock at the stations of the kernel's dependent chain
+// (QL_ATT_C: the shader clock counter, at entry and end: the clock the chain ran at).
+#ifdef QL_ATT_STAMPS
+__device__ unsigned long long ql_att_stamps[2 * 16];
+#define QL_ATT_T(i, ...)                                                                                   \
+    do {                                                                                                   \
+        asm volatile("" ::__VA_ARGS__);                                                                    \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wv == 0 || wv == NWV - 1))                 \
+            ql_att_stamps[(wv == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime();                    \
+    } while (0)
+#define QL_ATT_C(i)                                                                                        \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wv == 0 || wv == NWV - 1))                 \
+            ql_att_stamps[(wv == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memtime();                        \
+    } while (0)
+#else
+#define QL_ATT_T(i, ...)
+#define QL_ATT_C(i)
+#endif
+
 template <typename T> struct AttMma;
 template <> struct AttMma<f16> {
     typedef _Float16 v8 __attribute__((ext_vector_type(8)));
@@ -538,6 +565,7 @@ template <> struct AttMma<__bf16> {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
     }
 };
+#ifdef QL_DEV_TUNING                                 // round 2's kernel: the A/B partner of decode_attention_group_kernel below (QLINEAR_ATTENTION_R2=1)
 template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ pos,
                                                                          const int64_t* __restrict__ widx, T* Kc, T* Vc,
@@ -780,6 +808,396 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
             }
         }
     }
+}
+#endif   // QL_DEV_TUNING
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: the group kernel rebuilt (the round-2 kernel above stays in the developer library: QLINEAR_ATTENTION_R2=1).
+// Measured on the round-2 kernel (tools/attention_timeline.py: the 100 MHz clock stamped inside the launch, profiles/r05_attention_timeline.txt):
+// two workgroups on two CUs; of 6.3 us launch to launch 5.5 are inside the kernel, and its data has only landed 2.3 - 2.9 us after entry -
+// whatever is requested (the 4-byte position lands 1.0 us after entry in the first wave, 2.0 us in the last: a CU's address unit takes the
+// waves' requests in arrival order, 128 KB of keys and values per CU queue in front), then a 2.6 us chain of 1 160 instructions per wave at
+// two waves per SIMD.  What this kernel changes, and what each step measured (tools/ab/run_attention_ab.sh, profiles/r05_attention_ab.txt):
+//   * instruction count (-0.23 us): workgroup -> (sequence, group) by one multiply with a host-made reciprocal, wave index / tile bases /
+//     pointers in SGPRs, lanes add one 32-bit offset (global_load saddr form, immediates for the d chunks): ~90 instructions until the last
+//     request is out (was 280); wave max / exp-sum across the four 16-lane rows by v_permlane16/32_swap (was four LDS bpermute round
+//     trips); -inf handled once per wave (a safe maximum) and once per head in the merge; q / sqrt(d) as the correctly rounded quotient by
+//     two fused steps on a host-rounded reciprocal (exhaustively equal to the division: tests/test_attention_scale_cpu.py);
+//   * request ORDER (-0.12 us): widx, pos, queries, new key / value, keys, [pos has landed] table row, masks, values.  Requests retire in
+//     order: the table row no longer waits behind the values, rotary -> barrier -> K Q^T -> softmax run while the values stream in; the
+//     first barrier is a raw s_barrier behind an LDS wait (__syncthreads() would drain the values); widx / pos are VECTOR loads (as scalar
+//     loads they cost a scalar-queue drain in front of the key requests);
+//   * rows behind the step's own row hold nothing of this sequence (the reference appends at the END of its cache,
+//     chatglm_q/model.py:148-151): their tiles' scores are -inf without MFMAs, their value / mask requests go to tile 0's rows (this CU's L1
+//     has them: no bytes from L2; NOT a branch - a branch around a request costs a queue drain at its join); wave w owns the 16-position
+//     tiles w, w + NWV, ...: a short context spreads over the waves;
+//   * the new key / value row replaces its cache row in the ONE wave that owns its tile (wave-uniform branch).
+// 6.30 -> 5.96 us at capacity 256, 9.48 -> 8.85 at 1152 - 4224 (window split + combine launch).  Measured and NOT adopted: the table row
+// without the position's round trip (QL_ATT_NOPOS, a timing-only build: -0.09 us - a per-step row buffer would buy that), a barrier between
+// the small first-needed requests and the bulk ones (QL_ATT_PREBAR: 0), waiting for widx to skip the keys' requests too (+0.5 us), 4 waves
+// (+0.06).  Same rounding points as the round-2 kernel except that P = exp(s - wave max) is taken per wave of INTERLEAVED tiles.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xrow_max(float x) {          // max over the lanes li, li + 16, li + 32, li + 48
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    x = fmaxf(a, b);
+    a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float xrow_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    x = a + b;
+    a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// x / d for a host-rounded r = RN(1 / d): q0 = x r, then one exact residual and one correction (Markstein): the correctly rounded quotient
+__device__ __forceinline__ float div_by(float x, float d, float r) {
+    const float q0 = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, d, x), r, q0);
+}
+
+template <typename T, int NWV>
+__global__ __launch_bounds__(NWV * 64) void decode_attention_group_kernel(const T* __restrict__ QKV, const int64_t* __restrict__ widx,
+                                                                          const int64_t* __restrict__ pos, T* Kc, T* Vc, int ga, int cap_full,
+                                                                          int ldq32, unsigned ginv, const float* __restrict__ mask,
+                                                                          const T* __restrict__ table,
+                                                                          float sqrt_d, float rsqrt_d, T* __restrict__ Out,
+                                                                          float* __restrict__ split_out, Prefetch next) {
+    // The leading 14 argument dwords are preloaded into SGPRs at wave launch (Makefile): what the position / query / key / value loads need
+    // (the mask and table pointers arrive by scalar load while those are issued).
+    // ga = G | attention workgroups << 12 (B G of them along x, the prefetchers behind); ginv = floor(2^32 / G) + 1: x / G by one multiply.
+    const int G = ga & 0xFFF, att_blocks = (int)((unsigned)ga >> 12);
+    if ((int)blockIdx.x >= att_blocks) {                      // workgroups past the attention ones warm the caches for the next launch
+        if (blockIdx.y == 0) prefetch_blocks(next, (int)blockIdx.x - att_blocks, (int)gridDim.x - att_blocks, att_blocks);
+        return;
+    }
+    static_assert(sizeof(T) == 2, "16-bit dtypes");
+    static_assert(NWV == 4 || NWV == 8, "waves per block");
+    constexpr int D = 128, HP = 16, WIN = 256, NTH = NWV * 64;
+    constexpr int PT = WIN / NWV / 16;                        // 16-position tiles per wave
+    constexpr int NH = PT / 2;                                // 32-row value images per wave
+    constexpr int QPT = HP * 64 / NTH;                        // query pairs rotated per thread
+    constexpr int VP = 288;                                   // bytes per value row in LDS: rows 8 banks apart (tr reads conflict-free)
+    constexpr int QP = 272;                                   // bytes per query head in LDS
+    constexpr int OP = 132;                                   // floats per head of a wave's partial output
+    __shared__ __attribute__((aligned(16))) unsigned char vimg[NWV][32 * VP];   // per wave: 32 value rows; later its partial O
+    __shared__ __attribute__((aligned(16))) unsigned char qs[HP * QP];
+    __shared__ __attribute__((aligned(16))) T knew[D];
+    __shared__ __attribute__((aligned(16))) T vnew[D];
+    __shared__ __attribute__((aligned(16))) float mw[HP][NWV], lw[HP][NWV];
+    static_assert(HP * OP * 4 <= 32 * VP, "partial output fits the wave's value image");
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    QL_ATT_T(0, "v"(tid));
+    QL_ATT_C(13);
+    // widx[0] and pos[b] live in device memory.  As VECTOR loads (a laundered zero lane offset keeps the compiler from making them scalar
+    // loads) they retire in order with everything else: a scalar load here cost a queue drain in front of the key loads (its destination
+    // registers were reused), and the table row's address waits for exactly one load instead of for every scalar one.
+    unsigned z0 = 0;
+    asm volatile("" : "+v"(z0));
+    const int b = G == 1 ? (int)blockIdx.x : (int)__umulhi(blockIdx.x, ginv), g = (int)blockIdx.x - b * G;
+    const int w_abs_v = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(widx) + z0);       // (low words: |values| < 2^31)
+    const int pos_v = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(pos + b) + z0);
+    const int t_lo = (int)blockIdx.y * WIN;
+    const int wlen = cap_full - t_lo < WIN ? cap_full - t_lo : WIN;
+    const int pitch = G * D * 2;                              // bytes per cache row
+    const int64_t win0 = (((int64_t)b * cap_full + t_lo) * G + g) * D;
+    const char* kb = reinterpret_cast<const char*>(Kc + win0);
+    const char* vb = reinterpret_cast<const char*>(Vc + win0);
+    const T* row = QKV + (int64_t)b * ldq32;
+    const float* mk = mask + (int64_t)b * cap_full + t_lo;
+
+    // every load of the block up front.  The group's 16 query heads are 4 KB in a row: thread t takes pairs t, t + NTH, ...
+    u32 xq[QPT];
+    {
+        const char* qb = reinterpret_cast<const char*>(row + g * (HP * D));
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) xq[k] = *reinterpret_cast<const u32*>(qb + (unsigned)(4 * tid) + 4 * NTH * k);
+    }
+#ifdef QL_ATT_NOPOS                                          // timing ablation (results wrong): the table row without the position's round trip
+    const u32 cq = *reinterpret_cast<const u32*>(reinterpret_cast<const char*>(table + (b + (pos_v & 0)) * D) + (unsigned)(4 * lane));
+#endif
+    // (every wave requests the new key pair and value chunk: two instructions; a branch around them costs a queue drain at its join)
+    u32 xk = *reinterpret_cast<const u32*>(reinterpret_cast<const char*>(row + (HP * G + g) * D) + (unsigned)(4 * lane));
+    u32x4 xv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(row + (HP * G + G + g) * D) + (unsigned)(16 * li));
+#ifdef QL_ATT_PREBAR
+    // the CU's address unit takes requests in arrival order: every wave's small first-needed requests are in its queue before any wave's
+    // bulk ones (a barrier nobody waits long at: the waves enter together)
+    asm volatile("s_barrier" ::: "memory");
+#endif
+    u32x4 kf[PT][4];                                          // [tile][d chunk j]: d = 32 j + 8 q .. + 7 of row li
+    u32x4 vr[4 * PT];                                         // tile i >> 2, row 4 (i & 3) + q of it, 16-byte chunk li
+    f32x4 mr[PT];                                             // mask of position 4 q + e of the tile
+    // scalar base + one 32-bit lane offset (+ immediate): row clamped to the window (the ragged last tile of a cache), three instructions
+    const int last = wlen - 1;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int t0 = 16 * (wv + NWV * pt);                  // the tile's first window-local position (scalar)
+        const int r = t0 + li;
+        const unsigned off = (unsigned)((r < last ? r : last) * pitch + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[pt][j] = *reinterpret_cast<const u32x4*>(kb + off + 64 * j);
+    }
+    // The position's table row is needed first (rotary -> barrier -> scores) and the values last: requests return in order, so the row is
+    // requested as soon as pos has landed - behind the keys, in front of the masks and the values - and the chain up to the softmax runs
+    // while the values stream in.  widx went out in front of pos: it has landed too, so tiles behind the step's own row request nothing more.
+#ifndef QL_ATT_NOPOS
+    const int pos_b = __builtin_amdgcn_readfirstlane(pos_v);
+    const T* cs = table + (pos_b < 0 ? 0 : pos_b <= cap_full ? pos_b : cap_full) * D;   // clamp_pos
+    const u32 cq = *reinterpret_cast<const u32*>(reinterpret_cast<const char*>(cs) + (unsigned)(4 * lane));   // pair `lane` of the position's row
+#endif
+    // rows that exist: [0, nvalid) of the window (a write index outside the cache writes nothing and hides nothing)
+    const int w_abs = __builtin_amdgcn_readfirstlane(w_abs_v);
+    const int lim = w_abs >= 0 && w_abs < cap_full ? w_abs + 1 - t_lo : wlen;
+    const int nvalid = lim < 0 ? 0 : lim < wlen ? lim : wlen;
+    const int wrow = w_abs - t_lo;                            // window-local row written by this step
+    const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
+    // wave-local new row 16 pt + (row in its tile) when the row's tile is one of this wave's, else -1
+    const int wl = has_new && ((wrow >> 4) & (NWV - 1)) == wv ? 16 * ((wrow >> 4) / NWV) + (wrow & 15) : -1;
+    bool tv[PT];                                              // the wave's tile pt holds a row that exists (scalar)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) tv[pt] = 16 * (wv + NWV * pt) < nvalid;
+    // (no branch around a request: a join costs a queue drain.  A tile behind the step's row re-requests tile 0's rows instead - they are in
+    // this CU's L1 by then: no bytes from L2)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int t0 = tv[pt] ? 16 * (wv + NWV * pt) : 0;
+        if (wlen >= WIN) {                                    // (block-uniform; a ragged last window: clamped element by element)
+            mr[pt] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(mk + t0) + (unsigned)(16 * q));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = t0 + 4 * q + e;
+                mr[pt][e] = mk[r < last ? r : last];
+            }
+        }
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int t0 = tv[pt] ? 16 * (wv + NWV * pt) : 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int r = t0 + 4 * a + q;
+            const unsigned off = (unsigned)((r < last ? r : last) * pitch + 16 * li);
+            vr[4 * pt + a] = *reinterpret_cast<const u32x4*>(vb + off);
+        }
+    }
+    QL_ATT_T(15, "v"(tid));
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {                         // validity into the mask (while the loads fly)
+        const int t0 = 16 * (wv + NWV * pt);
+        if (tv[pt] && t0 + 16 > nvalid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mr[pt][e] = t0 + 4 * q + e < nvalid ? mr[pt][e] : -INFINITY;
+        }
+    }
+    {                                                         // (keeps the two loads where they are: not sunk into the branches below)
+        u32 x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3];
+        asm volatile("" : "+v"(xk), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        xv = u32x4{x0, x1, x2, x3};
+    }
+    QL_ATT_T(1, "v"(tid));
+#ifdef QL_ATT_STAMPS
+    QL_ATT_T(12, "v"(xq[0]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QL_ATT_T(2, "v"(cq));
+#endif
+
+    // rotary: 16 heads x 64 pairs (QPT per thread, all of pair `lane`), the group's key pair (wave 0), the value row (wave 1)
+    float c0, c1;
+    unpack2<T>(cq, c0, c1);
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        float x0, x1, y0, y1;
+        unpack2<T>(xq[k], x0, x1);
+        rope_pair(x0, x1, c0, c1, y0, y1);
+        *reinterpret_cast<u32*>(qs + (wv + NWV * k) * QP + 4 * lane) =
+            pack2<T>(div_by(Act<T>::round(y0), sqrt_d, rsqrt_d), div_by(Act<T>::round(y1), sqrt_d, rsqrt_d));
+    }
+    if (wv == 0) {
+        float x0, x1, y0, y1;
+        unpack2<T>(xk, x0, x1);
+        rope_pair(x0, x1, c0, c1, y0, y1);
+        reinterpret_cast<u32*>(knew)[lane] = pack2<T>(y0, y1);
+    } else if (wv == 1) {
+        if (lane < 16) reinterpret_cast<u32x4*>(vnew)[lane] = xv;
+    }
+    QL_ATT_T(3, "v"(tid));
+    // the rotated queries / new row are in LDS; NOT __syncthreads(): its fence would wait for the values still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    QL_ATT_T(4, "v"(tid));
+    if (has_new && wv == NWV - 1 && lane < 32) {              // the cache row of this step (read back from LDS by nobody else)
+        const int64_t at = win0 + (int64_t)wrow * (G * D);
+        if (lane < 16) *reinterpret_cast<u32x4*>(Kc + at + 8 * lane) = reinterpret_cast<const u32x4*>(knew)[lane];
+        else *reinterpret_cast<u32x4*>(Vc + at + 8 * (lane - 16)) = reinterpret_cast<const u32x4*>(vnew)[lane - 16];
+    }
+
+    // S^T = K Q^T: lane (li, q) ends with scores of head li at positions 4 q + e of each tile
+    u32x4 qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const u32x4*>(qs + li * QP + 64 * j + 16 * q);
+    if (wl >= 0) {                                            // this wave owns the new row's tile: the row comes from LDS
+        const bool mine_k = li == (wl & 15);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+            if ((wl >> 4) == pt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 knf = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(knew) + 64 * j + 16 * q);
+                    kf[pt][j] = mine_k ? knf : kf[pt][j];
+                }
+            }
+    }
+    f32x4 s[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (tv[pt]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = AttMma<T>::qk(kf[pt][j], qf[j], acc);
+        }
+        s[pt] = acc;
+    }
+    QL_ATT_T(5, "v"(s[0][0]), "v"(s[PT - 1][3]));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+        if (tv[pt]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[pt][e] = Act<T>::round(s[pt][e]) + mr[pt][e];
+                mx = fmaxf(mx, s[pt][e]);
+            }
+        }
+    mx = xrow_max(mx);
+    const float mxs = mx == -INFINITY ? 0.f : mx;             // a wave without a visible row: every exp below is exp(-inf) = 0
+    float lsum = 0.f;
+    u32x2v pf[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        pf[pt] = u32x2v{0u, 0u};
+        if (tv[pt]) {
+            float ev[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ev[e] = __expf(s[pt][e] - mxs);
+                lsum += ev[e];
+            }
+            pf[pt] = u32x2v{pack2<T>(ev[0], ev[1]), pack2<T>(ev[2], ev[3])};
+        }
+    }
+    lsum = xrow_sum(lsum);
+    QL_ATT_T(6, "v"(lsum), "v"(pf[PT - 1]));
+
+    // O^T = V^T P^T, 32 value rows (two tiles) at a time through the wave's LDS image
+    if (wl >= 0) {                                            // (the values are first touched here: they streamed in behind everything above)
+        const bool mine_v = q == (wl & 3);
+        const u32x4 vnf = reinterpret_cast<const u32x4*>(vnew)[li];
+#pragma unroll
+        for (int i = 0; i < 4 * PT; ++i)
+            if ((wl >> 2) == i) vr[i] = mine_v ? vnf : vr[i];
+    }
+    unsigned char* img = vimg[wv];
+    f32x4 o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+        if (!tv[2 * hf]) continue;                            // (tiles are valid in order: the second implies the first)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < 4 || tv[2 * hf + 1]) *reinterpret_cast<u32x4*>(img + (4 * i + q) * VP + 16 * li) = vr[8 * hf + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ptl = 0; ptl < 2; ++ptl) {
+            if (!tv[2 * hf + ptl]) continue;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const unsigned char* p = img + (16 * ptl + 4 * q + (li >> 2)) * VP + 2 * (16 * dt + 4 * (li & 3));
+                const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
+                o[dt] = AttMma<T>::pv(__builtin_bit_cast(u32x2v, a), pf[2 * hf + ptl], o[dt]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    QL_ATT_T(7, "v"(o[0]), "v"(o[7]));
+    // partial results of the wave: O[head li][d = 16 dt + 4 q + e], max and exp-sum per head
+    float* ow = reinterpret_cast<float*>(img);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(ow + li * OP + 16 * dt + 4 * q) = o[dt];
+    if (q == 0) {
+        mw[li][wv] = mx;
+        lw[li][wv] = lsum;
+    }
+    QL_ATT_T(8, "v"(tid));
+    __syncthreads();
+    QL_ATT_T(9, "v"(tid));
+    {
+        constexpr int CW = HP * D / NTH;                      // d values per thread: 8 (4 waves) or 4 (8 waves)
+        constexpr int CPH = D / CW;                           // threads per head
+        const int hh = tid / CPH, ch = tid - hh * CPH;
+        float mv[NWV], lv[NWV];
+#pragma unroll
+        for (int w4 = 0; w4 < NWV; w4 += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&mw[hh][w4]), c = *reinterpret_cast<const f32x4*>(&lw[hh][w4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mv[w4 + e] = a[e], lv[w4 + e] = c[e];
+        }
+        float m = mv[0];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) m = fmaxf(m, mv[w]);
+        const float ms = m == -INFINITY ? 0.f : m;            // a window without a visible row: every weight exp(-inf) = 0
+        float l = 0.f, acc[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            const float fw = __expf(mv[w] - ms);
+            l = __builtin_fmaf(lv[w], fw, l);
+            const float* src = reinterpret_cast<const float*>(vimg[w]) + hh * OP + CW * ch;
+#pragma unroll
+            for (int e4 = 0; e4 < CW; e4 += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + e4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e4 + e] = __builtin_fmaf(a[e], fw, acc[e4 + e]);
+            }
+        }
+        const int64_t head = ((int64_t)b * G + g) * HP + hh;
+        if (split_out) {
+            float* so = split_out + (head * gridDim.y + blockIdx.y) * (D + 2);
+            if (ch == 0) {
+                so[0] = m;
+                so[1] = l;
+            }
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int e = 0; e < CW; e += 2) *reinterpret_cast<f32x2*>(so + 2 + CW * ch + e) = f32x2{acc[e], acc[e + 1]};
+        } else {
+            const float inv = 1.0f / l;
+            T* dst = Out + head * D + CW * ch;
+            if constexpr (CW == 8) {
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = acc[e] * inv;
+                store8<T>(dst, y);
+            } else {
+                typedef u32 u32x2s __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<u32x2s*>(dst) = u32x2s{pack2<T>(acc[0] * inv, acc[1] * inv), pack2<T>(acc[2] * inv, acc[3] * inv)};
+            }
+        }
+    }
+    QL_ATT_T(10, "v"(tid));
+#ifdef QL_ATT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QL_ATT_T(11, "v"(tid));
+    QL_ATT_C(14);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1098,24 +1516,41 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
     if constexpr (ROPE && sizeof(T) == 2) {
         // 16 heads per key/value group: the group kernel on the matrix cores (QLINEAR_DISPATCH=nogroupattn: per-head kernels)
         const bool one_window = capacity <= kAttnWindow;
-        if (D == 128 && H == 16 * G && H < 65536 && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) && !(dispatch_flags() & QL_D_NOGROUPATTN)) {
+        if (D == 128 && H == 16 * G && G < 4096 && B * G < (1 << 19) && ldq % 8 == 0 && ldq <= 0x7fffffff && (one_window || split_ws) &&
+            !(dispatch_flags() & QL_D_NOGROUPATTN)) {
             // prefetch workgroups: about one per CU (they only issue loads); none without a descriptor, none when the
             // attention itself fills the chip (windows of a long context, large batches: measured slower)
             const int att_blocks = (int)(B * G);
-            const int hg = (int)H | ((int)G << 16);
             const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < 256 ? ((pf.blocks + 7) & ~7) : 256) : 0;
             dim3 gridg((unsigned)(att_blocks + npf), (unsigned)(one_window ? 1 : nwin));
-            // 8 waves x 32 positions: 6.3 us against 6.6 for 4 x 64 (the kernel is one dependent chain; LABNOTES r2)
 #ifdef QL_DEV_TUNING
-            if (QL_TUNE("QLINEAR_ATTENTION_WAVES", 8) == 4)
-                decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
-                                                                         (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws, pf);
-            else
+            if (QL_TUNE("QLINEAR_ATTENTION_R2", 0)) {         // round 2's kernel (8 waves x 32 positions: 6.3 us against 6.6 for 4 x 64)
+                const int hg = (int)H | ((int)G << 16);
+                if (QL_TUNE("QLINEAR_ATTENTION_WAVES", 8) == 4)
+                    decode_attention_mfma_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
+                                                                             (int)capacity, (int)ldq, (const T*)table, mask, sq,
+                                                                             (T*)Out, one_window ? nullptr : split_ws, pf);
+                else
+                    decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
+                                                                             (int)capacity, (int)ldq, (const T*)table, mask, sq,
+                                                                             (T*)Out, one_window ? nullptr : split_ws, pf);
+            } else
 #endif
-                decode_attention_mfma_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, pos, widx, (T*)Kc, (T*)Vc, hg, att_blocks,
-                                                                         (int)capacity, (int)ldq, (const T*)table, mask, sq,
-                                                                         (T*)Out, one_window ? nullptr : split_ws, pf);
+            {
+                const int ga = (int)G | (att_blocks << 12);
+                const unsigned ginv = (unsigned)(0x100000000ull / (unsigned long long)G) + 1u;   // x / G = (x * ginv) >> 32 for x G < 2^32
+                const float rsq = (float)(1.0 / (double)sq);  // RN(1 / sqrt(d)) for the kernel's two-step division
+#ifdef QL_DEV_TUNING
+                if (QL_TUNE("QLINEAR_ATTENTION_WAVES", 8) == 4)
+                    decode_attention_group_kernel<T, 4><<<gridg, 256, 0, st>>>((const T*)Q, widx, pos, (T*)Kc, (T*)Vc, ga, (int)capacity, (int)ldq, ginv,
+                                                                              mask, (const T*)table, sq, rsq, (T*)Out,
+                                                                              one_window ? nullptr : split_ws, pf);
+                else
+#endif
+                    decode_attention_group_kernel<T, 8><<<gridg, 512, 0, st>>>((const T*)Q, widx, pos, (T*)Kc, (T*)Vc, ga, (int)capacity, (int)ldq, ginv,
+                                                                              mask, (const T*)table, sq, rsq, (T*)Out,
+                                                                              one_window ? nullptr : split_ws, pf);
+            }
             const int rc = finish_launch();
             if (rc != 0 || one_window) return rc;
             attention_combine_kernel<T, 128><<<(unsigned)(B * H), 256, 0, st>>>(split_ws, (T*)Out, nwin);
@@ -1183,3 +1618,9 @@ int silu_mul(int dtype, const void* In, void* Out, int64_t rows, int64_t hidden,
 }
 
 }  // namespace ql
+
+#ifdef QL_ATT_STAMPS
+extern "C" int qlinear_att_stamps_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ql::ql_att_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
