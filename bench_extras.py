@@ -648,6 +648,47 @@ def e2e_cpu(torch, device):
             "generated": len(toks), "prefill_s": round(s["init_s"], 2), "gen_tok_per_s": round(s["gen_tok_per_s"], 4)}
 
 
+def decode_attention(torch, device):
+    """The decode attention launch alone (ChatGLM2 geometry: 32 heads, 2 key / value groups, D = 128, batch 1; rotary + cache write + attention
+    in one launch, window split + combine launch above 256 positions): 28 rotating caches in one HIP graph, per capacity, the context 20
+    positions short of it; plus the same launch followed by o_proj with the prefetch workgroups, as the decode loop runs it."""
+    from chatglm_q_amd import _lib, fused_ops as F_
+    from chatglm_q_amd import model as M
+    B, H, G, D, L = 1, 32, 2, 128, 28
+    out = {}
+    gen = torch.Generator(device=device).manual_seed(3)
+    for cap in (256, 1152, 4224):
+        n = cap - 20
+        qkv = torch.randn(B, 1, (H + 2 * G) * D, device=device, generator=gen).half()
+        table = M.rotary_table(D, cap + 8).to(device).half().reshape(cap + 8, -1).contiguous()
+        pos = torch.full((B, 1), n + 1, dtype=torch.long, device=device)
+        widx = torch.tensor([n], dtype=torch.long, device=device)
+        mask = torch.full((B, 1, cap), -1e10, device=device)
+        mask[:, :, : n + 1] = 0
+        caches = [(torch.randn(B, cap, G, D, device=device, generator=gen).half(), torch.randn(B, cap, G, D, device=device, generator=gen).half())
+                  for _ in range(L)]
+
+        def run():
+            for k, v in caches:
+                F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, G, D, split=cap > 256)
+        out[f"capacity_{cap}_us"] = round(_graph_time(torch, device, run, reps=10) / L * 1e3, 2)
+        if cap == 256:
+            layers = [_w4_layer(torch, device, 4096, 4096, False, gen) for _ in range(L)]
+
+            def pair():
+                for (k, v), l in zip(caches, layers):
+                    nxt = (l.prepare()._packed, _lib.NEXT_W4G32_PACKED, 4096, 4096)
+                    a = F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, G, D, prefetch=nxt)
+                    with torch.no_grad():
+                        l(a)
+            out["capacity_256_with_o_proj_us"] = round(_graph_time(torch, device, pair, reps=10) / L * 1e3, 2)
+            del layers
+        del caches
+    out["note"] = ("launch to launch; round 2's kernel: 6.30 / 9.2 - 9.5 us; attention + o_proj 10.3 (profiles/r05_attention_ab.txt); what the launch "
+                   "is made of: profiles/r05_attention_timeline.txt")
+    return out
+
+
 def prefill_attention(torch, device):
     """The attention of config 5's prefill (batch 4, one chunk of 2048 positions, 32 heads x 128, 2 key / value groups): the
     one-launch kernel (qlinear_prefill_attention) beside the GEMM route (two batched GEMMs around qlinear_masked_softmax); FLOPs
@@ -709,7 +750,7 @@ def run(torch, device):
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
                      ("prefill_gemm_M8192", prefill_gemm), ("prefill_gemm_power", prefill_gemm_power), ("fp32_rows_512", fp32_many_rows), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
-                     ("prefill_attention_b4_s2048", prefill_attention), ("e2e_generate", e2e_generate), ("int8_model_prefill", int8_model_prefill),
+                     ("prefill_attention_b4_s2048", prefill_attention), ("decode_attention", decode_attention), ("e2e_generate", e2e_generate), ("int8_model_prefill", int8_model_prefill),
                      ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)

@@ -141,7 +141,9 @@ def decode_attention_rope(qkv: Tensor, table: Tensor, pos: Tensor, write_index: 
     ``write_index[0]``.  ``prefetch = (weights, kind, N, K)``: the weights of the next one-row linear on the stream
     (kind ``_lib.NEXT_W4G32_PACKED`` / ``_lib.NEXT_W8_ROWS``) are pulled into the caches by spare workgroups of this
     launch (include/qlinear_hip.h).  ``plan_out``: a list receiving a pre-bound launch ``run(qkv)`` (``_lib.make_plan``) that
-    is valid while table / pos / write_index / caches / mask / prefetched weights stay at their addresses - the caller's key."""
+    is valid while table / pos / write_index / caches / mask / prefetched weights stay at their addresses - the caller's key.
+    Cache rows behind ``write_index[0]`` hold nothing of the sequence (the reference appends the step's key / value at the end of its
+    cache, chatglm_q/model.py:148-151): ``mask`` must hide them, and the 16-heads-per-group kernel skips them whatever it says."""
     lib = _lib.get_lib()
     B, S, W = qkv.shape
     if S != 1:

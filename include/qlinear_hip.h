@@ -392,7 +392,11 @@ int qlinear_qembedding_w8(const int64_t* ids, const int8_t* W, const void* S, vo
  * decode_attention:  one query position: q (B, H*D), mask (B, capacity) additive fp32 -> out (B, H*D)
  *                                                                                              model.py:157-175
  * decode_attention_rope: rope_kv_write (S = 1) and decode_attention in ONE launch: qkv (B, (H+2G)*D) in, the
- *                    cache row widx[0] written by one block per (b, group), out (B, H*D)
+ *                    cache row widx[0] written by one block per (b, group), out (B, H*D).  The reference appends the
+ *                    step's key / value at the END of its cache (model.py:148-151); here the cache is preallocated, so
+ *                    rows behind widx[0] hold nothing of the sequence: the caller masks them (as it must for the
+ *                    per-head kernels too) and the 16-heads-per-group kernel does not compute on them whatever the
+ *                    mask says; with widx[0] outside [0, capacity) nothing is written and the mask alone decides
  * silu_mul:          in (rows, 2*hidden) -> out[r,i] = round(round(silu(in[r,i])) * in[r,hidden+i])   model.py:200-201
  * Bounds of the rotary entry points (no table length crosses the ABI): `table` must hold capacity + 1 positions; pos
  * values are clamped to [0, capacity] - positions are 1-based counts (model.py:307-308), a valid one is at most its
