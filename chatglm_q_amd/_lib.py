@@ -70,6 +70,7 @@ EXPORTS = {
     "qlinear_w4g32_packed_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_repack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "qlinear_w4g32_rows_on_tiled": (c_int, [c_int64, c_int64, c_int64, c_int, c_int]),
+    "qlinear_w4g32_packed_dispatch": (c_int, [c_int64, c_int64, c_int64, c_int, c_int]),
     "qlinear_gated_serves": (c_int, [c_int64, c_int64, c_int64, c_int, c_int]),
     "qlinear_w4g32_gemv_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "qlinear_w4g32_tiled_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),

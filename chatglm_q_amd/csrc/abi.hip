@@ -29,6 +29,7 @@ static unsigned parse_dispatch_env() {
     if (strstr(e, "nohalf")) v |= QL_D_NOHALF;
     if (strstr(e, "nof32mfma")) v |= QL_D_NOF32MFMA;
     if (strstr(e, "nofewrow")) v |= QL_D_NOFEWROW;
+    if (strstr(e, "norows16")) v |= QL_D_NOROWS16;
     if (strstr(e, "norows4")) v |= QL_D_NOROWS4;
     if (strstr(e, "nogroupattn")) v |= QL_D_NOGROUPATTN;
     return v;
@@ -248,7 +249,18 @@ int qlinear_w4g32_fwd_tiled(const void* A, const void* tiled, const void* bias, 
 int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags) {
     if (dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return 0;         // fp32 has no MFMA path
     if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
-    return w4_rows_use_gemm(M, N, K) && !w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0) ? 1 : 0;
+    return w4_rows_use_gemm(M, N, K) && !w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0) &&
+                   !w4_rows16_serves(dtype, M, N, K, K)
+               ? 1
+               : 0;
+}
+
+int qlinear_w4g32_packed_dispatch(int64_t M, int64_t N, int64_t K, int dtype, int flags) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || !dtype_ok(dtype)) return 0;
+    if (qlinear_w4g32_rows_on_tiled(M, N, K, dtype, flags)) return 0;
+    if (w4_rows4_serves(dtype, M, N, K, K, (flags & QL_FLAG_STRICT_ROUNDING) != 0)) return QL_K_W4_ROWS4;
+    if (w4_rows_use_gemm(M, N, K) && w4_rows16_serves(dtype, M, N, K, K)) return QL_K_W4_ROWS16;
+    return QL_K_W4_GEMV;
 }
 
 unsigned qlinear_dispatch_flags(void) { return dispatch_flags() & 0x7FFFFFFFu; }
@@ -332,6 +344,12 @@ int qlinear_w4g32_fwd_packed_gated(const void* A, const void* packed, const void
         if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || N % 4 != 0 || lda < K || ldc < N / 2) return QL_ERR_BAD_SHAPE;
         if (!aligned(packed, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
         return w4_rows4_gated(dtype, A, packed, bias, C, M, N, K, lda, ldc, (hipStream_t)stream);
+    }
+    if (w4_rows16_serves(dtype, M, N, K, lda)) {                // 3..16 rows: part 1 of the gate-interleaved copy, 16x16x32 MFMA (w4_rows16.hip)
+        if (!A || !C) return QL_ERR_NULL_POINTER;
+        if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || N % 4 != 0 || lda < K || ldc < N / 2) return QL_ERR_BAD_SHAPE;
+        if (!aligned(packed, 16) || !aligned(A, 16) || lda % 8 != 0) return QL_ERR_MISALIGNED;
+        return w4_rows16(dtype, A, packed, bias, C, M, N, K, lda, ldc, (hipStream_t)stream, true);
     }
     return qlinear_w4g32_fwd_tiled_gated(A, (const char*)packed + w4_layout(N, K, 2).off_wm, bias, C, M, N, K, lda, ldc, dtype,
                                          stream);

@@ -106,6 +106,10 @@ int w4_mlp_engine(int dtype, bool strict, const void* x, const void* ln_weight, 
 // w4_rows4.hip (1..4 rows, fp16 / bf16, exact-dequant arithmetic): 4x4x4 MFMA on part 1 of the derived layout; ks = K slices per quad
 bool w4_rows4_supported(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
 bool w4_rows4_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda, bool strict);   // w4_packed.hip: the routing rule
+// w4_rows16.hip (3..16 rows, fp16 / bf16, reference rounding): 16x16x32 MFMA on part 1, K split over the waves of a workgroup, one launch
+bool w4_rows16_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda);
+int w4_rows16(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+              int64_t ldc, hipStream_t st, bool gate = false);
 int w4_rows4(int dtype, int ks, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
              int64_t lda, int64_t ldc, hipStream_t st, bool gate = false, const void* delta = nullptr, const void* ln_weight = nullptr,
              void* hout = nullptr, float eps = 0.f);

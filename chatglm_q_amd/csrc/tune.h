@@ -25,7 +25,7 @@ inline int tune_env(const char* name, int dflt) {
 // "nohalf" (round 5: the half-tile last round of the int4g32 256-tile GEMM's launch; whole tiles only, the older peel where it applies -
 // the rows both serve are bit-equal), "nof32mfma" (round 5: the fp32 matrix-instruction kernel for fp32 activations with 128+ rows; the VALU kernels instead).
 enum : unsigned { QL_D_NO256 = 1, QL_D_NOPEEL = 2, QL_D_NOFEWROW = 4, QL_D_NOROWS4 = 8, QL_D_NOGROUPATTN = 16, QL_D_NOHALF = 32,
-                  QL_D_NOF32MFMA = 64 };
+                  QL_D_NOF32MFMA = 64, QL_D_NOROWS16 = 128 };
 unsigned dispatch_flags();     // abi.hip: parsed once; qlinear_dispatch_reload() parses again (tests, A/B tools)
 
 }  // namespace ql

@@ -251,7 +251,9 @@ struct FewRowPlan {
 };
 constexpr int kFewRowWaves = 4;
 // global K split: aim at >= ~2048 waves (8 per CU), at least 2 K steps per wave
+static int fewrow_waves() { return QL_TUNE("QLINEAR_FEWROW_KW", kFewRowWaves); }   // developer build: 4 / 8 / 16 waves per block
 static FewRowPlan fewrow_plan(int64_t M, int64_t N, int64_t K, size_t ws_bytes) {
+    const int kFewRowWaves = fewrow_waves();
     const int forced = QL_TUNE("QLINEAR_FEWROW_KSPLIT", 0);
     const int nt = fewrow_nt(N);
     const int64_t ksteps = (K / 32 + 1) / 2, nb = (N + 32 * nt - 1) / (32 * nt);
@@ -275,10 +277,9 @@ size_t w4_fewrow_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return p.ksplit > 1 ? (size_t)(p.ksplit * M * N) * sizeof(float) : 0;
 }
 
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, int KW = kFewRowWaves>
 static int launch_fewrow_nt(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda,
                             int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
-    constexpr int KW = kFewRowWaves;
     const FewRowPlan plan = fewrow_plan(M, N, K, ws && ((uintptr_t)ws & 15) == 0 ? ws_bytes : 0);
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const int64_t G = L.G;
@@ -289,6 +290,13 @@ static int launch_fewrow_nt(const void* A, const void* tiled, const void* bias, 
     dim3 grid((unsigned)((N + 32 * NT - 1) / (32 * NT)), (unsigned)plan.ksplit);
     constexpr size_t lds = (size_t)KW * 8192 * MT;
     static_assert((KW - 1) * MT * NT * 16 * 64 * 4 <= KW * 8192 * MT, "reduction scratch fits in the A buffers");
+    if constexpr (lds > 65536) {
+        static bool attr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_fewrow_kernel<T, KW, NT, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds) == hipSuccess;
+        }();
+        (void)attr;
+    }
     w4_fewrow_kernel<T, KW, NT, MT><<<grid, KW * 64, lds, st>>>((const T*)A, Wt, Sp, M, N, K, (int)G, lda, plan.per,
                                                             (const T*)bias, (T*)C, ldc, part, gate ? 1 : 0);
     const int rc = finish_launch(QL_K_W4_FEWROW);
@@ -301,6 +309,10 @@ static int launch_fewrow_nt(const void* A, const void* tiled, const void* bias, 
 template <typename T>
 static int launch_fewrow(const void* A, const void* tiled, const void* bias, void* C, int M, int N, int K, int64_t lda,
                          int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, bool gate) {
+#ifdef QL_DEV_TUNING
+    if (fewrow_waves() == 16) return launch_fewrow_nt<T, 1, 1, 16>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
+    if (fewrow_waves() == 8) return launch_fewrow_nt<T, 1, 1, 8>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
+#endif
     return launch_fewrow_nt<T, 1, 1>(A, tiled, bias, C, M, N, K, lda, ldc, ws, ws_bytes, st, gate);
 }
 

@@ -1101,6 +1101,7 @@ bool w4_rows_use_gemm(int64_t M, int64_t N, int64_t K) {
 
 size_t w4_packed_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (!w4_rows_use_gemm(M, N, K)) return 0;
+    if (w4_rows16_serves(QL_DTYPE_F16, M, N, K, K)) return 0;   // one launch, no slabs (unaligned rows fall to the few-row kernel, which then runs unsplit)
     return w4_fewrow_supported(M, N, K) ? w4_fewrow_workspace_bytes(M, N, K) : w4_packed_gemm_workspace_bytes(M, N, K);
 }
 
@@ -1117,6 +1118,12 @@ int w4_packed(int dtype, const void* A, const void* packed, const void* bias, vo
     if (w4_rows4_serves(dtype, M, N, K, lda, strict)) {
         const int64_t Npad = (N + 3) & ~(int64_t)3;
         return w4_rows4(dtype, choose_ksplit(Npad / 4, K / 32, (int)M), A, packed, bias, C, M, N, K, lda, ldc, st);
+    }
+    // 3..16 rows: 16x16x32 MFMA on part 1, one launch (w4_rows16.hip; always the reference's rounding sequence)
+    if (w4_rows_use_gemm(M, N, K) && w4_rows16_serves(dtype, M, N, K, K)) {
+        // (the caller was told part 1 serves this call - qlinear_w4g32_rows_on_tiled - and may hold nothing else: no silent detour to part 2)
+        if (lda % 8 != 0 || lda > 0x7fffffff || ((uintptr_t)A & 15) != 0) return QL_ERR_MISALIGNED;
+        return w4_rows16(dtype, A, packed, bias, C, M, N, K, lda, ldc, st);
     }
     // many rows: the MFMA GEMM (always the reference's rounding sequence); it needs 16-byte aligned rows
     if (w4_rows_use_gemm(M, N, K) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16))

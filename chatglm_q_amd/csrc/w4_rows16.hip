@@ -1,0 +1,227 @@
+// int4g32 forward for 3 .. 16 activation rows (batched decode) on PART 1 of the derived layout, gfx950 - round 5.
+//
+// What it replaces at these row counts: w4_fewrow_kernel (w4_fewrow.hip: 32 columns x a K slice per workgroup on part 2, K also split over
+// workgroups into fp32 slabs + splitk_reduce_kernel for every matrix narrower than ~8 k columns).  A batch-8 decode step spent 20 % of its
+// time in those reduce launches and 59 % in kernels running at half the one-row GEMV's byte rate (tools/ab/run_batched_decode_profile.sh).
+// Here the GEMV's execution shape is kept - many small independent waves, every weight byte requested in the wave's first instructions,
+// no cross-workgroup reduction - and the arithmetic goes to v_mfma_f32_16x16x32:
+//   * workgroup = 16 NT output columns x ALL of K, KW waves; wave w walks the 128-k blocks w, w + KW, ... (four int4 groups each);
+//   * lane (n = lane & 15, kq = lane >> 4) requests the 16-byte unit of column n, group 4 blk + kq - straight from part 1 (Wt[n][g]: 64
+//     contiguous bytes per column and request, the 8 waves' blocks contiguous behind each other) - and its scale;
+//   * the block's four MFMAs s = 0 .. 3 contract k = 32 (4 blk + kq) + 8 s .. + 7: the B operand is word s of the lane's unit, dequantised in
+//     registers with the reference's rounding ((n - 8) * s rounded to the activation dtype, chatglm_q/int4/triton_ops.py:72-73); the A
+//     operand is the activation rows' 16 bytes at that k (rows m = lane & 15, clamped to M - 1), read straight from global / L1 - the four
+//     reads of a block touch the same lines;
+//   * requests of a block go out A first, then the unit: they return in order, so block i's arithmetic runs when ITS unit has landed while
+//     the later units are still in flight (D blocks per wave in flight);
+//   * the waves' partial tiles are summed through LDS in a fixed order by 256 NT threads, which also run the epilogue (bias; SiLU * gate
+//     on gate-interleaved columns, chatglm_q/model.py:200-201) - one launch, deterministic.
+// No part 2 needed: a decode-only session (low-footprint mode) serves batched steps from the GEMV's copy.
+#include "launch.h"
+#include "w4_mma.h"
+
+namespace ql {
+
+typedef float r16_f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma16x16;
+template <> struct Mma16x16<f16> {
+    static __device__ __forceinline__ r16_f32x4 mma(f16x8 a, f16x8 b, r16_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma16x16<__bf16> {
+    static __device__ __forceinline__ r16_f32x4 mma(bf16x8 a, bf16x8 b, r16_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, int NT, int KW, bool GATE, int D>
+__global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
+                                                                   int M, int N, int Npad, int G, int lda, const T* __restrict__ bias,
+                                                                   T* __restrict__ C, int64_t ldc) {
+    typedef Mma<T> MM;
+    typedef typename MM::frag frag;
+    // D: blocks of a wave in flight (21 registers per block with one column tile, 26 with two)
+    __shared__ float red[KW][NT][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int nblk = (G + 3) >> 2;                             // 128-k blocks
+    const int mine = wave < nblk ? (nblk - wave + KW - 1) / KW : 0;   // blocks of this wave: wave, wave + KW, ...
+
+    u32 k_mask_lo, k_mask_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
+
+    // per column tile: the lane's column (clamped: loads stay inside part 1, stores are masked), its unit row and scale row
+    const u32x4* wcol[NT];
+    const T* scol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n_raw = ((int)blockIdx.x * NT + t) * 16 + n16;
+        const int n = n_raw < Npad ? n_raw : Npad - 1;
+        wcol[t] = Wt + (int64_t)n * G;
+        scol[t] = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+    }
+    const T* arow = A + (int64_t)(n16 < M ? n16 : M - 1) * lda;   // A operand: row m = lane & 15
+
+    struct Stage {
+        u32x4 a[4];
+        u32x4 w[NT];
+        T s[NT];
+    };
+    auto load_stage = [&](int i, Stage& sg) {                  // the wave's i-th block (clamped past the end: requested, never used)
+        const int blk = wave + KW * (i < mine ? i : (mine > 0 ? mine - 1 : 0));
+        const int g_raw = 4 * blk + kq, g = g_raw < G ? g_raw : G - 1;
+        const T* ap = arow + 32 * g;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sg.a[s] = u32x4{0u, 0u, 0u, 0u};
+        if (n16 < M) {                                         // rows past M: lanes switched off (their output rows are never stored)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sg.a[s] = *reinterpret_cast<const u32x4*>(ap + 8 * s);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sg.w[t] = __builtin_nontemporal_load(wcol[t] + g);   // streamed once
+            sg.s[t] = scol[t][(int64_t)g * 4];
+        }
+    };
+    r16_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = r16_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int i, const Stage& sg) {
+        const int g_raw = 4 * (wave + KW * i) + kq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const T s_eff = g_raw < G ? sg.s[t] : (T)0.f;      // the missing groups of a ragged last block contribute 0
+            const auto sc = MM::scale_pair(&s_eff, true);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[t] = Mma16x16<T>::mma(__builtin_bit_cast(frag, sg.a[s]), MM::dequant(sg.w[t][s], k_mask_lo, k_mask_hi, k_magic, sc), acc[t]);
+        }
+    };
+
+    // bias of the epilogue thread's column(s): requested up front, not in the tail (output e = tid + j KW 64: column e & 15 of tile e >> 8)
+    constexpr int EPT = (256 * NT + KW * 64 - 1) / (KW * 64);   // outputs per thread
+    float bias_v[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * KW * 64;
+        const int n = ((int)blockIdx.x * NT + (e >> 8)) * 16 + (e & 15);
+        bias_v[j] = Act<T>::load((bias ? bias : Sp) + (bias && e < 256 * NT && n < N ? n : 0));
+    }
+    if (mine > 0) {
+        Stage st[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_stage(d, st[d]);
+        int i = 0;
+        for (; i + D < mine; i += D) {                         // steady state: compute block i + d, request block i + d + D into its registers
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                Stage cur = st[d];
+                load_stage(i + d + D, st[d]);
+                compute(i + d, cur);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (i + d < mine) compute(i + d, st[d]);
+    }
+
+    // sum the KW partial tiles in wave order: thread e < 256 NT takes output (row = (e >> 4) & 15, column e & 15) of tile e >> 8
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * KW * 64;
+        if (e >= 256 * NT) break;                              // (wave-uniform: KW 64 and 256 NT are multiples of 64)
+        const int t = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        const int src = (row >> 2) * 16 + col;                 // the lane that holds (row, col): rows 4 q .. 4 q + 3 of column `col`
+        float sum = red[0][t][row & 3][src];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sum += red[w][t][row & 3][src];
+        const int n = ((int)blockIdx.x * NT + t) * 16 + col;
+        if constexpr (GATE) {
+            // SiLU * gate on gate-interleaved columns: columns 4 p, 4 p + 1 hold h, 4 p + 2, 4 p + 3 the gates of the same output pair; C gets
+            // N / 2 columns (N % 4 == 0).  y = rounded sum (+ bias, rounded); out = round(round(silu(y_h)) * y_gate)
+            float y = Act<T>::round(sum);
+            if (bias) y = Act<T>::round(y + bias_v[j]);
+            const float yg = __shfl_down(y, 2);                // every lane takes part
+            if (row < M && n < N && (col & 2) == 0)
+                Act<T>::store(C + (int64_t)row * ldc + ((n >> 2) << 1) + (col & 1), Act<T>::round(Act<T>::round(y / (1.0f + __expf(-y))) * yg));
+        } else {
+            if (row < M && n < N) {                            // store_out's sequence with the preloaded bias
+                float y = Act<T>::round(sum);
+                if (bias) y = y + bias_v[j];
+                Act<T>::store(C + (int64_t)row * ldc + n, y);
+            }
+        }
+    }
+}
+
+// column tiles per workgroup x waves per workgroup x blocks in flight, or nt = 0: not served.  Measured per layer shape against the few-row
+// kernel + its reduce launch (tools/rows16_sweep.py, profiles/r05_rows16_sweep.txt; us at 5 / 8 / 16 rows):
+//   N <= 16 x CUs, K <= 8192 (o_proj 4096 -> 4096: one workgroup per CU, one round)  1 x 8 x 4: 5.6 / 6.1 / 7.2  against 8.4 / 8.4 / 9.3
+//   N <= 32 x CUs, K <= 8192 (qkv_proj 4096 -> 4608)                                 2 x 4 x 3: 7.9 / 8.5 / 9.8  against 9.0 / 9.3 / 10.4
+//   N <= 16 x CUs, K  > 8192 (w_out 13696 -> 4096), up to 8 rows                     1 x 8 x 2: 13.9 / 14.7      against 14.8 / 15.2 (16 rows: 19.7 / 15.8)
+//   wider (w_in 4096 -> 27392): every workgroup re-reads the activation rows for its 16 or 32 columns - 23.7 / 26.3 / 32.0 against 20.0 / 20.3 / 22.3:
+//   the few-row kernel keeps those
+struct Rows16Cfg {
+    int nt, kw, d;
+};
+static Rows16Cfg rows16_cfg(int64_t M, int64_t N, int64_t K) {
+    const int64_t cus = cu_count();
+    Rows16Cfg c{0, 8, 4};
+    if (N <= 16 * cus && K <= 8192) c = {1, 8, 4};
+    else if (N <= 32 * cus && K <= 8192) c = {2, 4, 3};
+    else if (N <= 16 * cus && M <= 8) c = {1, 8, 2};
+    if (QL_TUNE("QLINEAR_ROWS16_NT", 0)) c.nt = QL_TUNE("QLINEAR_ROWS16_NT", 0), c.d = c.nt == 1 ? 4 : 3;
+    if (QL_TUNE("QLINEAR_ROWS16_KW", 0)) c.kw = QL_TUNE("QLINEAR_ROWS16_KW", 0);
+    if (QL_TUNE("QLINEAR_ROWS16_D", 0)) c.d = QL_TUNE("QLINEAR_ROWS16_D", 0);
+    return c;
+}
+
+// 3 .. 16 rows of a 16-bit dtype with 16-byte aligned activation rows, shapes as above; QLINEAR_DISPATCH=norows16: the few-row kernel on part 2
+bool w4_rows16_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda) {
+    const int lo = QL_TUNE("QLINEAR_ROWS16_MIN", 3), hi = QL_TUNE("QLINEAR_ROWS16_MAX", 16);
+    return !(dispatch_flags() & QL_D_NOROWS16) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && M >= lo && M <= hi && N > 0 && K >= 128 &&
+           K % 32 == 0 && lda % 8 == 0 && lda <= 0x7fffffff && rows16_cfg(M, N, K).nt != 0;
+}
+
+template <typename T, int NT, int KW, bool GATE, int D>
+static int launch_rows16_cfg(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc, hipStream_t st) {
+    const W4Layout L = w4_layout(N, K, sizeof(T));
+    const u32x4* Wt = (const u32x4*)packed;
+    const T* Sp = (const T*)((const char*)packed + L.off_sp);
+    w4_rows16_kernel<T, NT, KW, GATE, D><<<(unsigned)((N + 16 * NT - 1) / (16 * NT)), KW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, (int)L.Npad, (int)L.G,
+                                                                                                 (int)lda, (const T*)bias, (T*)C, ldc);
+    return finish_launch(QL_K_W4_ROWS16);
+}
+
+template <typename T, bool GATE>
+static int launch_rows16(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc, hipStream_t st) {
+    const Rows16Cfg c = rows16_cfg(M, N, K);
+#define QL_R16(NT_, KW_, D_) \
+    if (c.nt == NT_ && c.kw == KW_ && c.d == D_) return launch_rows16_cfg<T, NT_, KW_, GATE, D_>(A, packed, bias, C, M, N, K, lda, ldc, st);
+    QL_R16(1, 8, 4) QL_R16(2, 4, 3) QL_R16(1, 8, 2)
+#ifdef QL_DEV_TUNING
+    QL_R16(1, 8, 3) QL_R16(1, 4, 4) QL_R16(1, 2, 4) QL_R16(2, 8, 3) QL_R16(2, 2, 3)
+#endif
+#undef QL_R16
+    return QL_ERR_UNSUPPORTED;
+}
+
+int w4_rows16(int dtype, const void* A, const void* packed, const void* bias, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc,
+              hipStream_t st, bool gate) {
+    if (gate && N % 4 != 0) return QL_ERR_BAD_SHAPE;
+    if (dtype == QL_DTYPE_F16)
+        return gate ? launch_rows16<f16, true>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st)
+                    : launch_rows16<f16, false>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    if (dtype == QL_DTYPE_BF16)
+        return gate ? launch_rows16<__bf16, true>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st)
+                    : launch_rows16<__bf16, false>(A, packed, bias, C, (int)M, (int)N, (int)K, lda, ldc, st);
+    return QL_ERR_BAD_DTYPE;
+}
+
+}  // namespace ql

@@ -111,17 +111,19 @@ uint64_t qlinear_launch_count(void);
 #define QL_K_W8A8_TILED 16      /* w8a8.hip: 64 / 128-row tiles, tile-major copy */
 #define QL_K_W8A8_GEMM256 17    /* w8a8_gemm256.hip */
 #define QL_K_ACT_QUANT 18
+#define QL_K_W4_ROWS16 19       /* w4_rows16.hip: 3..16 rows on v_mfma_f32_16x16x32, part 1, one launch */
 uint64_t qlinear_last_dispatch(void);
 void qlinear_dispatch_reset(void);
 void qlinear_dispatch_reload(void);   /* parse QLINEAR_DISPATCH again (it is read once, at the first dispatch decision) */
 /* The parsed QLINEAR_DISPATCH switches as the library holds them (bit 0 no256, 1 nopeel, 2 nofewrow, 3 norows4, 4 nogroupattn,
- * 5 nohalf, 6 nof32mfma): a host that sizes a workspace or picks an entry point by one of them asks here instead of parsing the variable again. */
+ * 5 nohalf, 6 nof32mfma, 7 norows16): a host that sizes a workspace or picks an entry point by one of them asks here instead of parsing the variable again. */
 unsigned qlinear_dispatch_flags(void);
 
 /* Environment variables read by THIS library (chatglm_q_amd/csrc/tune.h): exactly one,
  *   QLINEAR_DISPATCH = comma list of kernel families the dispatch must not use: no256, nopeel, nofewrow, norows4, nogroupattn,
  *   nohalf (the half-tile last round inside the int4g32 256-tile GEMM's launch: whole tiles only, the older peel where it applies),
- *   nof32mfma (the fp32 matrix-instruction kernel that serves fp32 activations from 128 rows on: the VALU kernels instead)
+ *   nof32mfma (the fp32 matrix-instruction kernel that serves fp32 activations from 128 rows on: the VALU kernels instead),
+ *   norows16 (the one-launch 3..16-row kernel on part 1: the few-row kernel on part 2 instead)
  * (every family has a slower fallback computing the same function; for A/B measurements and triage).  The host package reads
  * QLINEAR_LIB_PATH (another build of this library) and QLINEAR_STRICT (0 / 1 / auto: the per-weight rounding policy, see
  * QL_FLAG_STRICT_ROUNDING) - chatglm_q_amd/_lib.py.  Every other tuning value is a compile-time constant with its measurement
@@ -181,8 +183,11 @@ int qlinear_w4g32_fwd_packed(const void* A, const void* packed, const void* bias
  * The host module (chatglm_q_amd/int4/qlinear.py) builds part 2 on the first forward with >= 3 rows. */
 /* 1 when qlinear_w4g32_fwd_packed serves this call from part 2 (a caller that keeps the parts apart then calls
  * qlinear_w4g32_fwd_tiled), 0 when part 1 does: one or two rows (GEMV), 2..4 rows in the default arithmetic on the 4x4x4
- * matrix instruction while the staged rows stay within 64 KB (w4_rows4.hip), fp32 at any row count. */
+ * matrix instruction while the staged rows stay within 64 KB (w4_rows4.hip), 3..16 rows of the narrow layer shapes on the
+ * 16x16x32 matrix instruction in one launch (w4_rows16.hip: the rule is at rows16_cfg there), fp32 at any row count. */
 int qlinear_w4g32_rows_on_tiled(int64_t M, int64_t N, int64_t K, int dtype, int flags);
+/* The QL_K_* family that serves such a call from part 1 (QL_K_W4_GEMV / QL_K_W4_ROWS4 / QL_K_W4_ROWS16), 0 when part 2 serves it. */
+int qlinear_w4g32_packed_dispatch(int64_t M, int64_t N, int64_t K, int dtype, int flags);
 /* 1 when qlinear_w4g32_fwd_tiled_gated (weight_bits 4) / qlinear_w8_fwd_tiled_gated (weight_bits 8) / qlinear_w8a8_fwd_tiled_gated
  * (weight_bits 88: int8 activations x int8 weights, the ring kernel's own rule) serves M rows of a first MLP
  * projection (N = 2 * hidden outputs) with SiLU * gate in its epilogue, 0 when it would return QL_ERR_UNSUPPORTED for the shape:

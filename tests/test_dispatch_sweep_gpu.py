@@ -36,6 +36,12 @@ SHAPES = {"qkv_proj": (4096, 4608, True, None), "o_proj": (4096, 4096, False, "r
           "lm_head": (4096, 65024, False, None)}            # chatglm_q/model.py:262-263,382: 254 column tiles of 256
 K_OTHER, K_W4_GEMV, K_W4_ROWS4, K_W4_FEWROW, K_W4_GEMM128, K_W4_GEMM256 = 1, 2, 3, 4, 5, 6
 K_SPLITK, K_W8_GEMV, K_W8_FEWROW, K_W8_GEMM128, K_W8_GEMM256 = 9, 10, 11, 12, 13
+K_W4_ROWS16 = 19
+
+
+def part1_family(M, N, K, dtype, strict):
+    """The family that serves a call from part 1 of the derived layout (0: part 2 does) - the library's own table."""
+    return _lib.get_lib().qlinear_w4g32_packed_dispatch(M, N, K, _lib.dtype_code(dtype), 1 if strict else 0)
 M_MAX = 8192
 BASE_M = sorted(set(range(1, 10)) | {15, 16, 17, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 130, 255, 256, 257, 258, M_MAX})
 
@@ -80,7 +86,9 @@ def expected(bits, M, N, K, dtype):
     if bits == 4:
         strict = _lib.strict_for(dtype)
         if not h4.rows_on_tiled(M, N, K, dtype, strict):
-            return [K_W4_GEMV] if (M == 1 or strict) else [K_W4_ROWS4]
+            fam = part1_family(M, N, K, dtype, strict)
+            assert fam in (K_W4_GEMV, K_W4_ROWS4, K_W4_ROWS16) and (fam != K_W4_ROWS4 or not strict) and (fam != K_W4_GEMV or M <= 2 or M > 16)
+            return [fam]
         fam, first = table(4, M, N, K)
         return [fam] + ([K_W4_GEMM128] if first < M else [])
     if M <= 2:
@@ -189,7 +197,7 @@ def check_gated(L, M, y, want, first):
         gp, gb = L.mod.gated_packed(hidden) if part1 else L.mod.gated_tiled(hidden)
         out = h4.w4_forward_gated(x, gp, L.N, gb, part1=part1)
         should = part1 or M <= 32 or serves256
-        fam = K_W4_ROWS4 if part1 else (K_W4_FEWROW if M <= 32 else K_W4_GEMM256)
+        fam = part1_family(M, L.N, L.K, L.dtype, _lib.strict_for(L.dtype)) if part1 else (K_W4_FEWROW if M <= 32 else K_W4_GEMM256)
     else:
         if M <= 2:
             return
@@ -314,12 +322,18 @@ def test_dispatch_override_switches_families(monkeypatch):
     lib = _lib.get_lib()
     K, N = 4096, 4096
     try:
-        monkeypatch.setenv("QLINEAR_DISPATCH", "no256,nofewrow,norows4")
+        monkeypatch.setenv("QLINEAR_DISPATCH", "no256,nofewrow,norows4,norows16")
         lib.qlinear_dispatch_reload()
         assert lib.qlinear_gemm256_serves(8192, N, K) == 0
         assert table(4, 8192, N, K)[0] == K_W4_GEMM128 and table(4, 8, N, K)[0] == K_W4_GEMM128
         assert h4.rows_on_tiled.__wrapped__(3, N, K, torch.float16, False) is True
+        assert part1_family(8, N, K, torch.float16, False) == 0
+        monkeypatch.setenv("QLINEAR_DISPATCH", "norows4")
+        lib.qlinear_dispatch_reload()
+        assert part1_family(3, N, K, torch.float16, False) == K_W4_ROWS16      # 3..4 rows fall to the 16-row kernel, still on part 1
     finally:
         monkeypatch.delenv("QLINEAR_DISPATCH")
         lib.qlinear_dispatch_reload()
     assert lib.qlinear_gemm256_serves(8192, N, K) == 1 and table(4, 8, N, K)[0] == K_W4_FEWROW
+    assert part1_family(8, N, K, torch.float16, False) == K_W4_ROWS16 and part1_family(3, N, K, torch.float16, False) == K_W4_ROWS4
+    assert part1_family(8, 27392, K, torch.float16, False) == 0                # the wide first MLP projection stays on the few-row kernel

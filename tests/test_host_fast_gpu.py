@@ -245,7 +245,7 @@ def test_decode_attention_rope_rejects_a_compacted_mask():
 
 def test_release_frees_and_rebuilds_derived_layouts():
     layer, qw, sc, b = _layer4(1024, 768, "f16", 33)
-    x1, x8 = torch.randn(1, 1024, device=DEV).half(), torch.randn(8, 1024, device=DEV).half()
+    x1, x8 = torch.randn(1, 1024, device=DEV).half(), torch.randn(24, 1024, device=DEV).half()   # (24 rows: past what part 1 serves)
     with torch.no_grad():
         y1, y8 = layer(x1), layer(x8)
     nb = layer.derived_nbytes()

@@ -191,6 +191,68 @@ def test_int4_vs_oracle(M, K, N, dt, has_bias, layout):
         assert O.rel_l2(t2n(out), ref) <= 1.5e-4, O.rel_l2(t2n(out), ref)
 
 
+R16_SHAPES = [(5, 4096, 4096, "f16", False), (16, 4096, 4608, "f16", True), (8, 13696, 4096, "bf16", False), (3, 13696, 4096, "f16", True),
+              (7, 160, 36, "f16", True), (3, 8192, 100, "bf16", True), (11, 416, 4100, "f16", False), (16, 128, 16, "bf16", False), (9, 1056, 8190, "f16", True)]
+
+
+@pytest.mark.parametrize("M,K,N,dt,has_bias", R16_SHAPES)
+def test_int4_rows16_vs_oracle(M, K, N, dt, has_bias, monkeypatch):
+    """Round 5: 3..16 rows of the narrow layer shapes in ONE launch on part 1 (w4_rows16.hip: v_mfma_f32_16x16x32, K split over the waves of a
+    workgroup, reference rounding): o_proj / qkv_proj / w_out shapes, both column-tile configurations, K blocks that end ragged (G % 4 != 0),
+    column tiles past N, bias, bf16 - against the oracle, and against the few-row kernel on part 2 (QLINEAR_DISPATCH=norows16)."""
+    lib = _lib.get_lib()
+    strict = 1 if _lib.strict_for(TDT[dt]) else 0
+    if lib.qlinear_w4g32_packed_dispatch(M, N, K, _lib.dtype_code(TDT[dt]), strict) != 19:
+        assert M <= 4 and not strict        # 2..4 rows in the default arithmetic: the 4x4x4 kernel has them while the rows fit 64 KB
+        monkeypatch.setenv("QLINEAR_DISPATCH", "norows4")
+        lib.qlinear_dispatch_reload()
+        assert lib.qlinear_w4g32_packed_dispatch(M, N, K, _lib.dtype_code(TDT[dt]), strict) == 19
+    qw, sc = _rand_w4(K, N, dt, seed=K * 3 + N)
+    g = torch.Generator().manual_seed(M + 17)
+    a = torch.randn((M, K), generator=g).to(TDT[dt])
+    bias = (torch.randn(N, generator=g) * 0.1).to(TDT[dt]) if has_bias else None
+    ref = O.w4_matmul(t2n(a), qw.numpy(), t2n(sc), None if bias is None else t2n(bias), dtype=dt)
+    qd, sd, ad = qw.to(DEV), sc.to(DEV), a.to(DEV)
+    bd = None if bias is None else bias.to(DEV)
+    packed = h4.repack_w4g32(qd, sd)
+    before = launches()
+    out = h4.w4_forward(ad, qd, sd, bd, packed)
+    assert launches() - before == 1
+    assert_close(out, ref, dt, f"{M}x{K}x{N}")
+    assert O.rel_l2(t2n(out), ref) <= (1.5e-4 if dt == "f16" else 1e-3)
+    try:
+        monkeypatch.setenv("QLINEAR_DISPATCH", "norows16,norows4")
+        lib.qlinear_dispatch_reload()
+        other = h4.w4_forward(ad, qd, sd, bd, packed)
+    finally:
+        monkeypatch.delenv("QLINEAR_DISPATCH")
+        lib.qlinear_dispatch_reload()
+    assert O.rel_l2(t2n(out), t2n(other)) <= (2e-4 if dt == "f16" else 2e-3)      # same rounding sequence, another summation order
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("M,K,hidden,has_bias", [(8, 4096, 2048, False), (5, 1024, 4000, True), (8, 13696, 1024, False), (16, 160, 24, True)])
+def test_int4_rows16_gate_epilogue_equals_separate_ops(M, K, hidden, has_bias, dt):
+    """SiLU * gate in the epilogue of the 3..16-row kernel (part 1 of the gate-interleaved copy, qlinear_w4g32_fwd_packed_gated) against the
+    same kernel without the epilogue followed by silu_mul: same sums, same rounding sequence - bit for bit."""
+    from chatglm_q_amd import fused_ops as F_
+    tdt = TDT[dt]
+    g = torch.Generator(device=DEV).manual_seed(90 + M)
+    layer = q4.DynamicQuantizeLinear(K, 2 * hidden, bias=has_bias, dtype=tdt, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).to(tdt))
+    if has_bias:
+        layer.bias.copy_((torch.randn(2 * hidden, device=DEV, generator=g) * 0.1).to(tdt))
+    x = torch.randn(M, 1, K, device=DEV, generator=g).to(tdt)
+    assert _lib.get_lib().qlinear_w4g32_packed_dispatch(M, 2 * hidden, K, _lib.dtype_code(tdt), 1 if _lib.strict_for(tdt) else 0) == 19
+    gp, gb = layer.gated_packed(hidden)
+    got = h4.w4_forward_gated(x, gp, 2 * hidden, gb, part1=True)
+    with torch.no_grad():
+        want = F_.silu_mul(layer(x), hidden)
+    assert got is not None and got.shape == (M, 1, hidden)
+    assert torch.equal(got, want)
+
+
 G256_SHAPES = [(256, 128, 256, "f16", False), (300, 192, 264, "f16", True), (1000, 4096, 1000, "bf16", False),
                (512, 13696, 520, "f16", False), (2048, 1024, 4608, "bf16", True), (1, 256, 40, "f16", True),
                (777, 320, 36, "f16", False)]
@@ -966,7 +1028,7 @@ def test_int4_derived_parts_are_built_lazily_and_equal_the_single_buffer(dt):
     nb1, nb2 = h4.gemv_nbytes(N, K, tdt), h4.tiled_nbytes(N, K, tdt)
     assert nb1 + nb2 == full.numel() == h4.packed_nbytes(N, K, tdt)
     x1 = torch.randn(1, K).to(tdt).to(DEV)
-    x9 = torch.randn(9, K).to(tdt).to(DEV)
+    x9 = torch.randn(40, K).to(tdt).to(DEV)                 # (past the row counts part 1 serves: 1..2, 2..4, 3..16)
     with torch.no_grad():
         y1 = layer(x1)
     assert layer._packed is not None and layer._packed.numel() == nb1 and layer._tiled is None
@@ -996,19 +1058,23 @@ def test_int4_derived_parts_are_built_lazily_and_equal_the_single_buffer(dt):
 
 def test_int4_rows_on_tiled_is_the_librarys_routing():
     """qlinear_w4g32_rows_on_tiled answers which part of the derived layout a row count needs: part 1 for the GEMV rows
-    and for 2..4 rows in the default arithmetic (4x4x4-MFMA kernel; staged rows up to 64 KB), part 2 above, never for fp32;
-    a part-1-only buffer then really serves exactly the row counts it says."""
+    and for 2..4 rows in the default arithmetic (4x4x4-MFMA kernel; staged rows up to 64 KB), for 3..16 rows of the narrow layer shapes
+    (round 5: the one-launch 16x16x32 kernel, w4_rows16.hip), part 2 above and for the wide shapes, never for fp32; a part-1-only buffer
+    then really serves exactly the row counts it says."""
     f16 = torch.float16
     assert not h4.rows_on_tiled(1, 4096, 4096, f16) and not h4.rows_on_tiled(2, 4096, 13696, f16)
     assert not h4.rows_on_tiled(4, 4096, 4096, f16)              # 4 rows x 8 KB staged
-    assert h4.rows_on_tiled(3, 4096, 13696, f16)                 # 3 rows x 27 KB: few-row MFMA kernel
-    assert h4.rows_on_tiled(5, 4096, 4096, f16) and h4.rows_on_tiled(4096, 4096, 4096, torch.bfloat16)
-    assert h4.rows_on_tiled(3, 4096, 4096, f16, True)            # strict rounding keeps the few-row kernel
+    assert not h4.rows_on_tiled(3, 4096, 13696, f16)             # 3 rows x 27 KB: past the 4x4x4 kernel's staging, the 16-row kernel has them
+    assert h4.rows_on_tiled(16, 4096, 13696, f16)                # ... up to 8 rows at this K (w4_rows16.hip: rows16_cfg)
+    assert not h4.rows_on_tiled(5, 4096, 4096, f16) and not h4.rows_on_tiled(16, 4608, 4096, f16)
+    assert h4.rows_on_tiled(17, 4096, 4096, f16) and h4.rows_on_tiled(5, 27392, 4096, f16)     # few-row MFMA kernel on part 2
+    assert h4.rows_on_tiled(4096, 4096, 4096, torch.bfloat16)
+    assert not h4.rows_on_tiled(3, 4096, 4096, f16, True)        # strict rounding: not the 4x4x4 kernel, the 16-row one (reference rounding)
     assert not h4.rows_on_tiled(64, 4096, 4096, torch.float32)
     K, N = 1024, 264
     qw, sc = _rand_w4(K, N, "f16", 77)
     part1 = h4.repack_w4g32_gemv(qw.to(DEV), sc.to(DEV))
-    for M in (1, 2, 3, 4, 5, 8, 9):
+    for M in (1, 2, 3, 4, 5, 8, 9, 16, 17, 40):
         x = torch.randn(M, K).half().to(DEV)
         if h4.rows_on_tiled(M, N, K, f16):
             with pytest.raises(AssertionError):
