@@ -122,6 +122,14 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
             for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[u][e], v[u][e], ss);
         }
     }
+    // the norm weights do not depend on the row: requested in front of the block reduction, not as a second round trip behind it (few-row
+    // calls are a latency chain: 8 rows 5.1 -> 4.5 us under rocprof)
+    u32x4 wraw[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int i = (threadIdx.x + u * 256) * 8;
+        if constexpr (sizeof(T) == 2) wraw[u] = *reinterpret_cast<const u32x4*>(Wt + (i < dim ? i : 0));
+    }
     ss = block_sum_256(ss, red);
     const float r = rsqrtf(ss / (float)dim + eps);
     float mx = 0.f;
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ X, c
         const int i = (threadIdx.x + u * 256) * 8;
         if (i < dim) {
             float w[8], y[8];
-            load8<T>(Wt + i, w);
+            if constexpr (sizeof(T) == 2) unpack8<T>(wraw[u], w);
+            else load8<T>(Wt + i, w);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float t = v[u][e] * r;
