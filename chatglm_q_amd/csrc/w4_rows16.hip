@@ -32,14 +32,15 @@ template <> struct Mma16x16<__bf16> {
     static __device__ __forceinline__ r16_f32x4 mma(bf16x8 a, bf16x8 b, r16_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T, int NT, int KW, bool GATE, int D>
+template <typename T, int NT, int KW, bool GATE, int D, int MT = 1>
 __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp,
                                                                    int M, int N, int Npad, int G, int lda, const T* __restrict__ bias,
                                                                    T* __restrict__ C, int64_t ldc) {
     typedef Mma<T> MM;
     typedef typename MM::frag frag;
     // D: blocks of a wave in flight (21 registers per block with one column tile, 26 with two)
-    __shared__ float red[KW][NT][4][64];
+    // MT: 16-row tiles (1: up to 16 rows, 2: up to 32 - every weight fragment then feeds two MFMAs)
+    __shared__ float red[KW][MT][NT][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
@@ -61,22 +62,27 @@ __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict_
         wcol[t] = Wt + (int64_t)n * G;
         scol[t] = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
     }
-    const T* arow = A + (int64_t)(n16 < M ? n16 : M - 1) * lda;   // A operand: row m = lane & 15
+    const T* arow[MT];                                         // A operand: row m = 16 mt + (lane & 15)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (int64_t)(16 * mt + n16 < M ? 16 * mt + n16 : M - 1) * lda;
 
     struct Stage {
-        u32x4 a[4];
+        u32x4 a[MT][4];
         u32x4 w[NT];
         T s[NT];
     };
     auto load_stage = [&](int i, Stage& sg) {                  // the wave's i-th block (clamped past the end: requested, never used)
         const int blk = wave + KW * (i < mine ? i : (mine > 0 ? mine - 1 : 0));
         const int g_raw = 4 * blk + kq, g = g_raw < G ? g_raw : G - 1;
-        const T* ap = arow + 32 * g;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) sg.a[s] = u32x4{0u, 0u, 0u, 0u};
-        if (n16 < M) {                                         // rows past M: lanes switched off (their output rows are never stored)
+        for (int mt = 0; mt < MT; ++mt) {
+            const T* ap = arow[mt] + 32 * g;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) sg.a[s] = *reinterpret_cast<const u32x4*>(ap + 8 * s);
+            for (int s = 0; s < 4; ++s) sg.a[mt][s] = u32x4{0u, 0u, 0u, 0u};
+            if (16 * mt + n16 < M) {                           // rows past M: lanes switched off (their output rows are never stored)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sg.a[mt][s] = *reinterpret_cast<const u32x4*>(ap + 8 * s);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -84,9 +90,11 @@ __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict_
             sg.s[t] = scol[t][(int64_t)g * 4];
         }
     };
-    r16_f32x4 acc[NT];
+    r16_f32x4 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = r16_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = r16_f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int i, const Stage& sg) {
         const int g_raw = 4 * (wave + KW * i) + kq;
 #pragma unroll
@@ -94,19 +102,24 @@ __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict_
             const T s_eff = g_raw < G ? sg.s[t] : (T)0.f;      // the missing groups of a ragged last block contribute 0
             const auto sc = MM::scale_pair(&s_eff, true);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc[t] = Mma16x16<T>::mma(__builtin_bit_cast(frag, sg.a[s]), MM::dequant(sg.w[t][s], k_mask_lo, k_mask_hi, k_magic, sc), acc[t]);
+            for (int s = 0; s < 4; ++s) {
+                const frag b = MM::dequant(sg.w[t][s], k_mask_lo, k_mask_hi, k_magic, sc);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][t] = Mma16x16<T>::mma(__builtin_bit_cast(frag, sg.a[mt][s]), b, acc[mt][t]);
+            }
         }
     };
 
-    // bias of the epilogue thread's column(s): requested up front, not in the tail (output e = tid + j KW 64: column e & 15 of tile e >> 8)
-    constexpr int EPT = (256 * NT + KW * 64 - 1) / (KW * 64);   // outputs per thread
+    // bias of the epilogue thread's column(s): requested up front, not in the tail (output e = tid + j KW 64: column e & 15, row 16 mt + ((e >> 4)
+    // & 15) of tile e >> 8 = mt NT + t)
+    constexpr int NOUT = 256 * MT * NT;
+    constexpr int EPT = (NOUT + KW * 64 - 1) / (KW * 64);     // outputs per thread
     float bias_v[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int e = tid + j * KW * 64;
-        const int n = ((int)blockIdx.x * NT + (e >> 8)) * 16 + (e & 15);
-        bias_v[j] = Act<T>::load((bias ? bias : Sp) + (bias && e < 256 * NT && n < N ? n : 0));
+        const int n = ((int)blockIdx.x * NT + ((e >> 8) % NT)) * 16 + (e & 15);
+        bias_v[j] = Act<T>::load((bias ? bias : Sp) + (bias && e < NOUT && n < N ? n : 0));
     }
     if (mine > 0) {
         Stage st[D];
@@ -128,19 +141,21 @@ __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict_
 
     // sum the KW partial tiles in wave order: thread e < 256 NT takes output (row = (e >> 4) & 15, column e & 15) of tile e >> 8
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][t][r][lane] = acc[t][r];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][mt][t][r][lane] = acc[mt][t][r];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int e = tid + j * KW * 64;
-        if (e >= 256 * NT) break;                              // (wave-uniform: KW 64 and 256 NT are multiples of 64)
-        const int t = e >> 8, row = (e >> 4) & 15, col = e & 15;
-        const int src = (row >> 2) * 16 + col;                 // the lane that holds (row, col): rows 4 q .. 4 q + 3 of column `col`
-        float sum = red[0][t][row & 3][src];
+        if (e >= NOUT) break;                                  // (wave-uniform: KW 64 and NOUT are multiples of 64)
+        const int mt = (e >> 8) / NT, t = (e >> 8) % NT, r16 = (e >> 4) & 15, col = e & 15, row = 16 * mt + r16;
+        const int src = (r16 >> 2) * 16 + col;                 // the lane that holds (row, col): rows 4 q .. 4 q + 3 of column `col`
+        float sum = red[0][mt][t][r16 & 3][src];
 #pragma unroll
-        for (int w = 1; w < KW; ++w) sum += red[w][t][row & 3][src];
+        for (int w = 1; w < KW; ++w) sum += red[w][mt][t][r16 & 3][src];
         const int n = ((int)blockIdx.x * NT + t) * 16 + col;
         if constexpr (GATE) {
             // SiLU * gate on gate-interleaved columns: columns 4 p, 4 p + 1 hold h, 4 p + 2, 4 p + 3 the gates of the same output pair; C gets
@@ -184,17 +199,17 @@ static Rows16Cfg rows16_cfg(int64_t M, int64_t N, int64_t K) {
 
 // 3 .. 16 rows of a 16-bit dtype with 16-byte aligned activation rows, shapes as above; QLINEAR_DISPATCH=norows16: the few-row kernel on part 2
 bool w4_rows16_serves(int dtype, int64_t M, int64_t N, int64_t K, int64_t lda) {
-    const int lo = QL_TUNE("QLINEAR_ROWS16_MIN", 3), hi = QL_TUNE("QLINEAR_ROWS16_MAX", 16);
+    const int lo = QL_TUNE("QLINEAR_ROWS16_MIN", 3), hi = QL_TUNE("QLINEAR_ROWS16_MAX", 16);      // (developer build: 32 = the two-tile form, measured below)
     return !(dispatch_flags() & QL_D_NOROWS16) && (dtype == QL_DTYPE_F16 || dtype == QL_DTYPE_BF16) && M >= lo && M <= hi && N > 0 && K >= 128 &&
            K % 32 == 0 && lda % 8 == 0 && lda <= 0x7fffffff && rows16_cfg(M, N, K).nt != 0;
 }
 
-template <typename T, int NT, int KW, bool GATE, int D>
+template <typename T, int NT, int KW, bool GATE, int D, int MT = 1>
 static int launch_rows16_cfg(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc, hipStream_t st) {
     const W4Layout L = w4_layout(N, K, sizeof(T));
     const u32x4* Wt = (const u32x4*)packed;
     const T* Sp = (const T*)((const char*)packed + L.off_sp);
-    w4_rows16_kernel<T, NT, KW, GATE, D><<<(unsigned)((N + 16 * NT - 1) / (16 * NT)), KW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, (int)L.Npad, (int)L.G,
+    w4_rows16_kernel<T, NT, KW, GATE, D, MT><<<(unsigned)((N + 16 * NT - 1) / (16 * NT)), KW * 64, 0, st>>>((const T*)A, Wt, Sp, M, N, (int)L.Npad, (int)L.G,
                                                                                                  (int)lda, (const T*)bias, (T*)C, ldc);
     return finish_launch(QL_K_W4_ROWS16);
 }
@@ -204,6 +219,18 @@ static int launch_rows16(const void* A, const void* packed, const void* bias, vo
     const Rows16Cfg c = rows16_cfg(M, N, K);
 #define QL_R16(NT_, KW_, D_) \
     if (c.nt == NT_ && c.kw == KW_ && c.d == D_) return launch_rows16_cfg<T, NT_, KW_, GATE, D_>(A, packed, bias, C, M, N, K, lda, ldc, st);
+#ifdef QL_DEV_TUNING
+    // two 16-row tiles (QLINEAR_ROWS16_MAX=32; tools/rows16_mt2_check.py): correct (1e-5 of the few-row kernel), and slower than it - o_proj at
+    // 17 / 24 / 32 rows 11.4 / 13.1 / 15.0 us against 10.1 / 10.3 / 11.1, qkv_proj 11.7 / 12.1 / 12.8 against 10.8 / 11.4 / 12.6: the activation rows every
+    // workgroup reads grow with M, the few-row kernel's staged tiles do not.  Not in the product.
+    if (M > 16) {
+        if (c.nt == 1 && c.kw == 8) return launch_rows16_cfg<T, 1, 8, GATE, 3, 2>(A, packed, bias, C, M, N, K, lda, ldc, st);
+        if (c.nt == 2 && c.kw == 4) return launch_rows16_cfg<T, 2, 4, GATE, 2, 2>(A, packed, bias, C, M, N, K, lda, ldc, st);
+        return QL_ERR_UNSUPPORTED;
+    }
+#else
+    if (M > 16) return QL_ERR_UNSUPPORTED;
+#endif
     QL_R16(1, 8, 4) QL_R16(2, 4, 3) QL_R16(1, 8, 2)
 #ifdef QL_DEV_TUNING
     QL_R16(1, 8, 3) QL_R16(1, 4, 4) QL_R16(1, 2, 4) QL_R16(2, 8, 3) QL_R16(2, 2, 3)
