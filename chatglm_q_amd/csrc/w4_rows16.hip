@@ -175,13 +175,132 @@ __global__ __launch_bounds__(KW * 64) void w4_rows16_kernel(const T* __restrict_
     }
 }
 
+// ---- WIDE matrices (a first MLP projection: 27 392 columns): the activation rows in LDS, no K split ---------------------------------------------
+// With one workgroup per 16 / 32 columns every workgroup re-reads the M x K activation rows (224 MB of L2 -> L1 traffic at 16 rows against 63 MB
+// of weights, and the lanes' 16-byte pieces of 16 different rows cost four address-unit passes per request).  Here a workgroup of 8 waves stages
+// the rows ONCE into LDS (row pitch 2 K + 16 bytes: the 16 rows of a fragment read fall into 16 different 16-byte bank groups) and every wave
+// then owns 16 columns over ALL of K: no partial tiles, no reduction, the epilogue runs from the accumulator registers (column n of rows 4 q ..
+// 4 q + 3 per lane; the SiLU * gate partner column n + 2 is two lanes away).  A block's requests are the unit and its scale only (5 registers):
+// eight blocks per wave in flight.  Measured level with the few-row kernel (see rows16_cfg below): its point is the layout, not the time.
+template <typename T, bool GATE, int D>
+__global__ __launch_bounds__(512) void w4_rows16w_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt, const T* __restrict__ Sp, int M, int N,
+                                                         int Npad, int G, int lda, const T* __restrict__ bias, T* __restrict__ C, int64_t ldc) {
+    typedef Mma<T> MM;
+    typedef typename MM::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char a_lds[];   // M rows x (2 K + 16) bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int K = G * 32, pitch = 2 * K + 16;
+    const int nblk = (G + 3) >> 2;
+
+    u32 k_mask_lo, k_mask_hi, k_magic;
+    asm volatile("s_mov_b32 %0, 0x000F000F" : "=s"(k_mask_lo));
+    asm volatile("s_mov_b32 %0, 0x00F000F0" : "=s"(k_mask_hi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(k_magic) : "i"(MM::kMagic));
+
+    // (1) the activation rows: 16-byte chunks, consecutive lanes consecutive chunks of a row - requested first (they come from L2 / the
+    // memory-side cache, are needed first, and requests return in order), then (2) the first D blocks of this wave's 16 columns, and only then
+    // the rows go to LDS: the weight stream is under way while they arrive
+    const int cpr = K / 8, chunks = M * cpr;                  // chunks per row, in all
+    constexpr int SR = 16;                                     // staging requests per thread and pass (16 rows x 4096: one pass)
+    int m0 = tid / cpr, k0 = tid - m0 * cpr;                   // chunk tid: row, 16-byte column (stepped by 512 below: no more divisions)
+    auto stage_request = [&](u32x4 (&stg)[SR], int (&dst)[SR], int c0, int& m, int& k8) {
+#pragma unroll
+        for (int u = 0; u < SR; ++u) {
+            const bool ok = c0 + tid + 512 * u < chunks;
+            const int mm = ok ? m : M - 1, kk = ok ? k8 : 0;
+            stg[u] = *reinterpret_cast<const u32x4*>(A + (int64_t)mm * lda + 8 * kk);
+            dst[u] = ok ? mm * pitch + 16 * kk : -1;
+            k8 += 512;
+            while (k8 >= cpr) k8 -= cpr, ++m;
+        }
+    };
+    auto stage_store = [&](const u32x4 (&stg)[SR], const int (&dst)[SR]) {
+#pragma unroll
+        for (int u = 0; u < SR; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<u32x4*>(a_lds + dst[u]) = stg[u];
+    };
+    u32x4 stg[SR];
+    int dst[SR];
+    stage_request(stg, dst, 0, m0, k0);
+    const int n_raw = ((int)blockIdx.x * 8 + wave) * 16 + n16;
+    const int n = n_raw < Npad ? n_raw : Npad - 1;
+    const u32x4* wcol = Wt + (int64_t)n * G;
+    const T* scol = Sp + ((int64_t)(n >> 2) * G) * 4 + (n & 3);
+    const float bias_v = Act<T>::load((bias ? bias : Sp) + (bias && n_raw < N ? n_raw : 0));
+    struct Stage {
+        u32x4 w;
+        T s;
+    };
+    auto load_stage = [&](int i, Stage& sg) {
+        const int blk = i < nblk ? i : nblk - 1;
+        const int g_raw = 4 * blk + kq, g = g_raw < G ? g_raw : G - 1;
+        sg.w = __builtin_nontemporal_load(wcol + g);
+        sg.s = scol[(int64_t)g * 4];
+    };
+    Stage st[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_stage(d, st[d]);
+    stage_store(stg, dst);
+    for (int c0 = 512 * SR; c0 < chunks; c0 += 512 * SR) {     // (more than 64 K activation values: further passes behind the first units)
+        stage_request(stg, dst, c0, m0, k0);
+        stage_store(stg, dst);
+    }
+    // the rows are in LDS; NOT __syncthreads(): its fence would wait for the units in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const char* arow = a_lds + (n16 < M ? n16 : M - 1) * pitch + 64 * kq;   // A operand: row lane & 15, + 256 blk + 16 s
+    r16_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int i, const Stage& sg) {
+        const int g_raw = 4 * i + kq;
+        const T s_eff = g_raw < G ? sg.s : (T)0.f;
+        const auto sc = MM::scale_pair(&s_eff, true);
+        const char* ap = arow + 256 * i - (g_raw < G ? 0 : 64 * (g_raw - (G - 1)));   // (a ragged last block: stay inside the row)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            acc = Mma16x16<T>::mma(__builtin_bit_cast(frag, *reinterpret_cast<const u32x4*>(ap + 16 * s)),
+                                   MM::dequant(sg.w[s], k_mask_lo, k_mask_hi, k_magic, sc), acc);
+    };
+    int i = 0;
+    for (; i + D < nblk; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const Stage cur = st[d];
+            load_stage(i + d + D, st[d]);
+            compute(i + d, cur);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (i + d < nblk) compute(i + d, st[d]);
+
+    // epilogue from registers: lane (n16, q) holds rows 4 q .. 4 q + 3 of its column
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        float y = Act<T>::round(acc[r]);
+        if constexpr (GATE) {
+            if (bias) y = Act<T>::round(y + bias_v);
+            const float yg = __shfl_down(y, 2);                // the gate of the same output pair: column n + 2
+            if (row < M && n_raw < N && (n16 & 2) == 0)
+                Act<T>::store(C + (int64_t)row * ldc + ((n_raw >> 2) << 1) + (n16 & 1), Act<T>::round(Act<T>::round(y / (1.0f + __expf(-y))) * yg));
+        } else {
+            if (bias) y = y + bias_v;
+            if (row < M && n_raw < N) Act<T>::store(C + (int64_t)row * ldc + n_raw, y);
+        }
+    }
+}
+
 // column tiles per workgroup x waves per workgroup x blocks in flight, or nt = 0: not served.  Measured per layer shape against the few-row
 // kernel + its reduce launch (tools/rows16_sweep.py, profiles/r05_rows16_sweep.txt; us at 5 / 8 / 16 rows):
 //   N <= 16 x CUs, K <= 8192 (o_proj 4096 -> 4096: one workgroup per CU, one round)  1 x 8 x 4: 5.6 / 6.1 / 7.2  against 8.4 / 8.4 / 9.3
 //   N <= 32 x CUs, K <= 8192 (qkv_proj 4096 -> 4608)                                 2 x 4 x 3: 7.9 / 8.5 / 9.8  against 9.0 / 9.3 / 10.4
 //   N <= 16 x CUs, K  > 8192 (w_out 13696 -> 4096), up to 8 rows                     1 x 8 x 2: 13.9 / 14.7      against 14.8 / 15.2 (16 rows: 19.7 / 15.8)
-//   wider (w_in 4096 -> 27392): every workgroup re-reads the activation rows for its 16 or 32 columns - 23.7 / 26.3 / 32.0 against 20.0 / 20.3 / 22.3:
-//   the few-row kernel keeps those
+//   wider (w_in 4096 -> 27392): every workgroup re-reads the activation rows for its 16 or 32 columns - 23.7 / 26.3 / 32.0 against 20.0 / 20.3 / 22.3;
+//   with the rows in LDS (w4_rows16w_kernel, nt = -1; rows x (2 K + 16) bytes must fit 160 KB): 21.5 / 21.0 / 21.5 against 21.3 / 21.5 / 22.6 - level
+//   with the few-row kernel (both are ~8 us of dequant VALU beside a 10 us stream that do not overlap: profiles/r05_w_in_fewrows_pmc.txt); what it
+//   buys is that part 2 is not needed for these row counts
 struct Rows16Cfg {
     int nt, kw, d;
 };
@@ -191,6 +310,7 @@ static Rows16Cfg rows16_cfg(int64_t M, int64_t N, int64_t K) {
     if (N <= 16 * cus && K <= 8192) c = {1, 8, 4};
     else if (N <= 32 * cus && K <= 8192) c = {2, 4, 3};
     else if (N <= 16 * cus && M <= 8) c = {1, 8, 2};
+    else if (N > 32 * cus && M * (2 * K + 16) <= 160 * 1024 && QL_TUNE("QLINEAR_ROWS16_WIDE", 1)) c = {-1, 8, 8};   // wide: the rows in LDS (w4_rows16w_kernel)
     if (QL_TUNE("QLINEAR_ROWS16_NT", 0)) c.nt = QL_TUNE("QLINEAR_ROWS16_NT", 0), c.d = c.nt == 1 ? 4 : 3;
     if (QL_TUNE("QLINEAR_ROWS16_KW", 0)) c.kw = QL_TUNE("QLINEAR_ROWS16_KW", 0);
     if (QL_TUNE("QLINEAR_ROWS16_D", 0)) c.d = QL_TUNE("QLINEAR_ROWS16_D", 0);
@@ -217,6 +337,19 @@ static int launch_rows16_cfg(const void* A, const void* packed, const void* bias
 template <typename T, bool GATE>
 static int launch_rows16(const void* A, const void* packed, const void* bias, void* C, int M, int N, int K, int64_t lda, int64_t ldc, hipStream_t st) {
     const Rows16Cfg c = rows16_cfg(M, N, K);
+    if (c.nt < 0) {
+        const W4Layout L = w4_layout(N, K, sizeof(T));
+        const int lds = M * (2 * K + 16);
+        static bool attr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&w4_rows16w_kernel<T, GATE, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024) == hipSuccess;
+        }();
+        (void)attr;
+        w4_rows16w_kernel<T, GATE, 8><<<(unsigned)((N + 127) / 128), 512, (size_t)lds, st>>>(
+            (const T*)A, (const u32x4*)packed, (const T*)((const char*)packed + L.off_sp), M, N, (int)L.Npad, (int)L.G, (int)lda, (const T*)bias, (T*)C,
+            ldc);
+        return finish_launch(QL_K_W4_ROWS16);
+    }
 #define QL_R16(NT_, KW_, D_) \
     if (c.nt == NT_ && c.kw == KW_ && c.d == D_) return launch_rows16_cfg<T, NT_, KW_, GATE, D_>(A, packed, bias, C, M, N, K, lda, ldc, st);
 #ifdef QL_DEV_TUNING

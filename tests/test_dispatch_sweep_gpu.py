@@ -336,4 +336,5 @@ def test_dispatch_override_switches_families(monkeypatch):
         lib.qlinear_dispatch_reload()
     assert lib.qlinear_gemm256_serves(8192, N, K) == 1 and table(4, 8, N, K)[0] == K_W4_FEWROW
     assert part1_family(8, N, K, torch.float16, False) == K_W4_ROWS16 and part1_family(3, N, K, torch.float16, False) == K_W4_ROWS4
-    assert part1_family(8, 27392, K, torch.float16, False) == 0                # the wide first MLP projection stays on the few-row kernel
+    assert part1_family(8, 27392, K, torch.float16, False) == K_W4_ROWS16      # the wide first MLP projection: rows in LDS, still part 1
+    assert part1_family(16, 27392, 2 * K, torch.float16, False) == 0           # ... while they fit: otherwise the few-row kernel on part 2

@@ -1067,7 +1067,9 @@ def test_int4_rows_on_tiled_is_the_librarys_routing():
     assert not h4.rows_on_tiled(3, 4096, 13696, f16)             # 3 rows x 27 KB: past the 4x4x4 kernel's staging, the 16-row kernel has them
     assert h4.rows_on_tiled(16, 4096, 13696, f16)                # ... up to 8 rows at this K (w4_rows16.hip: rows16_cfg)
     assert not h4.rows_on_tiled(5, 4096, 4096, f16) and not h4.rows_on_tiled(16, 4608, 4096, f16)
-    assert h4.rows_on_tiled(17, 4096, 4096, f16) and h4.rows_on_tiled(5, 27392, 4096, f16)     # few-row MFMA kernel on part 2
+    assert not h4.rows_on_tiled(16, 27392, 4096, f16)            # the wide first MLP projection: activation rows in LDS (w4_rows16w_kernel)
+    assert h4.rows_on_tiled(17, 4096, 4096, f16) and h4.rows_on_tiled(17, 27392, 4096, f16)    # few-row MFMA kernel on part 2
+    assert h4.rows_on_tiled(16, 27392, 8192, f16)                # ... and where 16 rows x 8192 do not fit the LDS
     assert h4.rows_on_tiled(4096, 4096, 4096, torch.bfloat16)
     assert not h4.rows_on_tiled(3, 4096, 4096, f16, True)        # strict rounding: not the 4x4x4 kernel, the 16-row one (reference rounding)
     assert not h4.rows_on_tiled(64, 4096, 4096, torch.float32)

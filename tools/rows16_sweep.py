@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 env0 = dict(os.environ, QLINEAR_LIB_PATH="chatglm_q_amd/csrc/libqlinear_hip_dev.so")
 print("us at M = 3 5 8 16")
-for name, extra in [("few-row kernel (part 2)", {"QLINEAR_DISPATCH": "norows16"})] + [
+for name, extra in [("few-row kernel (part 2)", {"QLINEAR_DISPATCH": "norows16"}), ("product rule", {}), ("product rule, no wide kernel", {"QLINEAR_ROWS16_WIDE": "0"})] + [
         (f"rows16 NT={nt} KW={kw} D={d or 'default'}", {"QLINEAR_ROWS16_NT": str(nt), "QLINEAR_ROWS16_KW": str(kw), "QLINEAR_ROWS16_D": str(d)})
         for nt, kw, d in ((1, 8, 0), (1, 8, 3), (1, 8, 2), (1, 4, 0), (2, 8, 0), (2, 4, 0))]:
     r = subprocess.run([sys.executable, __file__, "child"], env=dict(env0, **extra), capture_output=True, text=True, timeout=600)
