@@ -289,6 +289,33 @@ def test_decode_only_session_frees_prefill_layouts_and_decodes_the_same():
     assert w_in.derived_nbytes()["tiled"] == 0 and w_in.derived_nbytes()["packed"] == 0 and w_in.derived_nbytes()["gated"] > 0
 
 
+def test_decode_only_session_serves_a_batch_of_8_from_part_1_alone():
+    """Round 5: 3..16 rows run on part 1 of the derived layout (w4_rows16.hip), so a decode-only session that dropped the tile-major copies
+    after its prefill decodes a batch of 8 without rebuilding them - and chooses the same tokens as a session that kept everything."""
+    model, cfg = _tiny()
+    ids = torch.randint(0, 320, (8, 12), device=DEV)
+
+    def run(decode_only):
+        for m in model.modules():
+            if hasattr(m, "invalidate"):
+                m.invalidate()
+        sess = DecodeSession(model, 8, 64, use_graph=True, decode_only=decode_only)
+        lg = sess.prefill(ids)                                   # 96 rows: part 2 of every layer
+        sess.tok.copy_(lg.argmax(-1, keepdim=True))
+        sess.capture(greedy=True)
+        out = [sess.tok.flatten().tolist()]
+        for _ in range(5):
+            sess.decode_step(greedy=True)
+            out.append(sess.tok.flatten().tolist())
+        tiled = sum(m.derived_nbytes()["tiled"] + m.derived_nbytes()["gated_tiled"] for m in model.modules() if hasattr(m, "derived_nbytes"))
+        return out, tiled
+
+    want, tiled_full = run(False)
+    got, tiled_lean = run(True)
+    assert got == want
+    assert tiled_full > 0 and tiled_lean == 0
+
+
 # ---- quantising producers (round 3): RMSNorm / SiLU * gate emit the int8 rows + scales of the int8-activation GEMM behind them ----
 @pytest.mark.parametrize("rows,dim", [(5, 4096), (1, 256), (37, 1024), (3, 13696 // 2), (2, 16384), (9, 264)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
