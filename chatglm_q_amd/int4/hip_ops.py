@@ -349,7 +349,7 @@ def w4_forward_gated(a: Tensor, gated: Tensor, n_out: int, bias: Tensor | None, 
     """Few rows through a gate-interleaved first MLP projection with SiLU * gate in the kernel's epilogue: (..., K) ->
     (..., n_out / 2).  ``gated``: part 2 of the gate-interleaved copy (``DynamicQuantizeLinear.gated_tiled``; 3..32 rows,
     ``qlinear_w4g32_fwd_tiled_gated``) or, with ``part1``, its part 1 (``gated_packed``; the row counts for which
-    ``rows_on_tiled`` is False, ``qlinear_w4g32_fwd_packed_gated`` -> the 4x4x4-MFMA kernel).  None when the library does
+    ``rows_on_tiled`` is False, ``qlinear_w4g32_fwd_packed_gated`` -> the 4x4x4-MFMA kernel at 2..4 rows, the 16x16x32 one-launch kernels at 3..16).  None when the library does
     not serve the shape that way (the caller then runs the projection and ``silu_mul`` separately)."""
     lib = _lib.get_lib()
     K = a.shape[-1]

@@ -341,7 +341,7 @@ class DynamicQuantizeLinear(nn.Module):
 
     @torch.no_grad()
     def gated_tiled(self, hidden: int):
-        """Part 2 of the gate-interleaved copy (batched decode, 3..32 rows: qlinear_w4g32_fwd_tiled_gated), built on first
+        """Part 2 of the gate-interleaved copy (the row counts ``rows_on_tiled`` gives to part 2: qlinear_w4g32_fwd_tiled_gated), built on first
         use.  Returns (tiled, bias_or_None)."""
         packed, bias = self.gated_packed(hidden)
         key = self._gated_key

@@ -96,7 +96,7 @@ uint64_t qlinear_launch_count(void);
 #define QL_K_OTHER 1            /* repacks, norms, attention, embeddings, quantisers, ... */
 #define QL_K_W4_GEMV 2          /* w4_packed.hip: 1..2 rows (4 per pass), part 1 */
 #define QL_K_W4_ROWS4 3         /* w4_rows4.hip: 2..4 rows on v_mfma_f32_4x4x4, part 1 */
-#define QL_K_W4_FEWROW 4        /* w4_fewrow.hip: 3..32 rows, part 2 */
+#define QL_K_W4_FEWROW 4        /* w4_fewrow.hip: 3..32 rows not served by QL_K_W4_ROWS16, part 2 */
 #define QL_K_W4_GEMM128 5       /* w4_gemm.hip: 32..128-row tiles, part 2 (+ QL_K_SPLITK_REDUCE for few rows) */
 #define QL_K_W4_GEMM256 6       /* w4_gemm256.hip: 256 x 256 tiles, part 2 */
 #define QL_K_W4_CANON 7         /* w4_kernels.hip: canonical layout, split-K */
