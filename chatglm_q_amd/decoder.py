@@ -49,6 +49,7 @@ def filtered_distribution(logits: Tensor, top_k: int = 100, top_p: float = 0.8, 
 
 
 # hook of the developer experiments (chatglm_q_amd/dev/experiments.py); None in the product
+AHEAD_LAUNCH = True           # greedy graph decoding launches step k + 1 before reading token k (ChatGLMDecoder._generate)
 POST_GENERATE_CHECK = None
 
 class DecodeSession:
@@ -449,7 +450,39 @@ class ChatGLMDecoder:
             sess.tok.fill_(token)
             sess.capture(greedy=greedy)
         pending = []
-        while len(generated) < budget and (ignore_eos or generated[-1] != self.eos_token_id):
+        # Greedy decoding on a captured step: the graph feeds its own argmax back, so step k + 1 does not wait for the HOST to have seen
+        # token k.  It is launched before token k is read (one step of speculation: wasted - and harmless, the next prefill re-arms the
+        # session - when token k turns out to be the end token), so the device never idles for the host's read-back + launch latency
+        # (~20 us of a 1.15 ms token).  Tokens are yielded one by one as before.
+        ahead = (greedy and not device_loop and sess.graph is not None and sess.device.type == "cuda" and AHEAD_LAUNCH
+                 and len(generated) < budget and (ignore_eos or token != self.eos_token_id))
+        if ahead:
+            ring = torch.empty((2, 1), dtype=torch.long).pin_memory()
+            events = [torch.cuda.Event(), torch.cuda.Event()]
+
+            def launch(k):
+                sess.decode_step(None, greedy=True)
+                ring[k & 1].copy_(sess.tok.view(-1), non_blocking=True)
+                events[k & 1].record()
+
+            t0 = time.perf_counter()
+            k = 0
+            launch(0)
+            while True:
+                more = len(generated) + 1 < budget and sess.length + 1 <= sess.capacity     # a token after this one is wanted (and fits)
+                if more:
+                    launch(k + 1)
+                events[k & 1].synchronize()
+                token = int(ring[k & 1, 0])
+                now = time.perf_counter()
+                times.append(now - t0)
+                t0 = now
+                generated.append(token)
+                yield token
+                if not more or (not ignore_eos and token == self.eos_token_id):
+                    break
+                k += 1
+        while not ahead and len(generated) < budget and (ignore_eos or generated[-1] != self.eos_token_id):
             t0 = time.perf_counter()
             if device_loop:
                 # the graph feeds its own argmax back as the next input: the host only replays

@@ -175,6 +175,34 @@ def test_graph_is_recaptured_when_the_weights_move():
     assert dec._session.graph is not g1
 
 
+def test_launch_ahead_greedy_decoding_yields_the_same_tokens_and_stops_at_the_end_token(monkeypatch):
+    """Round 5: on a captured greedy step generate_ids launches step k + 1 before it reads token k (the graph feeds its own argmax back).  Same
+    tokens as the launch-read-launch loop and as the eager loop; with an end token the generation stops AT it (the speculative step behind it is
+    thrown away), a following generation on the same session is unaffected, and the budget / the cache's end are respected."""
+    from chatglm_q_amd import decoder as Dm
+    model, cfg = _tiny()
+    prefix = [3, 17, 200, 5, 77]
+    kw = dict(max_generated_tokens=12, greedy=True, ignore_eos=True)
+    eager = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, **kw))
+    monkeypatch.setattr(Dm, "AHEAD_LAUNCH", False)
+    plain = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=True, **kw))
+    monkeypatch.setattr(Dm, "AHEAD_LAUNCH", True)
+    dec = ChatGLMDecoder(None, model)
+    ahead = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    assert ahead == plain == eager and len(ahead) == 12
+    stop = 5
+    if eager[stop] not in eager[:stop]:                       # an end token in the middle: stop at it, in both loops
+        dec_eos = ChatGLMDecoder(None, model, eos_token_id=eager[stop])
+        assert list(dec_eos.generate_ids(prefix, max_generated_tokens=12, greedy=True, use_graph=True)) == eager[:stop + 1]
+        assert list(dec_eos.generate_ids(prefix, max_generated_tokens=12, greedy=True, use_graph=True)) == eager[:stop + 1]   # session reused
+    assert list(dec.generate_ids(prefix, use_graph=True, **kw)) == eager                         # ... and after a full run
+    assert list(dec.generate_ids(prefix, max_generated_tokens=1, greedy=True, ignore_eos=True, use_graph=True)) == eager[:1]
+    assert list(dec.generate_ids(prefix, max_generated_tokens=2, greedy=True, ignore_eos=True, use_graph=True)) == eager[:2]
+    full = cfg.max_sequence_length - len(prefix)               # up to the cache's last row
+    out = list(dec.generate_ids(prefix, max_generated_tokens=10 ** 6, greedy=True, ignore_eos=True, use_graph=True))
+    assert len(out) == full and out[:12] == eager
+
+
 def test_two_live_generators_do_not_share_a_session():
     model, cfg = _tiny()
     dec = ChatGLMDecoder(None, model)
