@@ -14,3 +14,6 @@ for rep in range(4):
         Dm.AHEAD_LAUNCH = flag
         list(dec.generate_ids(prompt, max_generated_tokens=200, greedy=True, ignore_eos=True, use_graph=True))
         print("ahead" if flag else "plain", round(dec.last_stats["gen_tok_per_s"], 1), flush=True)
+for rep in range(3):                                       # upper bound: no read-back at all until the end (sync_every_token=False)
+    list(dec.generate_ids(prompt, max_generated_tokens=200, greedy=True, ignore_eos=True, use_graph=True, sync_every_token=False))
+    print("device loop (read back at the end)", round(dec.last_stats["gen_tok_per_s"], 1), flush=True)
