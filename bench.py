@@ -600,6 +600,8 @@ def main():
         if isinstance(e2e.get("graph_sync_every_token"), dict):
             # second half of BASELINE.json's metric: ChatGLM2-6B int4g32 decode tok/s (reference timing definition)
             result["decode_tok_per_s"] = e2e["graph_sync_every_token"]["gen_tok_per_s"]
+            if isinstance(e2e.get("sampled_default"), dict):      # the reference's default generate(): top-k / top-p sampling per token
+                result["decode_tok_per_s_sampled_default"] = e2e["sampled_default"]["gen_tok_per_s"]
             # the figures that can still move: a whole token's QLinear bytes against the HBM peak
             result["roofline"]["decode_tok_per_s_frac_of_ceiling"] = round(result["decode_tok_per_s"] / DECODE_CEILING_TOK_S, 4)
             result["roofline"]["decode_ceiling_tok_per_s"] = DECODE_CEILING_TOK_S

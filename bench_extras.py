@@ -551,6 +551,21 @@ def e2e_generate(torch, device):
                       "gen_tok_per_s": round(s["gen_tok_per_s"], 1), "avg_tok_per_s": round(s["avg_tok_per_s"], 1),
                       "linear_GBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 1e9, 1),
                       "linear_frac_of_8TBps": round(s["gen_tok_per_s"] * LINEAR_BYTES_PER_TOKEN / 8e12, 4)}
+    # The reference's ONLY decoding mode (chatglm_q/decoder.py:85: top_p_sampling(top_k 100, top_p 0.8, T 1.0) per token) = the default call of
+    # generate_ids: "sampled_default" runs it as one launch inside the captured step (csrc/sampler.hip, round 6), "sampled_host_torch" as round 5
+    # ran it - the composed torch ops (a 65 024-wide sort among them) on the host's side of the loop with an H2D copy of the token per step.
+    for kw in (dict(use_graph=True, seed=1), dict(use_graph=True, device_sampler=False)):
+        list(dec.generate_ids(prompt, max_generated_tokens=8, ignore_eos=True, **kw))
+    for label, kw in [("sampled_default", dict(use_graph=True, seed=20260930)),
+                      ("sampled_default_device_loop", dict(use_graph=True, seed=20260930, sync_every_token=False)),
+                      ("sampled_host_torch", dict(use_graph=True, device_sampler=False))]:
+        toks = list(dec.generate_ids(prompt, max_generated_tokens=128, ignore_eos=True, **kw))      # greedy=False: the default
+        streams[label] = toks
+        s = dec.last_stats
+        out[label] = {"generated": len(toks), "gen_tok_per_s": round(s["gen_tok_per_s"], 1), "avg_tok_per_s": round(s["avg_tok_per_s"], 1),
+                      "distinct_tokens": len(set(toks))}
+    out["sampled_default"]["vs_greedy"] = round(out["sampled_default"]["gen_tok_per_s"] / out["graph_sync_every_token"]["gen_tok_per_s"], 4)
+    out["sampled_default"]["same_tokens_in_device_loop"] = streams["sampled_default"] == streams["sampled_default_device_loop"]
     # correctness of what was just timed: the three modes emit one token stream, and the logits of a fused
     # graph-replayed step agree with the same model run through plain torch ops around eager QLinear launches
     out["check"] = {"graph_equals_device_loop": streams["graph_sync_every_token"] == streams["graph_device_loop"],
@@ -558,7 +573,8 @@ def e2e_generate(torch, device):
                     "fused_graph_step_vs_plain_torch_graph_rel_l2": _fused_vs_plain(torch, model, prompt)}
     out["resident_bytes"] = _resident_bytes(model)
     out["drop_in_reference_graph"] = drop_in_generate(torch, model, prompt)
-    out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, greedy, fp16, synthetic weights"
+    out["workload"] = ("ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, 128 generated tokens, fp16, synthetic weights; greedy legs + the "
+                       "reference's default sampler (sampled_*)")
     # chunked prefill, BASELINE config 5: seq 2048 x batch 4, chunks of 2048 positions (M = 8192 rows per forward: every projection on
     # the 256 x 256-tile GEMM; attention = one launch per layer, csrc/prefill_attention.hip; tools/prefill_chunks.py, round 3:
     # 0.127 / 0.107 / 0.095 / 0.092 s for chunks of 256 / 512 / 1024 / 2048 - with the GEMM-route attention 0.153 / 0.131 / 0.122 / 0.130)

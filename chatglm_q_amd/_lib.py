@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QLINEAR_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip.so")
 # product + experiments + tuning knobs as environment variables; QLINEAR_DEV_LIB_PATH: another developer build (tools/ab/)
 DEV_LIB_PATH = os.environ.get("QLINEAR_DEV_LIB_PATH") or os.path.join(_HERE, "csrc", "libqlinear_hip_dev.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
@@ -128,6 +128,8 @@ EXPORTS = {
                                                         c_int64, c_int64, c_void_p]),
     "qlinear_greedy_advance": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_int, c_void_p]),
+    "qlinear_top_p_sample": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "qlinear_masked_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64,
                                        c_int, c_void_p]),
     "qlinear_silu_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),

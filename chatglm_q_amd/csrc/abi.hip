@@ -756,4 +756,19 @@ int qlinear_greedy_advance(const void* logits, int64_t B, int64_t N, int64_t ldl
     return greedy_advance(dtype, logits, B, N, ldl, tok, write_index, pos, mask, capacity, (hipStream_t)stream);
 }
 
+int qlinear_top_p_sample(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t top_k, float top_p, float temperature,
+                         const float* dev_params, uint64_t* rng_state, int64_t* tok, int64_t* write_index, int64_t* pos, float* mask,
+                         int64_t capacity, float* probs_out, int64_t* index_out, float* u_out, int64_t out_ld, int dtype, void* stream) {
+    if (!logits || !tok) return QL_ERR_NULL_POINTER;
+    if (!dtype_ok(dtype)) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(B) || !fits_i32(N) || ldl < N) return QL_ERR_BAD_SHAPE;
+    const bool book = write_index || pos || mask;
+    if (book && !(write_index && pos && mask)) return QL_ERR_NULL_POINTER;
+    if (book && !fits_i32(capacity)) return QL_ERR_BAD_SHAPE;
+    if ((probs_out == nullptr) != (index_out == nullptr)) return QL_ERR_NULL_POINTER;
+    if (probs_out && (out_ld < (top_k < N ? top_k : N) || !fits_i32(out_ld))) return QL_ERR_BAD_SHAPE;
+    return top_p_sample(dtype, logits, B, N, ldl, top_k, top_p, temperature, dev_params, rng_state, tok, write_index, pos, mask,
+                        capacity, probs_out, index_out, u_out, out_ld, (hipStream_t)stream);
+}
+
 }  // extern "C"

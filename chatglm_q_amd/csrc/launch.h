@@ -273,6 +273,11 @@ int masked_softmax(int dtype, const void* Sc, const float* mask, void* P, int64_
 int greedy_advance(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
                    int64_t* pos, float* mask, int64_t capacity, hipStream_t st);
 
+// sampler.hip: top-k / top-p sampling + the step's bookkeeping in one launch (chatglm_q/decoder.py:12-27)
+int top_p_sample(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t top_k, float top_p, float temperature,
+                 const float* dparams, uint64_t* rng_state, int64_t* tok, int64_t* write_index, int64_t* pos, float* mask,
+                 int64_t capacity, float* probs_out, int64_t* index_out, float* u_out, int64_t out_ld, hipStream_t st);
+
 // prefill_attention.hip: many-position attention in one launch (D = 128, H = 16 G, fp16 / bf16)
 int prefill_attention(int dtype, const void* Q, const void* Kc, const void* Vc, const float* mask, const uint8_t* flags, void* Out,
                       int64_t B, int64_t S, int64_t Tkv, int64_t H, int64_t G, int64_t cap, int64_t ldm, hipStream_t st);

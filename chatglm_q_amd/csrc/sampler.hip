@@ -1,0 +1,474 @@
+// The reference's decoding mode - top-k / top-p sampling (chatglm_q/decoder.py:12-27, called by generate() at :85) - as ONE launch
+// behind lm_head, so that the sampled step can live in the captured HIP graph like the greedy one (greedy_advance_kernel):
+//
+//     probs = softmax(logits.float() / temperature)              fp32
+//     probs, indices = sort(probs, descending)[:top_k]           ties: lowest index first (a stable sort)
+//     probs[(cumsum(probs) - probs) > top_p] = 0
+//     probs /= probs.sum()
+//     token = indices[multinomial(probs, 1)]
+//
+// One workgroup of 1024 threads per logits row, which is walked twice (the second time from L2): (1) scale / maxima, (2) exp-sum +
+// collection of every value >= a first threshold into LDS.  No sort of the row, nothing of it kept in registers (64 values per thread
+// at 1024 threads per workgroup = the whole register budget: hipcc spilled 66 registers per lane):
+//   * first threshold t0 = min over G >= top_k lane groups of the group's maximum: at least G distinct values are >= t0, and for
+//     logits in no particular order only ~G ln G are (a few hundred of 65 024);
+//   * the k-th largest of THOSE is found by a histogram select in ordered-key space on the LDS list (256 bins between the bounds,
+//     repeated on the crossing bin until at most top_k + 28 values are left or the bin is one key wide);
+//   * the finalists are ranked by counting ((value desc, index asc) is a strict total order), the top k land sorted in LDS;
+//   * one wave does cumsum / top-p cut / renormalisation and one inverse-CDF draw from a counter-based generator (Philox4x32-10,
+//     key = seed, counter = the row's own draw counter in device memory: a replayed graph draws fresh numbers).
+// Rows that defeat the first threshold (sorted logits, most of the row at -inf, huge tie groups: more than 2048 values >= t0) take
+// an exact bisection instead, one walk over the row per step - slow (tens of microseconds) and still exact, ties by lowest index.
+// The bookkeeping of a decode step (token -> tok, pos += 1, write_index += 1, unmask the new position) is greedy_advance_kernel's.
+#include "launch.h"
+#include "ql_common.h"
+
+namespace ql {
+namespace {
+
+constexpr int SB = 1024;        // threads per workgroup
+constexpr int SU = 8;           // 16-byte chunks a thread requests before it uses the first
+constexpr int S_CAP = 2048;     // LDS candidate list
+constexpr int S_KMAX = 1024;    // largest top_k served
+constexpr int S_SLACK = 28;     // refinement stops at top_k + S_SLACK finalists
+
+struct SamplerShared {
+    float cx[S_CAP];            // candidates: every value >= the first threshold, unordered
+    int ci[S_CAP];
+    u32 fk[S_CAP];              // finalists (ordered key >= the refined threshold), unordered
+    int fi[S_CAP];
+    float sx[S_KMAX];           // the top k in order
+    int si[S_KMAX];
+    int hist[256];
+    float wmax[16], wmin[16], wsum[16];
+    int wcnt[16];
+    int cnt, fcnt, cross_bin, cross_above;
+};
+
+// float -> u32 with the same order (and -0 == +0); NaN sorts above +inf, where torch.sort(descending) puts it
+__device__ __forceinline__ u32 okey(float x) {
+    x += 0.0f;
+    const u32 b = f32_as_u32(x);
+    return b ^ ((u32)((int)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float okey_inv(u32 k) { return u32_as_f32((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+__device__ __forceinline__ float wave_min_dpp(float v) { return -wave_max_dpp(-v); }
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// sum over the block, result in every thread (two barriers: the scratch may be reused right away)
+__device__ __forceinline__ int block_sum_i(int v, int* wcnt) {
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wcnt[w];
+    __syncthreads();
+    return t;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> first output word
+__device__ __forceinline__ u32 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_chunk8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        unpack8<T>(*reinterpret_cast<const u32x4*>(p), v);
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+}
+
+// x = logit / temperature in fp32 (chatglm_q/decoder.py:14): q = l r, one residual correction (r = 1 / T rounded once): the quotient
+// rounded to nearest but for rare half-ulp cases, at 3 instructions per logit instead of the ~10 of the full division sequence
+struct Scale {
+    float t, r;
+    bool on;
+    __device__ __forceinline__ float operator()(float l) const {
+        if (!on) return l;
+        const float q = l * r;
+        const float y = __builtin_fmaf(__builtin_fmaf(-t, q, l), r, q);
+        return (y == y) ? y : q;                             // infinities: the residual is inf - inf
+    }
+};
+
+// One walk over a logits row by the whole workgroup: chunk c (logits 8 c .. 8 c + 7) belongs to thread c % 1024 of round c / 1024;
+// SU chunks per thread are requested before the first is used.  f(c, v): the chunk's scaled values, -inf past the row's end.
+template <typename T, typename F>
+__device__ __forceinline__ void walk_row(const T* __restrict__ row, int N, const Scale& sc, F f) {
+    const int nch = (N + 7) >> 3, tid = threadIdx.x;
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    for (int c0 = 0; c0 < nch; c0 += SU * SB) {
+        float v[SU][8];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int c = c0 + u * SB + tid;
+            if (vec && c * 8 + 8 <= N) {
+                load_chunk8<T>(row + c * 8, v[u]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = c * 8 + e < N ? Act<T>::load(row + c * 8 + e) : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int c = c0 + u * SB + tid;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = sc(v[u][e]);
+                f(c, v[u]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ logits, int N, int64_t ldl, int top_k_h, float top_p_h,
+                                                          float temperature_h, const float* __restrict__ dparams,
+                                                          unsigned long long* __restrict__ rng, int64_t* __restrict__ tok,
+                                                          int64_t* __restrict__ write_index, int64_t* __restrict__ pos,
+                                                          float* __restrict__ mask, int capacity, float* __restrict__ probs_out,
+                                                          int64_t* __restrict__ index_out, float* __restrict__ u_out, int out_ld) {
+    __shared__ SamplerShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T* row = logits + (int64_t)blockIdx.x * ldl;
+
+    // parameters: device-resident ones (a captured graph serves any setting) override the launch's
+    int k = top_k_h;
+    float top_p = top_p_h, temperature = temperature_h;
+    if (dparams) { k = (int)dparams[0]; top_p = dparams[1]; temperature = dparams[2]; }
+    k = k < 1 ? 1 : k;
+    k = k > S_KMAX ? S_KMAX : k;
+    k = k > N ? N : k;
+    const Scale sc = {temperature, 1.0f / temperature, temperature != 1.0f};
+
+    // ---- pass 1: thread maxima -> the row's maximum M and the first threshold t0 --------------------------------------------------
+    float tm = -INFINITY;
+    walk_row<T>(row, N, sc, [&](int, const float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tm = fmaxf(tm, v[e]);
+    });
+    // lanes per group: the largest power of two that still leaves 1024 / gl >= k groups
+    int gl = 1;
+    while (gl < 64 && SB / (gl * 2) >= k) gl *= 2;
+    float gm = tm;
+    for (int off = 1; off < gl; off <<= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+    {
+        const float wmx = wave_max_dpp(tm), wmn = wave_min_dpp(gm);
+        if (lane == 0) { sh.wmax[wv] = wmx; sh.wmin[wv] = wmn; }
+        if (tid == 0) sh.cnt = 0;
+    }
+    __syncthreads();
+    float M = sh.wmax[0], t0 = sh.wmin[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { M = fmaxf(M, sh.wmax[w]); t0 = fminf(t0, sh.wmin[w]); }
+
+    // ---- pass 2 (the row again, from L2): softmax denominator + every value >= t0 into the LDS list -----------------------------
+    constexpr float L2E = 1.4426950408889634f;
+    const float mb = -M * L2E;                               // exp(x - M) = 2^(x L2E - M L2E): one fma + v_exp_f32; the rounding of M L2E
+    float z = 0.f;                                           // is one common factor of every term and leaves p = e / Z alone
+    walk_row<T>(row, N, sc, [&](int c, const float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            z += __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], L2E, mb));
+            if (v[e] >= t0 && c * 8 + e < N) {
+                const int p = atomicAdd(&sh.cnt, 1);
+                if (p < S_CAP) { sh.cx[p] = v[e]; sh.ci[p] = c * 8 + e; }
+            }
+        }
+    });
+    z = wave_sum(z);
+    if (lane == 0) sh.wsum[wv] = z;
+    __syncthreads();
+    float Z = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) Z += sh.wsum[w];
+    int cnt = sh.cnt;
+    u32 lo = okey(t0);
+    const u32 kmax = okey(M);
+
+    // ---- the rare rows: more than S_CAP values >= t0.  Exact bisection, one walk over the row per step ---------------------------
+    if (cnt > S_CAP) {                                       // uniform
+        u32 hi = kmax;                                       // invariant: count(key >= lo) >= k > count(key > hi)
+        int c_lo = cnt;
+        while (lo < hi && c_lo > S_CAP) {
+            const u32 mid = lo + ((hi - lo - 1) >> 1) + 1;   // lo < mid <= hi
+            int n = 0;
+            walk_row<T>(row, N, sc, [&](int c, const float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) n += (okey(v[e]) >= mid && c * 8 + e < N) ? 1 : 0;
+            });
+            n = block_sum_i(n, sh.wcnt);
+            if (n >= k) { lo = mid; c_lo = n; } else hi = mid - 1;
+        }
+        __syncthreads();
+        if (tid == 0) sh.cnt = 0;
+        __syncthreads();
+        if (c_lo <= S_CAP) {                                 // every value >= lo fits the list
+            walk_row<T>(row, N, sc, [&](int c, const float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (okey(v[e]) >= lo && c * 8 + e < N) {
+                        const int p = atomicAdd(&sh.cnt, 1);
+                        sh.cx[p] = v[e]; sh.ci[p] = c * 8 + e;
+                    }
+            });
+            __syncthreads();
+            cnt = sh.cnt;
+        } else {                                             // lo == hi: the k-th value itself, tied more than S_CAP times
+            int gt = 0;                                      // everything above it (fewer than k) ...
+            walk_row<T>(row, N, sc, [&](int c, const float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (okey(v[e]) > lo && c * 8 + e < N) {
+                        const int p = atomicAdd(&sh.cnt, 1);
+                        sh.cx[p] = v[e]; sh.ci[p] = c * 8 + e;
+                        ++gt;
+                    }
+            });
+            gt = block_sum_i(gt, sh.wcnt);
+            const int need_t = k - gt;                       // ... plus that many of the ties, lowest indices first: rounds of 1024
+            const int nch = (N + 7) >> 3;                    // chunks in thread order are index order
+            int base = 0;
+            for (int c0 = 0; c0 < nch && base < need_t; c0 += SB) {
+                const int c = c0 + tid;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = c * 8 + e < N ? sc(Act<T>::load(row + c * 8 + e)) : -INFINITY;
+                int n = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) n += (okey(v[e]) == lo && c * 8 + e < N) ? 1 : 0;
+                int inc = n;                                 // inclusive scan over the wave, then over the waves
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += o;
+                }
+                if (lane == 63) sh.wcnt[wv] = inc;
+                __syncthreads();
+                int before = base, total = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { before += w < wv ? sh.wcnt[w] : 0; total += sh.wcnt[w]; }
+                int p = before + inc - n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (okey(v[e]) == lo && c * 8 + e < N) {
+                        if (p < need_t) { sh.cx[gt + p] = v[e]; sh.ci[gt + p] = c * 8 + e; }
+                        ++p;
+                    }
+                base += total;
+                __syncthreads();
+            }
+            cnt = k;
+        }
+    }
+
+    // ---- histogram select on the list: the k-th largest key --------------------------------------------------------------------
+    {
+        u32 hi = kmax;
+        int need = k, above = 0;
+        u32 tk;
+        int F;
+        while (true) {                                        // every quantity that steers the loop is block-uniform
+            const u32 span = hi - lo;
+            const int shift = span < 256u ? 0 : (32 - __builtin_clz(span)) - 8;
+            if (tid < 256) sh.hist[tid] = 0;
+            __syncthreads();
+            for (int p = tid; p < cnt; p += SB) {
+                const u32 key = okey(sh.cx[p]);
+                if (key >= lo && key <= hi) atomicAdd(&sh.hist[(key - lo) >> shift], 1);
+            }
+            __syncthreads();
+            if (wv == 0) {                                    // suffix sums S(b) = hist[b] + hist[b + 1] + ...: lane l owns bins 4 l .. 4 l + 3
+                const int h0 = sh.hist[4 * lane], h1 = sh.hist[4 * lane + 1], h2 = sh.hist[4 * lane + 2], h3 = sh.hist[4 * lane + 3];
+                const int mine = h0 + h1 + h2 + h3;
+                int suf = mine;                               // inclusive suffix scan over the lanes
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(suf, off, 64);
+                    if (lane + off < 64) suf += o;
+                }
+                const int after = suf - mine;                 // bins right of mine
+                const int s3 = after + h3, s2 = s3 + h2, s1 = s2 + h1, s0 = s1 + h0;
+                // the crossing bin b*: the highest b with S(b) >= need (S does not increase with b; S(0) >= need)
+                if (s0 >= need && after < need) {
+                    int b, ab;
+                    if (s3 >= need) { b = 3; ab = after; }
+                    else if (s2 >= need) { b = 2; ab = s3; }
+                    else if (s1 >= need) { b = 1; ab = s2; }
+                    else { b = 0; ab = s1; }
+                    sh.cross_bin = 4 * lane + b;
+                    sh.cross_above = ab;                      // S(b* + 1)
+                }
+            }
+            __syncthreads();
+            const int b = sh.cross_bin, ab = sh.cross_above, hb = sh.hist[b];
+            tk = lo + ((u32)b << shift);
+            F = above + ab + hb;
+            if (F <= k + S_SLACK || shift == 0) break;
+            above += ab;
+            need -= ab;
+            const unsigned long long top = (unsigned long long)tk + ((1ull << shift) - 1ull);
+            lo = tk;
+            hi = top < (unsigned long long)hi ? (u32)top : hi;
+            __syncthreads();                                  // hist / cross_* are rewritten by the next round
+        }
+
+        // ---- finalists (key >= tk) compacted, ranked by counting; the top k land in order ---------------------------------------
+        if (tid == 0) sh.fcnt = 0;
+        __syncthreads();
+        for (int p = tid; p < cnt; p += SB) {
+            const u32 key = okey(sh.cx[p]);
+            if (key >= tk) {
+                const int q = atomicAdd(&sh.fcnt, 1);
+                sh.fk[q] = key; sh.fi[q] = sh.ci[p];
+            }
+        }
+        __syncthreads();
+        F = sh.fcnt;
+        int tpe = 1;                                          // threads per finalist (a power of two: groups stay inside a wave)
+        while (tpe < 64 && tpe * 2 * F <= SB) tpe *= 2;
+        const int per_round = SB / tpe;
+        for (int e0 = 0; e0 < F; e0 += per_round) {           // uniform trip count
+            const int ent = e0 + tid / tpe, part = tid & (tpe - 1);
+            int r = 0;
+            u32 myk = 0;
+            int myi = 0;
+            if (ent < F) {
+                myk = sh.fk[ent]; myi = sh.fi[ent];
+                for (int j = part; j < F; j += tpe) {
+                    const u32 kj = sh.fk[j];
+                    const int ij = sh.fi[j];
+                    r += (kj > myk || (kj == myk && ij < myi)) ? 1 : 0;
+                }
+            }
+            for (int off = 1; off < tpe; off <<= 1) r += __shfl_xor(r, off, 64);
+            if (ent < F && part == 0 && r < k) { sh.sx[r] = okey_inv(myk); sh.si[r] = myi; }
+        }
+        __syncthreads();
+    }
+
+    // ---- one wave: probabilities, cumulative sums, top-p cut, renormalisation, the draw ---------------------------------------------
+    if (wv == 0) {
+        const int per = (k + 63) >> 6;                        // lane l owns sorted entries per * l .. per * l + per - 1
+        float p[S_KMAX / 64], c[S_KMAX / 64];
+        float run = 0.f;
+#pragma unroll
+        for (int i = 0; i < S_KMAX / 64; ++i) {
+            p[i] = 0.f;
+            if (i < per) {                                    // uniform
+                const int j = per * lane + i;
+                if (j < k) p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sh.sx[j], L2E, mb)) / Z;
+                run += p[i];
+            }
+            c[i] = run;
+        }
+        float inc = run;                                      // cumsum(probs): the lanes' totals scanned, the lane's own run added
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        const float excl = inc - run;
+        float kept = 0.f;
+        int nkept = 0;
+#pragma unroll
+        for (int i = 0; i < S_KMAX / 64; ++i) {
+            const int j = per * lane + i;
+            c[i] += excl;
+            const bool keep = (i < per && j < k) && !((c[i] - p[i]) > top_p);
+            if (!keep) p[i] = 0.f;
+            kept += p[i];
+            nkept += keep ? 1 : 0;
+        }
+        const float s = wave_sum(kept);
+        nkept = wave_sum_i(nkept);                            // the kept entries are a prefix of the order (cumsum - p does not decrease)
+        // one uniform draw; the row's own counter advances by one per launch
+        float uni = 0.f;
+        if (lane == 0) {
+            const unsigned long long seed = rng ? rng[0] : 0ull, ctr = rng ? rng[1 + blockIdx.x] : 0ull;
+            if (rng) rng[1 + blockIdx.x] = ctr + 1ull;
+            const u32 r = philox4x32_10((u32)ctr, (u32)(ctr >> 32), blockIdx.x, 0u, (u32)seed, (u32)(seed >> 32));
+            uni = (float)(r >> 8) * 0x1p-24f;
+        }
+        uni = __shfl(uni, 0, 64);
+        const float target = uni * s;                         // inverse CDF on the un-normalised kept mass: entry j with cum(j-1) <= u s < cum(j)
+        int jstar = 0x7fffffff;
+#pragma unroll
+        for (int i = S_KMAX / 64 - 1; i >= 0; --i) {
+            const int j = per * lane + i;
+            if (p[i] > 0.f && c[i] > target) jstar = j;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(jstar, off, 64);
+            jstar = o < jstar ? o : jstar;
+        }
+        if (jstar >= nkept) jstar = nkept > 0 ? nkept - 1 : 0;   // u s rounded up to the whole mass: the last kept entry
+        if (probs_out) {
+#pragma unroll
+            for (int i = 0; i < S_KMAX / 64; ++i)
+                if (i < per) {
+                    const int j = per * lane + i;
+                    if (j < k) {
+                        probs_out[(int64_t)blockIdx.x * out_ld + j] = p[i] / s;
+                        index_out[(int64_t)blockIdx.x * out_ld + j] = sh.si[j];
+                    }
+                }
+        }
+        if (lane == 0) {
+            if (u_out) u_out[blockIdx.x] = uni;
+            tok[blockIdx.x] = sh.si[jstar];
+            if (pos) pos[blockIdx.x] += 1;
+            if (write_index && blockIdx.x == 0) {             // the shared write index and every row's mask: one writer (greedy_advance_kernel)
+                const int64_t nw = write_index[0] + 1;
+                write_index[0] = nw;
+                if (mask && nw < capacity)
+                    for (int b = 0; b < (int)gridDim.x; ++b) mask[(int64_t)b * capacity + nw] = 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int top_p_sample(int dtype, const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t top_k, float top_p, float temperature,
+                 const float* dparams, uint64_t* rng_state, int64_t* tok, int64_t* write_index, int64_t* pos, float* mask,
+                 int64_t capacity, float* probs_out, int64_t* index_out, float* u_out, int64_t out_ld, hipStream_t st) {
+    if (!logits || !tok) return QL_ERR_NULL_POINTER;
+    if (B < 1 || N < 1 || ldl < N) return QL_ERR_BAD_SHAPE;
+    if (N > (int64_t)1 << 30) return QL_ERR_UNSUPPORTED;
+    if (!dparams && (top_k < 1 || !(temperature > 0.f))) return QL_ERR_BAD_SHAPE;
+    if (!dparams && top_k > S_KMAX && N > S_KMAX) return QL_ERR_UNSUPPORTED;
+    if ((probs_out == nullptr) != (index_out == nullptr)) return QL_ERR_BAD_SHAPE;
+    switch (dtype) {
+#define QL_SAMPLE(TT)                                                                                                              \
+    top_p_sample_kernel<TT><<<(unsigned)B, SB, 0, st>>>((const TT*)logits, (int)N, ldl, (int)(top_k > S_KMAX ? S_KMAX : top_k), top_p, \
+                                                        temperature, dparams, (unsigned long long*)rng_state, tok, write_index, pos, \
+                                                        mask, (int)capacity, probs_out, index_out, u_out, (int)out_ld)
+    case QL_DTYPE_F32: QL_SAMPLE(float); break;
+    case QL_DTYPE_F16: QL_SAMPLE(f16); break;
+    case QL_DTYPE_BF16: QL_SAMPLE(__bf16); break;
+#undef QL_SAMPLE
+    default: return QL_ERR_BAD_DTYPE;
+    }
+    return finish_launch();
+}
+
+}  // namespace ql

@@ -7,8 +7,10 @@ Counterpart of the reference's ``ChatGLMDecoder.generate`` and ``top_p_sampling`
 MI355X-first differences (results unchanged):
   * the key/value cache is preallocated and a decode step is shape-static, so ONE step - 113 QLinear
     launches plus the small ops around them - is captured in a HIP graph and replayed per token; the
-    position counter, the cache write index, the attention mask and (for greedy decoding) the argmax and
-    the next input id are all updated on the device inside that graph, so the host only replays it;
+    position counter, the cache write index, the attention mask, the choice of the next token - the
+    reference's top-k / top-p sampler (``qlinear_top_p_sample``: one launch, counter-based generator in
+    device memory) or the argmax - and the next input id are all updated on the device inside that
+    graph, so the host only replays it;
   * lm_head is evaluated for the last position only (the loop uses nothing else, decoder.py:85);
   * prefill can be chunked (`prefill_chunk`), each chunk one forward over batch x chunk rows.
 Text handling (tokenizer, chat template, punctuation fix-ups) is out of scope: the loop works on token ids;
@@ -83,8 +85,14 @@ class DecodeSession:
         self.pad_cols = torch.zeros(batch, capacity, dtype=torch.bool, device=dev)   # left-padding columns (never attended)
         self.n_tokens = torch.zeros(batch, dtype=torch.long, device=dev)             # real tokens per sequence so far
         self.logits: Optional[Tensor] = None
-        self.graph = None
+        self.graph = None                                       # the captured step of the mode last asked for ...
+        self._graphs = {}                                       # ... of every mode captured under the current layouts
+        self._captured_mode = None
         self._graph_key = None
+        # the device sampler's state (chatglm_q/decoder.py:12-27 inside the captured step): top_k / top_p / temperature and the
+        # generator's (seed, per-row draw counter) live in device memory, so one captured graph serves every setting and every seed
+        self.sample_params = torch.tensor([100.0, 0.8, 1.0], dtype=torch.float32, device=dev)
+        self.rng_state = torch.zeros(1 + batch, dtype=torch.long, device=dev)
         self.length = 0
         self.busy = False                                       # a generate_ids generator is running on this session
 
@@ -149,10 +157,40 @@ class DecodeSession:
         return logits[:, -1]
 
     # -- one decode step -------------------------------------------------------------------------------
-    def _step_body(self, greedy: bool):
+    def set_sampling(self, top_k: int = 100, top_p: float = 0.8, temperature: float = 1.0, seed: Optional[int] = None):
+        """Arm the device sampler: its parameters and (seed given) a fresh generator state - draw counters back to 0."""
+        if top_k < 1 or not temperature > 0:
+            raise ValueError("top_k >= 1 and temperature > 0")
+        self.sample_params.copy_(torch.tensor([float(top_k), float(top_p), float(temperature)], dtype=torch.float32))
+        if seed is not None:
+            st = torch.zeros(1 + self.batch, dtype=torch.long)
+            st[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+            self.rng_state.copy_(st)
+
+    def device_sampler_serves(self, top_k: int) -> bool:
+        """The one-launch sampler runs on a GPU for top_k <= 1024 (or a vocabulary that small); otherwise the composed torch ops."""
+        from . import fused_ops
+        return self.device.type == "cuda" and (top_k <= fused_ops.SAMPLER_MAX_TOP_K
+                                               or self.model.config.vocab_size <= fused_ops.SAMPLER_MAX_TOP_K)
+
+    def sample_first(self, logits: Tensor) -> Tensor:
+        """The token after a prefill, drawn by the device sampler from the prefill's last-position logits (no bookkeeping: prefill
+        armed the step state).  Returns the (batch,) device tensor; ``tok`` holds it as the next step's input."""
+        from . import fused_ops
+        lg = logits if logits.stride(-1) == 1 else logits.contiguous()
+        fused_ops.top_p_sample(lg, self.tok.view(-1), self.rng_state, dev_params=self.sample_params)
+        return self.tok.view(-1)
+
+    def _step_body(self, greedy: bool, sample: bool = False):
         # invariant on entry: mask is 0 for positions <= write_index (the new position may attend to itself)
         logits = self.model.step(self.tok, self.cache, self.write_index, self.pos, self.mask, last_only=True)
         self.logits = logits[:, -1]
+        if sample:                                              # the reference's sampler + the bookkeeping: one launch
+            from . import fused_ops
+            lg = self.logits if self.logits.stride(-1) == 1 else self.logits.contiguous()
+            fused_ops.top_p_sample(lg, self.tok.view(-1), self.rng_state, dev_params=self.sample_params,
+                                   write_index=self.write_index, pos=self.pos.view(-1), mask=self.mask)
+            return
         if greedy and self.logits.is_cuda and self.logits.stride(-1) == 1:
             from . import fused_ops
             fused_ops.greedy_advance(self.logits, self.tok, self.write_index, self.pos, self.mask)   # one launch
@@ -209,42 +247,59 @@ class DecodeSession:
                             getattr(m, "act_quant", None)))
         return tuple(key)
 
+    @staticmethod
+    def _mode(greedy: bool, sample: bool) -> str:
+        return "sample" if sample else ("greedy" if greedy else "logits")
+
+    @property
+    def _captured_greedy(self):                                 # kept for the developer tools that read it
+        return self._captured_mode == "greedy"
+
     @torch.no_grad()
-    def capture(self, greedy: bool = True):
-        """Capture one decode step (or keep the captured one while nothing it bakes in has changed)."""
+    def capture(self, greedy: bool = True, sample: bool = False):
+        """Capture one decode step of the mode - "sample": the device sampler picks the next token, "greedy": the argmax does,
+        "logits": the host decides - or keep the captured one while nothing it bakes in has changed.  Graphs of several modes live
+        side by side (a decoder that alternates greedy and sampled generations captures each once)."""
         if not self.use_graph:
             return
         from . import _lib
-        if self.graph is not None:
+        mode = self._mode(greedy, sample)
+        if self._graphs:
             # cheap test first (a process-wide counter every derived-layout build / drop bumps), the full fingerprint when it moved
-            if self._captured_greedy == greedy and (self._graph_epoch == _lib.layout_epoch() and
-                                                    self._graph_versions == self._canonical_versions()):
-                return                                          # a reused session keeps its graph (static addresses)
-            if self._captured_greedy == greedy and self._graph_key == self._layout_fingerprint():
+            valid = self._graph_epoch == _lib.layout_epoch() and self._graph_versions == self._canonical_versions()
+            if not valid and self._graph_key == self._layout_fingerprint():
                 self._graph_epoch, self._graph_versions = _lib.layout_epoch(), self._canonical_versions()
+                valid = True
+            if not valid:
+                self._graphs.clear()                            # weights / layouts moved under the graphs: re-capture
+                self.graph = self._captured_mode = None
+            elif mode in self._graphs:
+                self.graph, self._captured_mode = self._graphs[mode], mode   # a reused session keeps its graphs (static addresses)
                 return
-            self.graph = None                                   # weights / layouts moved under the graph: re-capture
         if self.decode_only:
             self.release_prefill_layouts()
-        saved = (self.tok.clone(), self.write_index.clone(), self.pos.clone(), self.mask.clone())
+        saved = (self.tok.clone(), self.write_index.clone(), self.pos.clone(), self.mask.clone(), self.rng_state.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
-            self._step_body(greedy)                             # warm-up: allocations, lazy repacks
+            self._step_body(greedy, sample)                     # warm-up: allocations, lazy repacks
             # the warm-up built what the step reads (e.g. the gate-interleaved copy of w_in): what it made redundant goes now,
             # and the step runs once more so that every pre-bound launch exists before the capture
             if self.decode_only and self.release_prefill_layouts():
-                self._step_body(greedy)
+                self._step_body(greedy, sample)
             if self.low_footprint and self.drop_canonical():
-                self._step_body(greedy)                         # the pre-bound launches re-validate against the stand-in buffers
+                self._step_body(greedy, sample)                 # the pre-bound launches re-validate against the stand-in buffers
         torch.cuda.current_stream(self.device).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._step_body(greedy)
+        if self._graphs and self._graph_epoch != _lib.layout_epoch():
+            self._graphs.clear()                                # this mode's warm-up rebuilt / dropped a layout the older graphs baked in
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_body(greedy, sample)
         # capture ran the body twice on live state: restore (the cache rows it touched get rewritten)
-        for dst, src in zip((self.tok, self.write_index, self.pos, self.mask), saved):
+        for dst, src in zip((self.tok, self.write_index, self.pos, self.mask, self.rng_state), saved):
             dst.copy_(src)
-        self._captured_greedy = greedy
+        self._graphs[mode] = graph
+        self.graph, self._captured_mode = graph, mode
         self._graph_key = self._layout_fingerprint()            # AFTER the warm-up built the lazy layouts
         self._graph_epoch, self._graph_versions = _lib.layout_epoch(), self._canonical_versions()
 
@@ -263,20 +318,22 @@ class DecodeSession:
         return total
 
     @torch.no_grad()
-    def decode_step(self, token: Optional[Tensor] = None, greedy: bool = True) -> Tensor:
+    def decode_step(self, token: Optional[Tensor] = None, greedy: bool = True, sample: bool = False) -> Tensor:
         """Advance by one token.  `token` (batch, 1) overrides the device-resident next id (needed when the
-        host samples).  Returns this step's last-position logits (batch, vocab)."""
+        host samples).  ``sample``: the device sampler (set_sampling) draws the next id into ``tok``.  Returns this step's
+        last-position logits (batch, vocab)."""
         if self.length + 1 > self.capacity:
             raise ValueError("cache capacity exhausted")
         if token is not None:
             self.tok.copy_(token.to(self.device))
-        if self.graph is not None and self._captured_greedy == greedy:
+        mode = self._mode(greedy, sample)
+        if mode in self._graphs:
             from . import _lib
-            if self._graph_epoch != _lib.layout_epoch():        # a derived layout was rebuilt / dropped since the capture:
-                self.capture(greedy)                            # capture() compares the fingerprint and keeps the graph when
-            self.graph.replay()                                 # only modules of OTHER models / sessions moved (ADVICE r3)
+            if self._graph_epoch != _lib.layout_epoch() or self._captured_mode != mode:   # a derived layout was rebuilt / dropped since
+                self.capture(greedy, sample)                    # the capture: capture() compares the fingerprint and keeps the graphs
+            self.graph.replay()                                 # when only modules of OTHER models / sessions moved (ADVICE r3)
         else:
-            self._step_body(greedy)
+            self._step_body(greedy, sample)
         self.length += 1
         self.cache.length = self.length
         return self.logits
@@ -414,8 +471,15 @@ class ChatGLMDecoder:
     @torch.no_grad()
     def generate_ids(self, prefix_ids: Iterable[int], max_generated_tokens: int = 400, top_k: int = 100,
                      top_p: float = 0.8, temperature: float = 1.0, greedy: bool = False, ignore_eos: bool = False,
-                     prefill_chunk: Optional[int] = None, use_graph: Optional[bool] = None, sync_every_token: bool = True):
-        """Yields generated token ids one by one (batch 1, like the reference, chatglm_q/decoder.py:70)."""
+                     prefill_chunk: Optional[int] = None, use_graph: Optional[bool] = None, sync_every_token: bool = True,
+                     seed: Optional[int] = None, device_sampler: Optional[bool] = None):
+        """Yields generated token ids one by one (batch 1, like the reference, chatglm_q/decoder.py:70).
+
+        Default = the reference's only mode: top-k / top-p sampling (top_k 100, top_p 0.8, temperature 1.0).  On a GPU the
+        sampler is one launch inside the captured step (``device_sampler`` None / True; False: the composed torch ops of
+        ``top_p_sampling`` on the host's side of the loop, as the reference runs them) and draws from a counter-based generator
+        seeded by ``seed`` (None: a seed taken from torch's global generator, so ``torch.manual_seed`` makes a run repeatable as it
+        does for the reference's ``torch.multinomial``).  ``greedy=True``: argmax instead."""
         prefix = list(prefix_ids)
         limit = min(self.max_sequence_length, self.model.config.max_sequence_length)   # the cache cannot outgrow the rotary table
         budget = min(max_generated_tokens, limit - len(prefix))
@@ -425,43 +489,55 @@ class ChatGLMDecoder:
         sess = self._session_for(capacity, use_graph)
         sess.busy = True
         try:
+            dev_sample = (not greedy) and sess.device_sampler_serves(top_k) and device_sampler is not False
+            if device_sampler and not greedy and not dev_sample:
+                raise ValueError(f"device_sampler=True needs a GPU and top_k <= 1024 (got {sess.device}, top_k {top_k})")
+            if dev_sample:
+                if seed is None:
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                sess.set_sampling(top_k, top_p, temperature, seed)
             yield from self._generate(sess, prefix, budget, top_k, top_p, temperature, greedy, ignore_eos, prefill_chunk,
-                                      sync_every_token)
+                                      sync_every_token, dev_sample)
         finally:
             sess.busy = False
             if POST_GENERATE_CHECK is not None:                 # set by chatglm_q_amd.dev.experiments: error words of one-launch MLPs
                 POST_GENERATE_CHECK(sess)
 
     def _generate(self, sess: DecodeSession, prefix, budget: int, top_k: int, top_p: float, temperature: float, greedy: bool,
-                  ignore_eos: bool, prefill_chunk: Optional[int], sync_every_token: bool):
+                  ignore_eos: bool, prefill_chunk: Optional[int], sync_every_token: bool, dev_sample: bool = False):
+        # `auto`: the device picks the next token inside the step (argmax or the one-launch sampler) and feeds it back itself
+        auto = greedy or dev_sample
         times = []
         sync = (lambda: torch.cuda.synchronize(sess.device)) if sess.device.type == "cuda" else (lambda: None)
 
         t0 = time.perf_counter()
         logits = sess.prefill(torch.tensor([prefix], dtype=torch.long), prefill_chunk)
-        nxt = logits.argmax(-1) if greedy else top_p_sampling(logits, top_k, top_p, temperature)
+        if dev_sample:
+            nxt = sess.sample_first(logits)
+        else:
+            nxt = logits.argmax(-1) if greedy else top_p_sampling(logits, top_k, top_p, temperature)
         token = int(nxt.item())                                    # the sync that makes the timing valid
         times.append(time.perf_counter() - t0)
         generated = [token]
         yield token
 
-        device_loop = greedy and not sync_every_token and (ignore_eos or self.eos_token_id is None)
+        device_loop = auto and not sync_every_token and (ignore_eos or self.eos_token_id is None)
         if len(generated) < budget and (ignore_eos or token != self.eos_token_id):
             sess.tok.fill_(token)
-            sess.capture(greedy=greedy)
+            sess.capture(greedy=greedy, sample=dev_sample)
         pending = []
-        # Greedy decoding on a captured step: the graph feeds its own argmax back, so step k + 1 does not wait for the HOST to have seen
+        # Greedy or device-sampled decoding on a captured step: the graph feeds its own choice back, so step k + 1 does not wait for the HOST to have seen
         # token k.  It is launched before token k is read (one step of speculation: wasted - and harmless, the next prefill re-arms the
         # session - when token k turns out to be the end token), so the device never idles for the host's read-back + launch latency
         # (~20 us of a 1.15 ms token).  Tokens are yielded one by one as before.
-        ahead = (greedy and not device_loop and sess.graph is not None and sess.device.type == "cuda" and AHEAD_LAUNCH
+        ahead = (auto and not device_loop and sess.graph is not None and sess.device.type == "cuda" and AHEAD_LAUNCH
                  and len(generated) < budget and (ignore_eos or token != self.eos_token_id))
         if ahead:
             ring = torch.empty((2, 1), dtype=torch.long).pin_memory()
             events = [torch.cuda.Event(), torch.cuda.Event()]
 
             def launch(k):
-                sess.decode_step(None, greedy=True)
+                sess.decode_step(None, greedy=greedy, sample=dev_sample)
                 ring[k & 1].copy_(sess.tok.view(-1), non_blocking=True)
                 events[k & 1].record()
 
@@ -485,14 +561,14 @@ class ChatGLMDecoder:
         while not ahead and len(generated) < budget and (ignore_eos or generated[-1] != self.eos_token_id):
             t0 = time.perf_counter()
             if device_loop:
-                # the graph feeds its own argmax back as the next input: the host only replays
-                sess.decode_step(greedy=True)
+                # the graph feeds its own choice back as the next input: the host only replays
+                sess.decode_step(greedy=greedy, sample=dev_sample)
                 pending.append(sess.tok.clone())
                 generated.append(-1)
                 times.append(time.perf_counter() - t0)
                 continue
-            logits = sess.decode_step(None if greedy else torch.tensor([[generated[-1]]]), greedy=greedy)
-            nxt = sess.tok[:, 0] if greedy else top_p_sampling(logits, top_k, top_p, temperature)
+            logits = sess.decode_step(None if auto else torch.tensor([[generated[-1]]]), greedy=greedy, sample=dev_sample)
+            nxt = sess.tok[:, 0] if auto else top_p_sampling(logits, top_k, top_p, temperature)
             token = int(nxt.item())
             times.append(time.perf_counter() - t0)
             generated.append(token)

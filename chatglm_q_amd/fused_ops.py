@@ -295,3 +295,50 @@ def greedy_advance(logits: Tensor, tok: Tensor, write_index: Tensor, pos: Tensor
                                         pos.data_ptr(), mask.data_ptr(), mask.shape[-1], _lib.dtype_code(logits.dtype),
                                         _lib.stream_ptr(logits.device))
     _lib.check(st, "qlinear_greedy_advance")
+
+
+SAMPLER_MAX_TOP_K = 1024     # csrc/sampler.hip S_KMAX
+
+
+def new_rng_state(batch: int, seed: int, device) -> Tensor:
+    """Device state of qlinear_top_p_sample's generator: int64[1 + batch] = (seed, one draw counter per row)."""
+    st = torch.zeros(1 + batch, dtype=torch.int64)
+    st[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+    return st.to(device)
+
+
+def top_p_sample(logits: Tensor, tok: Tensor, rng_state: Tensor | None = None, top_k: int = 100, top_p: float = 0.8,
+                 temperature: float = 1.0, dev_params: Tensor | None = None, write_index: Tensor | None = None,
+                 pos: Tensor | None = None, mask: Tensor | None = None, return_distribution: bool = False):
+    """chatglm_q/decoder.py:12-27 in one launch: ``tok[b] = top_p_sampling(logits[b], top_k, top_p, temperature)`` for every row of
+    `logits` (B, N), drawing from the counter-based generator in `rng_state` (new_rng_state; None: seed 0, counter 0).  With
+    write_index / pos / mask the launch also does a decode step's bookkeeping (greedy_advance).  dev_params: device float32[3] =
+    (top_k, top_p, temperature) read by the kernel instead of the arguments (a captured graph then serves any setting).
+    return_distribution: also return (probs (B, k), indices (B, k), u (B,)) - the filtered distribution in sorted order (ties: lowest
+    index first), its token ids and the uniform number each row drew."""
+    lib = _lib.get_lib()
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise ValueError("top_p_sample: logits must be (B, N) with unit column stride")
+    B, N = logits.shape
+    if tok.dtype != torch.int64 or tok.numel() != B or not tok.is_contiguous():
+        raise ValueError("top_p_sample: tok must be a contiguous int64 tensor of B elements")
+    if dev_params is None and not (1 <= top_k and temperature > 0):
+        raise ValueError("top_p_sample: top_k >= 1 and temperature > 0")
+    if rng_state is not None and (rng_state.dtype != torch.int64 or rng_state.numel() < 1 + B or not rng_state.is_contiguous()):
+        raise ValueError("top_p_sample: rng_state must be int64[1 + B] (new_rng_state)")
+    if dev_params is not None and (dev_params.dtype != torch.float32 or dev_params.numel() < 3 or not dev_params.is_contiguous()):
+        raise ValueError("top_p_sample: dev_params must be float32[3]")
+    k_out = min(SAMPLER_MAX_TOP_K if dev_params is not None else top_k, N)
+    probs = idx = u = None
+    if return_distribution:
+        probs = torch.zeros((B, k_out), device=logits.device, dtype=torch.float32)
+        idx = torch.zeros((B, k_out), device=logits.device, dtype=torch.int64)
+        u = torch.zeros(B, device=logits.device, dtype=torch.float32)
+    with torch.cuda.device(logits.device):
+        st = lib.qlinear_top_p_sample(logits.data_ptr(), B, N, logits.stride(0), int(top_k), float(top_p), float(temperature),
+                                      _lib.ptr(dev_params), _lib.ptr(rng_state), tok.data_ptr(), _lib.ptr(write_index), _lib.ptr(pos),
+                                      _lib.ptr(mask), mask.shape[-1] if mask is not None else 0, _lib.ptr(probs), _lib.ptr(idx),
+                                      _lib.ptr(u), k_out, _lib.dtype_code(logits.dtype), _lib.stream_ptr(logits.device))
+    _lib.check(st, "qlinear_top_p_sample")
+    if return_distribution:
+        return probs, idx, u

@@ -44,7 +44,9 @@ extern "C" {
 /* 2 (round 4): qlinear_w4g32_fwd_packed_residual gained `flags` in front of `stream` (round 3); qlinear_last_dispatch /
  * qlinear_dispatch_reset / qlinear_dispatch_reload / qlinear_gemm256_serves / qlinear_tiled_dispatch added; the experimental entry points (one-launch MLP pair / persistent MLP
  * engine / W4A8) moved to include/qlinear_hip_dev.h and libqlinear_hip_dev.so. */
-#define QLINEAR_ABI_VERSION 2
+/* 3 (round 6): qlinear_top_p_sample added; round 5's additions (qlinear_w4g32_unpack_gemv, qlinear_dispatch_flags,
+ * qlinear_w4g32_packed_dispatch, QL_K code 19 = ROWS16, qlinear_gated_serves weight_bits 88 = int8 x int8) had gone out under 2. */
+#define QLINEAR_ABI_VERSION 3
 
 /* activation dtypes */
 #define QL_DTYPE_F32 0
@@ -473,6 +475,22 @@ int qlinear_silu_mul_quant_i8(const void* In, void* Out, int8_t* Aq, float* a_sc
  * row b (lowest index on ties), pos[b] += 1, write_index[0] += 1, mask[b][new write_index] = 0 for every row. */
 int qlinear_greedy_advance(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t* tok, int64_t* write_index,
                            int64_t* pos, float* mask, int64_t capacity, int dtype, void* stream);
+/* The reference's decoding mode in one launch behind lm_head (chatglm_q/decoder.py:12-27 `top_p_sampling`, called per token at :85):
+ *   probs = softmax(float(logits) / temperature); sort descending, keep top_k (ties: lowest index first); zero every entry whose
+ *   PRECEDING cumulative mass exceeds top_p; renormalise; one multinomial draw; tok[b] = its token index.
+ * logits (B, N) with row stride ldl, one workgroup per row, any N, top_k <= 1024 (QL_ERR_UNSUPPORTED above, unless N <= 1024).
+ * dev_params (nullable, device float[3] = top_k, top_p, temperature) overrides the three scalars at run time, so that ONE captured
+ * graph serves every sampler setting.  rng_state (device uint64[1 + B], nullable = seed 0 / counter 0): [0] the seed, [1 + b] row
+ * b's draw counter, advanced by one per launch - the draw is u = (Philox4x32-10(counter = (ctr, b, 0), key = seed).x >> 8) / 2^24
+ * and the token is the first sorted entry whose inclusive cumulative kept mass exceeds u * (kept mass): replays of a graph draw
+ * fresh numbers, equal (seed, counter) reproduce the token.  top_k = 1 is qlinear_greedy_advance's argmax bit for bit.
+ * write_index / pos / mask (all nullable together): the decode step's bookkeeping exactly as qlinear_greedy_advance does it.
+ * probs_out (B, out_ld) / index_out (B, out_ld) (nullable together): the filtered, renormalised distribution in sorted order and its
+ * token indices (the first min(top_k, N) entries of a row are written) - what the parity tests compare with the reference;
+ * u_out (B, nullable): the uniform number each row drew. */
+int qlinear_top_p_sample(const void* logits, int64_t B, int64_t N, int64_t ldl, int64_t top_k, float top_p, float temperature,
+                         const float* dev_params, uint64_t* rng_state, int64_t* tok, int64_t* write_index, int64_t* pos, float* mask,
+                         int64_t capacity, float* probs_out, int64_t* index_out, float* u_out, int64_t out_ld, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -365,3 +365,22 @@ def max_norm_err(y: np.ndarray, ref: np.ndarray) -> float:
     ref = as_f64(ref).ravel()
     den = np.abs(ref).max()
     return float(np.abs(y - ref).max() / (den if den > 0 else 1.0))
+
+
+# --------------------------------------------------------------------------
+# the decode loop's sampler (caller of the hot path: chatglm_q/decoder.py:12-27)
+# --------------------------------------------------------------------------
+def top_p_filter(logits: np.ndarray, top_k: int = 100, top_p: float = 0.8, temperature: float = 1.0):
+    """The deterministic part of ``top_p_sampling`` (chatglm_q/decoder.py:12-22): fp32 softmax of logits / temperature
+    (:14), descending sort cut to top_k (:15-17; ties keep the lower index first - what torch's CPU sort returns and what
+    a stable sort guarantees), entries whose PRECEDING cumulative mass exceeds top_p zeroed (:20-21), renormalised (:22).
+    Returns (probs float32 (min(top_k, N),), indices int64) - the distribution ``torch.multinomial`` then draws from (:25)
+    and the token ids the drawn position maps to (:26)."""
+    x = np.asarray(logits, dtype=np.float32) / np.float32(temperature)
+    e = np.exp(x - x.max(), dtype=np.float32)
+    probs = e / e.sum(dtype=np.float32)
+    order = np.argsort(-probs.astype(np.float64), kind="stable")[:top_k]
+    p = probs[order].astype(np.float32)
+    cum = np.cumsum(p, dtype=np.float32)
+    p = np.where((cum - p) > np.float32(top_p), np.float32(0), p)
+    return (p / p.sum(dtype=np.float32)).astype(np.float32), order.astype(np.int64)

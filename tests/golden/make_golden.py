@@ -363,6 +363,45 @@ def gen_model():
     np.savez_compressed(os.path.join(OUT, "tiny_model.npz"), **d)
 
 
+def gen_sampler():
+    """The reference's ``top_p_sampling`` (chatglm_q/decoder.py:12-27) run on seeded logits rows (tests/_sampler_cases.py): what it
+    hands to ``torch.multinomial`` (the filtered, renormalised distribution) and the index order its ``torch.sort`` produced are
+    recorded by wrapping those two torch functions around the call - the function under test is the reference's own."""
+    sys.path.insert(0, os.path.dirname(OUT))                        # tests/
+    import _sampler_cases as SC
+    from chatglm_q import decoder as refd
+    torch.set_num_threads(1)
+    d = {}
+    for name, (seed, N, recipe, dtype, top_k, top_p, temperature) in SC.CASES.items():
+        lg = torch.from_numpy(SC.logits_for(name)).to(DT[dtype])
+        seen = {}
+        real_sort, real_multinomial = torch.sort, torch.multinomial
+
+        def sort_spy(*a, **kw):
+            out = real_sort(*a, **kw)
+            seen["indices"] = out[1].clone()
+            return out
+
+        def multinomial_spy(probs, num_samples, *a, **kw):
+            seen["probs"] = probs.clone()
+            if not torch.isfinite(probs).all():                      # the reference would raise here: record and move on
+                return torch.zeros(probs.shape[:-1] + (num_samples,), dtype=torch.long)
+            return real_multinomial(probs, num_samples, *a, **kw)
+
+        torch.sort, torch.multinomial = sort_spy, multinomial_spy
+        try:
+            torch.manual_seed(seed)
+            picks = [int(refd.top_p_sampling(lg, top_k, top_p, temperature)) for _ in range(4)]
+        finally:
+            torch.sort, torch.multinomial = real_sort, real_multinomial
+        d[name + "/probs"] = seen["probs"].numpy().astype(np.float32)
+        d[name + "/indices"] = seen["indices"][:top_k].numpy().astype(np.int64)
+        d[name + "/picks"] = np.array(picks)
+        kept = int((seen["probs"] > 0).sum())
+        print("sampler", name, "N", N, "k", top_k, "kept", kept, "picks", picks)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **d)
+
+
 def gen_model_real():
     """ChatGLM2-6B LAYER DIMENSIONS (hidden 4096, FFN 13696, 32 heads x 128, 2 groups; 2 layers, vocab 1024), fp16,
     through the reference model on CPU.  Weights come from tests/_golden.py::fill_seeded_ (a pure function of the
@@ -636,11 +675,11 @@ def gen_loader():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "model_r3", "model_full", "backward", "loader"]
+    which = sys.argv[1:] or ["int4", "int8", "quantizers", "w8a8", "embedding", "model", "model_real", "model_r3", "model_full", "backward", "loader", "sampler"]
     torch.set_num_threads(4)
     for w in which:
         {"int4": gen_int4, "int8": gen_int8, "quantizers": gen_quantizers, "w8a8": gen_w8a8,
-         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "model_r3": gen_model_r3, "model_full": gen_model_full, "backward": gen_backward, "loader": gen_loader}[w]()
+         "embedding": gen_embedding, "model": gen_model, "model_real": gen_model_real, "model_r3": gen_model_r3, "model_full": gen_model_full, "backward": gen_backward, "loader": gen_loader, "sampler": gen_sampler}[w]()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -56,7 +56,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert getattr(dev, name) is not None
     for name in dev_declared:
         assert not hasattr(lib, name), name
-    assert _lib.get_lib().qlinear_abi_version() == 2
+    assert _lib.get_lib().qlinear_abi_version() == 3
     assert _lib.get_lib().qlinear_status_string(0) == b"ok"
     assert b"group" in _lib.get_lib().qlinear_status_string(-4)
     # host-only queries (no GPU needed)

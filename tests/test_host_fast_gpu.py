@@ -432,3 +432,65 @@ def test_int8_activation_model_prefill_with_quantising_producers_is_bit_equal(mo
     _, a_q, a_s, out = F_.rmsnorm_quant(x, w, 1e-5, want_out=True)
     with torch.no_grad():
         assert torch.equal(mod.forward_quantized(a_q, a_s), mod(out))
+
+
+def test_default_generate_samples_on_the_device_inside_the_captured_step(monkeypatch):
+    """Round 6: the reference's only decoding mode (chatglm_q/decoder.py:85: top_p_sampling per token) is the default of generate_ids and
+    runs as one launch inside the captured step.  (a) graph + launch-ahead, graph without it, the device loop and the eager loop yield
+    the same tokens for one seed; (b) every token is what the oracle's filter of THAT step's logits and the documented Philox draw give;
+    (c) another seed changes the tokens, torch.manual_seed makes an unseeded run repeatable; (d) greedy and sampled graphs live side by
+    side on one session; (e) the host-side torch sampler (device_sampler=False) still works and draws from the same support."""
+    import _philox
+    from chatglm_q_amd import decoder as Dm
+    from oracle import qlinear_oracle as O
+    model, cfg = _tiny()
+    prefix = [3, 17, 200, 5, 77]
+    kw = dict(max_generated_tokens=12, ignore_eos=True, top_k=20, top_p=0.9, temperature=1.5)
+    dec = ChatGLMDecoder(None, model)
+    ahead = list(dec.generate_ids(prefix, use_graph=True, seed=41, **kw))
+    sess = dec._session
+    assert sess._captured_mode == "sample" and sess.graph is not None
+    eager = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, seed=41, **kw))
+    loop = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=True, seed=41, sync_every_token=False, **kw))
+    monkeypatch.setattr(Dm, "AHEAD_LAUNCH", False)
+    plain = list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=True, seed=41, **kw))
+    monkeypatch.setattr(Dm, "AHEAD_LAUNCH", True)
+    assert ahead == plain == eager == loop and len(ahead) == 12
+    assert int(sess.rng_state[1].item()) >= 12                                 # one draw per token (+ at most the speculative step)
+    # (b) step by step against the oracle: feed the same tokens through an eager session and redo the sampler on the host
+    chk = DecodeSession(model, 1, 64, use_graph=False)
+    logits = chk.prefill(torch.tensor([prefix], device=DEV))
+    for step, tok in enumerate(ahead):
+        p, idx = O.top_p_filter(logits[0].float().cpu().numpy(), 20, 0.9, 1.5)
+        u = float(_philox.uniform(41, step, 0))
+        cdf = np.cumsum(p.astype(np.float64))
+        j = min(int(np.searchsorted(cdf, u * cdf[-1], side="right")), int((p > 0).sum()) - 1)
+        edge = min(abs(u * cdf[-1] - c) for c in cdf[max(0, j - 1): j + 1])
+        assert tok == idx[j] or (edge < 1e-5 and tok in idx[max(0, j - 1): j + 2]), (step, tok, idx[j])
+        logits = chk.decode_step(torch.tensor([[tok]], device=DEV), greedy=False)
+    # (c)
+    other = list(dec.generate_ids(prefix, use_graph=True, seed=42, **kw))
+    assert other != ahead
+    torch.manual_seed(7)
+    r1 = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    torch.manual_seed(7)
+    r2 = list(dec.generate_ids(prefix, use_graph=True, **kw))
+    assert r1 == r2
+    # (d)
+    g_sample = sess.graph
+    greedy = list(dec.generate_ids(prefix, use_graph=True, greedy=True, max_generated_tokens=12, ignore_eos=True))
+    assert dec._session is sess and sess._captured_mode == "greedy" and sess.graph is not g_sample
+    assert greedy == list(ChatGLMDecoder(None, model).generate_ids(prefix, use_graph=False, greedy=True, max_generated_tokens=12, ignore_eos=True))
+    assert list(dec.generate_ids(prefix, use_graph=True, seed=41, **kw)) == ahead and sess.graph is g_sample
+    top1 = list(dec.generate_ids(prefix, use_graph=True, seed=5, max_generated_tokens=12, ignore_eos=True, top_k=1))
+    assert top1 == greedy                                                       # top_k = 1 through the sampler graph == argmax
+    # (e)
+    host = list(dec.generate_ids(prefix, use_graph=True, device_sampler=False, **kw))
+    assert len(host) == 12 and all(0 <= t < cfg.vocab_size for t in host)
+    # an end token stops a sampled generation AT it
+    stop = 5
+    if ahead[stop] not in ahead[:stop]:
+        dec_eos = ChatGLMDecoder(None, model, eos_token_id=ahead[stop])
+        kw2 = dict(kw, ignore_eos=False)
+        assert list(dec_eos.generate_ids(prefix, use_graph=True, seed=41, **kw2)) == ahead[:stop + 1]
+        assert list(dec_eos.generate_ids(prefix, use_graph=True, seed=41, **kw2)) == ahead[:stop + 1]

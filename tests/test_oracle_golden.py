@@ -131,3 +131,40 @@ def test_act_quant_per_tensor_matches_formula_fixture():
     assert np.allclose(out, z["pt_out"], rtol=1e-6, atol=1e-6)
     zq, zs = O.act_quant_per_tensor(np.zeros((3, 16), np.float32))          # the 0 / 0 case the reference's comment mentions
     assert not zq.any() and np.all(zs == np.float32(1e-10))
+
+
+def test_top_p_filter_vs_reference_sampler():
+    """oracle.top_p_filter against what the reference's top_p_sampling handed to torch.multinomial (tests/golden/sampler.npz,
+    make_golden.py::gen_sampler) and against the older tiny_model.npz/sampler entry.  Probabilities entry for entry; indices
+    exactly where the selected logits are distinct, as tie groups otherwise (the reference's torch.sort is unstable: equal
+    probabilities come out in no index order, the oracle keeps the lowest index first)."""
+    import _sampler_cases as SC
+    Z = G.load("sampler.npz")
+    exact = 0
+    for name, (seed, N, recipe, dtype, top_k, top_p, temperature) in SC.CASES.items():
+        x = SC.logits_for(name)
+        p, idx = O.top_p_filter(x, top_k, top_p, temperature)
+        ref_p, ref_i = Z[name + "/probs"], Z[name + "/indices"]
+        k = min(top_k, N)
+        assert len(p) == k and len(ref_i) == k
+        np.testing.assert_allclose(p, ref_p, rtol=0, atol=2e-7)
+        assert np.array_equal(x[idx], x[ref_i]), name
+        if len(np.unique(x[idx])) == k and (k == N or x[idx][-1] > np.sort(x)[::-1][k]):     # no tie inside or across the cut
+            assert np.array_equal(idx, ref_i), name
+            exact += 1
+        for pick in Z[name + "/picks"]:
+            assert p[list(ref_i).index(int(pick))] > 0 if int(pick) in ref_i else False, name
+    assert exact >= 4
+    T = G.load("tiny_model.npz")
+    p, idx = O.top_p_filter(T["sampler/logits"], 100, 0.8, 1.0)
+    assert np.array_equal(idx, T["sampler/indices"])
+    np.testing.assert_allclose(p, T["sampler/probs"], rtol=1e-6, atol=1e-8)
+
+
+def test_philox_known_answers():
+    """The draw's generator (tests/_philox.py = the spec in include/qlinear_hip.h) against Random123's known-answer vectors."""
+    import _philox
+    assert _philox.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert _philox.philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert _philox.philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == \
+        (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
