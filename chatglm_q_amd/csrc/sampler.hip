@@ -138,6 +138,13 @@ __device__ __forceinline__ void walk_row(const T* __restrict__ row, int N, const
     }
 }
 
+// developer build only (make strace; tools/sampler_timeline.py): thread 0 stamps the 100 MHz clock at the phase boundaries into u_out[2..]
+#ifdef QL_SAMPLER_TRACE
+#define S_STAMP(i) do { if (threadIdx.x == 0 && u_out) reinterpret_cast<unsigned long long*>(u_out)[1 + (i)] = wall_clock64(); } while (0)
+#else
+#define S_STAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ logits, int N, int64_t ldl, int top_k_h, float top_p_h,
                                                           float temperature_h, const float* __restrict__ dparams,
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
     k = k > N ? N : k;
     const Scale sc = {temperature, 1.0f / temperature, temperature != 1.0f};
 
+    S_STAMP(0);
     // ---- pass 1: thread maxima -> the row's maximum M and the first threshold t0 --------------------------------------------------
     float tm = -INFINITY;
     walk_row<T>(row, N, sc, [&](int, const float (&v)[8]) {
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
 #pragma unroll
     for (int w = 1; w < 16; ++w) { M = fmaxf(M, sh.wmax[w]); t0 = fminf(t0, sh.wmin[w]); }
 
+    S_STAMP(1);
     // ---- pass 2 (the row again, from L2): softmax denominator + every value >= t0 into the LDS list -----------------------------
     constexpr float L2E = 1.4426950408889634f;
     const float mb = -M * L2E;                               // exp(x - M) = 2^(x L2E - M L2E): one fma + v_exp_f32; the rounding of M L2E
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
 #pragma unroll
     for (int w = 0; w < 16; ++w) Z += sh.wsum[w];
     int cnt = sh.cnt;
+    S_STAMP(2);
     u32 lo = okey(t0);
     const u32 kmax = okey(M);
 
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
         }
     }
 
+    S_STAMP(3);
     // ---- histogram select on the list: the k-th largest key --------------------------------------------------------------------
     {
         u32 hi = kmax;
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
             __syncthreads();                                  // hist / cross_* are rewritten by the next round
         }
 
+        S_STAMP(4);
         // ---- finalists (key >= tk) compacted, ranked by counting; the top k land in order ---------------------------------------
         if (tid == 0) sh.fcnt = 0;
         __syncthreads();
@@ -364,6 +376,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
         __syncthreads();
     }
 
+    S_STAMP(5);
     // ---- one wave: probabilities, cumulative sums, top-p cut, renormalisation, the draw ---------------------------------------------
     if (wv == 0) {
         const int per = (k + 63) >> 6;                        // lane l owns sorted entries per * l .. per * l + per - 1
@@ -432,6 +445,7 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
                     }
                 }
         }
+        S_STAMP(6);
         if (lane == 0) {
             if (u_out) u_out[blockIdx.x] = uni;
             tok[blockIdx.x] = sh.si[jstar];
