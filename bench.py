@@ -21,10 +21,21 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON 
             chatglm_q/int4/qlinear.py:20-33,50) through DynamicQuantizeLinear on the same shape: all host cores and one
             core, median of >= 7; the C oracle's time is kept as a second figure.
 
-The timed steps are replayed from ONE captured HIP graph (K kernel nodes, strictly sequential on one
+The timed steps are replayed from captured HIP graphs (K kernel nodes each, strictly sequential on one
 stream) so that the figure is not the Python/ctypes launch overhead; `--launch eager` times plain
-launches instead.  Multi-GPU: the path does not shard (DESIGN.md "replicas only"): `--gpus N` runs N
-independent replicas, one process per GPU, no data-path collective; scaling is "weak".
+launches instead.  A K-step region lasts K x 4 us: at K < 144 ONE such bracket is dominated by event / replay noise (BENCH r01-r05:
+1 479 .. 2 046 GB/s on an unchanged kernel at the driver's --steps 20), so R = ceil(1440 / K) graphs of K launches - graph r walks the
+weight rotation from set r K on, so consecutive replays stream from HBM like the roofline leg - are replayed inside the ONE barrier +
+synchronize bracket, each between its own HIP events, and `ms_per_step` = (first event -> last event) / (R K): every one of the R K launches is inside
+the bracket and the clock (`replays`, `steps_timed`, the median single block and the bracket's own wall clock are reported beside it).
+
+Multi-GPU: the path does not shard (DESIGN.md "replicas only"): N independent replicas, one process per GPU, no data-path
+collective (the only exchange is the barrier and the max-over-ranks of the timings); scaling is "weak".  Two ways in:
+  * the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the env);
+  * plain `python bench.py --gpus N` (no WORLD_SIZE in the env): bench.py spawns the N workers itself (one per GPU, rendezvous on
+    127.0.0.1) and relays rank 0's JSON line; it refuses N > visible devices.
+`--dry-run` (implies `--backend gloo`, CPU tensors): the launch / barrier / max-over-ranks / JSON assembly path without a kernel -
+what tests/test_replicas_gloo.py drives here, where there is no GPU; its line carries "dry_run": true and no throughput.
 """
 from __future__ import annotations
 
@@ -43,6 +54,8 @@ HBM_COPY_CEILING_GBPS = 6290.0  # measured float4 copy ceiling, same guide ("8.0
 ROOF_LAUNCHES = 1440            # >= 200 timed launches; BENCH r1 was timed over --steps (20) only
 ROOF_GRAPH = 144
 ROOF_REPLAYS = 7
+ROOF_LAUNCHES_SWEEP = 432       # per shape of the pure-read floor sweep (3 graphs of 144)
+ROOF_REPLAYS_SWEEP = 5
 K_DIM = 4096
 N_DIM = 4096
 GROUP = 32
@@ -316,8 +329,8 @@ def floor_leg(torch, x, stream, bytes_per_launch, n_sets):
     sink = torch.zeros(int(lib.qlinear_probe_read_waves(bytes_per_launch)) + 64, dtype=torch.int32, device=dev)
     st = stream.cuda_stream
 
-    def timed(launch):
-        n_graphs = ROOF_LAUNCHES // ROOF_GRAPH
+    def timed(launch, launches=ROOF_LAUNCHES, reps=ROOF_REPLAYS):
+        n_graphs = launches // ROOF_GRAPH
         samples = []
         with torch.cuda.stream(stream):
             graphs = []
@@ -331,7 +344,7 @@ def floor_leg(torch, x, stream, bytes_per_launch, n_sets):
             for g in graphs:
                 g.replay()
             stream.synchronize()
-            for _ in range(ROOF_REPLAYS):
+            for _ in range(reps):
                 for g in graphs:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(stream)
@@ -345,6 +358,29 @@ def floor_leg(torch, x, stream, bytes_per_launch, n_sets):
 
     empty = timed(lambda i: lib.qlinear_probe_empty(256, st))
     read = timed(lambda i: lib.qlinear_probe_read(buf.data_ptr() + (i % n_sets) * region, bytes_per_launch, sink.data_ptr(), st))
+    # the floor as a sweep (round 6): loads in flight x workgroups x load kind; the minimum is the floor, round 5's one shape is kept above
+    sweep, best_shape = {}, None
+    if hasattr(lib, "qlinear_probe_read_sweep"):
+        lib.qlinear_probe_read_sweep.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_void_p]
+        sink2 = torch.zeros(4 * 2048 + 64, dtype=torch.int32, device=dev)
+        saved = (ROOF_LAUNCHES_SWEEP, ROOF_REPLAYS_SWEEP)
+        for mode, mname in ((0, "default"), (1, "nt"), (2, "lds_dma")):
+            for blocks in (256, 512, 1024, 2048):
+                for loads in (2, 4, 8, 9, 16):
+                    per_lane = bytes_per_launch / 16 / (blocks * 256)
+                    if loads > 2 and loads / 2 >= per_lane:      # more loads in flight than the lane has units: same kernel as the smaller count
+                        continue
+                    try:
+                        r = timed(lambda i, loads=loads, blocks=blocks, mode=mode: lib.qlinear_probe_read_sweep(
+                            buf.data_ptr() + (i % n_sets) * region, bytes_per_launch, sink2.data_ptr(), loads, blocks, mode, st),
+                            launches=saved[0], reps=saved[1])
+                    except RuntimeError:
+                        continue
+                    key = f"{mname}/wg{blocks}/loads{loads}"
+                    sweep[key] = r["median_us"]
+                    if best_shape is None or r["median_us"] < sweep[best_shape]:
+                        best_shape = key
     # device copy ceiling: 1 GiB -> 1 GiB (4 x the 256 MB memory-side cache), best of 5
     n_copy = 1 << 30
     src = torch.empty(n_copy, dtype=torch.uint8, device=dev)
@@ -376,7 +412,14 @@ def floor_leg(torch, x, stream, bytes_per_launch, n_sets):
             if r > 0:
                 per_variant["runtime_memcpy"] = max(per_variant.get("runtime_memcpy", 0.0), round(2.0 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1))
     del src, dst, buf
-    return {"empty_us": empty["median_us"], "pure_read_us": read["median_us"], "copy_GBps": round(2.0 * n_copy / (best * 1e-3) / 1e9, 1),
+    floor_us = min([read["median_us"]] + list(sweep.values()))
+    return {"empty_us": empty["median_us"], "pure_read_us": floor_us, "pure_read_us_round5_shape": read["median_us"],
+            "pure_read_best_shape": best_shape if sweep and sweep[best_shape] <= read["median_us"] else "nt/wg289/loads8 (round 5's probe)",
+            "pure_read_sweep_us": sweep,
+            "pure_read_sweep_protocol": f"every shape: {ROOF_LAUNCHES_SWEEP} launches in graphs of {ROOF_GRAPH} x {ROOF_REPLAYS_SWEEP} replays, regions "
+                                        "rotated like the weights; loads = 16-byte loads in flight per lane, wg = workgroups of 256 threads "
+                                        "(a wave owns a contiguous span), default / non-temporal loads or LDS-DMA",
+            "copy_GBps": round(2.0 * n_copy / (best * 1e-3) / 1e9, 1),
             "copy_GBps_per_variant": per_variant,
             "empty": empty, "pure_read": read, "pure_read_bytes": bytes_per_launch,
             "protocol": f"graphs of {ROOF_GRAPH} sequential launches x {ROOF_REPLAYS} replays, HIP events on the launch stream; probe kernels of "
@@ -414,9 +457,92 @@ def make_layers(torch, n_sets, device, bias=False):
     return layers
 
 
+def spawn_replicas(args, argv):
+    """`python bench.py --gpus N` without a launcher: N worker processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    one GPU each), rank 0's stdout is this process's stdout.  Returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n > have:
+            print(f"[bench] --gpus {n}: only {have} device(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
+
+
+def device_card(torch, device):
+    """Which physical device a rank ran on (the N > 1 line lists one per rank: they must differ)."""
+    if device.type != "cuda":
+        return {"device": "cpu", "pid": os.getpid()}
+    pr = torch.cuda.get_device_properties(device)
+    card = {"device": f"cuda:{device.index}", "name": pr.name, "pid": os.getpid()}
+    for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(pr, attr):
+            card[attr] = str(getattr(pr, attr))
+    return card
+
+
+def gather_cards(card, dist, world):
+    if dist is None:
+        return [card]
+    cards = [None] * world
+    dist.all_gather_object(cards, card)
+    return cards
+
+
+def dry_run(args, rank, world):
+    """The replica launch path without a kernel: gloo rendezvous, barrier, K fake steps between the barriers, max-over-ranks of the
+    timings, rank 0 assembles and prints the line.  No throughput is claimed (`value` null)."""
+    import torch
+    dist = None
+    device = torch.device("cpu")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = 0
+    for i in range(args.steps):
+        acc += i
+    if dist is not None:
+        dist.barrier()
+    wall_s = time.perf_counter() - t0 + 1e-4 * rank          # rank-dependent: the max must be the last rank's
+    own = wall_s
+    (wall_s,) = max_over_ranks([wall_s], dist, device)
+    cards = gather_cards(dict(device_card(torch, device), rank=rank, wall_s=own), dist, world)
+    if rank == 0:
+        print(json.dumps({"metric": "QLinear fwd GB/s + tok/s ChatGLM2-6B int4g32 decode, 1xMI355X", "value": None, "unit": "GB/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall_s * 1e3 / max(1, args.steps),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "dry_run": True, "max_over_ranks_is_slowest_rank": wall_s == max(c["wall_s"] for c in cards),
+                          "config": {"workload": "dry run: no kernel launched", "parallelism": "replicas" if world > 1 else "single"},
+                          "ranks": cards}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dry-run", action="store_true", help="launch / barrier / max-over-ranks / JSON path only (CPU, gloo): no kernel, no throughput")
     ap.add_argument("--steps", type=int, default=1440)
     ap.add_argument("--warmup", type=int, default=144)
     ap.add_argument("--sets", type=int, default=72, help="distinct weight sets in the rotation (72 x 9.4 MB = 680 MB)")
@@ -428,21 +554,36 @@ def main():
 
     if args.layout == "canonical":
         os.environ["QLINEAR_W4_LAYOUT"] = "canonical"
-
-    import torch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: be the launcher
+        raise SystemExit(spawn_replicas(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # the launcher's world is what runs; a mismatch with --gpus is a caller error worth a loud line, not a silent n_gpus
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} replica(s)", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback for device work")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from chatglm_q_amd import _lib
     _lib.get_lib()  # fail loudly if the HIP extension is missing
@@ -468,50 +609,62 @@ def main():
     torch.cuda.synchronize()
 
     stream = torch.cuda.Stream(device=device)
-    graph = None
     launch_mode = args.launch
+    # R graphs of `steps` launches; graph r starts at weight set r * steps of the rotation (docstring)
+    replays = max(1, -(-ROOF_LAUNCHES // args.steps)) if args.steps < ROOF_GRAPH else 1
+    graphs = []
     with torch.cuda.stream(stream):
         if launch_mode == "graph":
             try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
-                    run_steps(args.steps)
-                graph.replay()                      # one untimed replay
-                # ... whose `steps` weight sets (20 x 9.4 MB) would otherwise sit in the 256 MB memory-side cache for the timed
-                # replay: the OTHER sets run once more, untimed, so that the timed region streams its weights from HBM
-                # whatever --steps the caller picks
+                for r in range(replays):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        run_steps(args.steps, offset=r * args.steps)
+                    graphs.append(g)
+                for g in graphs:                    # one untimed pass
+                    g.replay()
+                # ... after which the last replays' weight sets sit in the 256 MB memory-side cache: the sets the FIRST timed replay
+                # does not touch run once more, untimed, so that the timed region streams its weights from HBM whatever --steps the
+                # caller picks
                 flush_sets = max(0, len(layers) - args.steps)
                 run_steps(flush_sets, offset=args.steps)
                 stream.synchronize()
             except Exception as e:                  # pragma: no cover - capture unsupported
                 print(f"[bench] graph capture failed ({e}); falling back to eager", file=sys.stderr)
-                graph = None
+                graphs = []
                 launch_mode = "eager"
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
+                replays = 1
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(replays)]
         launches_before = _lib.launch_count()
         barrier()
         t0 = time.perf_counter()
-        ev0.record(stream)
-        if graph is not None:
-            graph.replay()
-        else:
-            run_steps(args.steps)
-        ev1.record(stream)
+        for r in range(replays):
+            events[r][0].record(stream)
+            if graphs:
+                graphs[r].replay()
+            else:
+                run_steps(args.steps)
+            events[r][1].record(stream)
         stream.synchronize()
         barrier()
         t1 = time.perf_counter()
     wall_s = t1 - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    wall_s, ev_ms = max_over_ranks([wall_s, ev_ms], dist, device)
-    if graph is None:
+    blocks_ms = sorted(a.elapsed_time(b) for a, b in events)
+    # the clock: first event -> last event over all R x K launches of the bracket, per K steps (R == 1: the one block).  The median
+    # single block is kept beside it: a K-node graph pays its own launch latency once per replay (~0.3 us per step at K = 20), which
+    # the back-to-back stream overlaps with the previous replay's tail
+    span_ms = events[0][0].elapsed_time(events[-1][1])
+    ev_ms = span_ms / replays
+    block_med = _pct(blocks_ms, 0.5)
+    wall_s, ev_ms, block_med, ev_min, ev_max = max_over_ranks([wall_s, ev_ms, block_med, blocks_ms[0], blocks_ms[-1]], dist, device)
+    if not graphs:
         assert _lib.launch_count() - launches_before >= args.steps, "steps did not go through the HIP library"
 
     # the timed region's own HIP events (recorded inside the barrier + synchronize bracket, max over ranks) are the clock: the
     # host's perf_counter around the same bracket adds the two synchronize() round trips to a region that lasts ~6 ms at the
     # default --steps and drifts with host noise; it is kept beside the event figure
     ms_per_step = ev_ms / args.steps
-    ms_per_step_wall = wall_s * 1e3 / args.steps
+    ms_per_step_wall = wall_s * 1e3 / (args.steps * replays)
     us_per_launch_ev = ev_ms * 1e3 / args.steps
     value = whole_job_gbps(world, args.steps, bytes_per_step, ev_ms * 1e-3)
     # roofline: its own >= 1440-launch measurement on every rank (the slowest rank's median is reported)
@@ -537,6 +690,10 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6),
         "ms_per_step_wall_clock": round(ms_per_step_wall, 6),
+        "replays": replays,                                   # K-step blocks inside the one barrier + synchronize bracket
+        "steps_timed": args.steps * replays,
+        "ms_per_step_median_block": round(block_med / args.steps, 6),   # one K-step replay between its own events, median of R
+        "ms_per_step_block_min_max": [round(ev_min / args.steps, 6), round(ev_max / args.steps, 6)],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -559,10 +716,17 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            # the same fraction from the committed rocprofv3 kernel trace (average kernel duration under the profiler)
+            # the same fraction from the COMMITTED rocprofv3 kernel trace (average dispatch duration under the profiler: read from
+            # profiles/, NOT measured by this run - see rocprof_note)
             "frac_rocprof": (round(bytes_per_step / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4) if prof else None),
             "rocprof_kernel_avg_ns": prof["avg_ns"] if prof else None,
             "rocprof_source": prof_src,
+            "rocprof_note": "constant read from the committed profile summary, not a measurement of this run.  rocprofv3's dispatch duration "
+                            "(5.0 us) exceeds the unprofiled launch-to-launch interval (4.1 us) because consecutive dispatches of a stream overlap: "
+                            "the next kernel's front end (packet fetch, kernarg / code prefetch, wave launch ramp) runs under the previous "
+                            "kernel's tail, while the profiler serialises dispatches (start-to-start 7.5 us) and times each from packet "
+                            "processing to completion signal; profiles/r06_summary.json carries durations, start-to-start intervals and gaps "
+                            "of one trace side by side",
             # the floor of ONE dependent launch of this size, measured in this run (floor_leg): empty launch, pure streaming read of the
             # same bytes, device copy rate
             "floor": floor,
@@ -610,6 +774,9 @@ def main():
             result["roofline"]["token_sweep_frac"] = sweep["frac_of_8TBps"]       # 113 linear launches of one token / 8 TB/s
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline()
+    cards = gather_cards(dict(device_card(torch, device), rank=rank, roofline_median_us=round(roof["median_us"], 4),
+                              us_per_launch_timed_region=round(span_ms / replays * 1e3 / args.steps, 4)), dist, world)
+    result["ranks"] = cards
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -335,7 +335,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qv[e], kv[e], acc);
             acc = group_sum<CH>(acc);
-            const float sv = Act<T>::round(acc) + mt;
+            // ROPE (one-launch decode step): cache rows behind the row this step writes hold nothing of the sequence (the reference
+            // appends at the end of its cache, chatglm_q/model.py:148-151) - hidden whatever the mask says, as the 16-heads-per-group
+            // kernel hides them (the dispatch paths must compute one function)
+            const float sv = Act<T>::round(acc) + ((ROPE && t > wrow) ? -1e30f : mt);
             mx = fmaxf(mx, sv);                               // every lane of the group holds the same score
             if (c == 0) sc[t] = sv;
         };
@@ -654,6 +657,11 @@ __global__ __launch_bounds__(NWV * 64) void decode_attention_mfma_kernel(const T
             mr[pt][e] = mk[r < wlen ? r : wlen - 1];
         }
     const int wrow = (int)widx[0] - t_lo;                     // window-local row written by this step
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)                           // rows behind it: hidden whatever the mask says (see decode_attention_kernel)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (p0 + 16 * pt + 4 * q + e > wrow) mr[pt][e] = -1e30f;
     const bool has_new = wrow >= 0 && wrow < wlen;            // block-uniform
     const T* cs = table + clamp_pos(pos[b], cap_full) * D;
 #pragma unroll

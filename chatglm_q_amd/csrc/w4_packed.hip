@@ -23,6 +23,17 @@
 #include "w4_dequant.h"
 #include "w4_splice.h"
 
+// how the one-row kernels request their weight units: QL_GEMV_NT 1 = non-temporal loads (rounds 1 - 5), 0 = default loads (round 6's
+// pure-read sweep, bench.py roofline.floor.pure_read_sweep_us: default loads stream the same bytes 2 - 4 % faster than `nt` ones)
+#ifndef QL_GEMV_NT
+#define QL_GEMV_NT 1
+#endif
+#if QL_GEMV_NT
+#define QL_GEMV_W_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define QL_GEMV_W_LOAD(p) (*(p))
+#endif
+
 namespace ql {
 
 __device__ __forceinline__ int packed_pos(int kk) { return (kk >> 1) + 4 * (kk & 1); }
@@ -249,7 +260,7 @@ __device__ __forceinline__ void w4_packed_gemv_16_body(const T* __restrict__ A, 
         const int g = g_begin + it * 64 + lane;
         const int gc = g < g_end ? g : G - 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) tl.w[c] = __builtin_nontemporal_load(wbase + (int64_t)c * G + gc);
+        for (int c = 0; c < 4; ++c) tl.w[c] = QL_GEMV_W_LOAD(wbase + (int64_t)c * G + gc);
         tl.s = *reinterpret_cast<const u32x2*>(sbase + (int64_t)gc * 4);   // masked at use, not here:
                                                                            // touching it now would drain the queue
         if constexpr (!A_LDS) {
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(256) void w4_packed_gemv_kernel(const T* __restrict
         const int gc = g < G ? g : G - 1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            tl.w[c] = __builtin_nontemporal_load(wbase + (int64_t)c * G + gc);
+            tl.w[c] = QL_GEMV_W_LOAD(wbase + (int64_t)c * G + gc);
             tl.s[c] = Act<T>::load(sbase + (int64_t)gc * 4 + c);         // masked at use
         }
         return tl;

@@ -421,7 +421,8 @@ class ChatGLMDecoder:
             if tok_file.exists():
                 try:
                     tokenizer = SentencePieceIds(tok_file)
-                except (ImportError, OSError) as e:      # no sentencepiece module / unreadable model file: token ids only
+                except (ImportError, OSError, RuntimeError) as e:   # no sentencepiece module / unreadable or corrupt model file
+                    # (sentencepiece raises RuntimeError on a file it cannot parse): the decoder still serves token ids
                     import warnings
                     warnings.warn(f"{tok_file}: no tokenizer built ({e}); generate() takes and yields token ids only")
                 else:

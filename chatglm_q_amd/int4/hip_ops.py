@@ -84,14 +84,26 @@ def packed_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
 GEMV_MAX_ROWS = int(os.environ.get("QLINEAR_GEMV_MAX_ROWS", "2"))
 
 
+def _dispatch_key() -> int:
+    """What the library parsed from QLINEAR_DISPATCH (qlinear_dispatch_reload parses again): the routing answers cached below depend
+    on it - ADVICE r5: after a reload with `norows16` a cached "part 1 serves 5..16 rows" sent a part-1-only buffer to a kernel that
+    reads part 2."""
+    return int(_lib.get_lib().qlinear_dispatch_flags())
+
+
 @functools.lru_cache(maxsize=None)
-def rows_on_tiled(M: int, N: int, K: int, dtype: torch.dtype, strict: bool = False) -> bool:
-    """True when ``M`` rows of a (K, N) int4g32 weight are served from part 2 of the derived layout (tile-major: few-row and
-    MFMA GEMM kernels), False when part 1 serves them (GEMV, the 4x4x4-MFMA kernel for 2..4 rows, fp32)."""
-    if dtype not in (torch.float16, torch.bfloat16):
-        return False
+def _rows_on_tiled(M: int, N: int, K: int, dtype: torch.dtype, strict: bool, dispatch_key: int) -> bool:
     flags = _lib.FLAG_STRICT_ROUNDING if strict else 0
     return bool(_lib.get_lib().qlinear_w4g32_rows_on_tiled(M, N, K, _lib.dtype_code(dtype), flags))
+
+
+def rows_on_tiled(M: int, N: int, K: int, dtype: torch.dtype, strict: bool = False) -> bool:
+    """True when ``M`` rows of a (K, N) int4g32 weight are served from part 2 of the derived layout (tile-major: few-row and
+    MFMA GEMM kernels), False when part 1 serves them (GEMV, the 4x4x4-MFMA kernel for 2..4 rows, fp32).  The library's answer,
+    cached per (shape, dispatch flags)."""
+    if dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return _rows_on_tiled(M, N, K, dtype, strict, _dispatch_key())
 
 
 @functools.lru_cache(maxsize=None)
@@ -107,8 +119,12 @@ def tiled_nbytes(N: int, K: int, dtype: torch.dtype, group: int = 32) -> int:
 
 
 @functools.lru_cache(maxsize=None)
-def _workspace_nbytes(op: int, M: int, N: int, K: int, group: int) -> int:
+def _workspace_nbytes_for(op: int, M: int, N: int, K: int, group: int, dispatch_key: int) -> int:
     return int(_lib.get_lib().qlinear_workspace_bytes(op, M, N, K, group))
+
+
+def _workspace_nbytes(op: int, M: int, N: int, K: int, group: int) -> int:
+    return _workspace_nbytes_for(op, M, N, K, group, _dispatch_key())      # which kernel serves (and what it needs) follows the flags
 
 
 def _repack(entry: str, nbytes: int, b: Tensor, b_scale: Tensor) -> Tensor:

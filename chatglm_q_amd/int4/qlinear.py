@@ -164,6 +164,12 @@ class DynamicQuantizeLinear(nn.Module):
             self._build_part1()
         elif self._packed is not None and self._packed_key != self._canonical_key():
             self._build_part1()                      # a stale part 1 must not become the only copy
+        elif self._packed is None and self._gated_key[0] != self._canonical_key():
+            # only a gate-interleaved part 1 is resident (decode-only release) and the canonical buffers were written since it was
+            # built: it must not become the only copy either - rebuild the plain part 1 from the current weights and let
+            # the next fused step rebuild the gated copy
+            self._gated = None
+            self._build_part1()
         freed = self.weight.numel() * self.weight.element_size() + self.weight_scale.numel() * self.weight_scale.element_size()
         key = self._canonical_key()
         dev, sdt = self.weight.device, self.weight_scale.dtype

@@ -9,6 +9,7 @@ counters and rebuild their derived decode layout on the next forward.
 from __future__ import annotations
 
 import json
+import os
 from dataclasses import asdict, dataclass, field
 from pathlib import Path
 from typing import Optional, Union
@@ -103,7 +104,9 @@ def save_model(path: Union[str, Path], config: ChatGLMLoadConfig, model: ChatGLM
     path = Path(path)
     path.mkdir(parents=True, exist_ok=True)
     if tokenizer_file is not None:
-        shutil.copy(tokenizer_file, path / config.tokenizer_file)
+        dst = path / config.tokenizer_file
+        if not (dst.exists() and os.path.samefile(tokenizer_file, dst)):      # saving back into the folder it was loaded from
+            shutil.copy(tokenizer_file, dst)
     state = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
     if not shard:
         config.weight_files = ["model_weights.safetensors"]

@@ -326,7 +326,7 @@ def test_dispatch_override_switches_families(monkeypatch):
         lib.qlinear_dispatch_reload()
         assert lib.qlinear_gemm256_serves(8192, N, K) == 0
         assert table(4, 8192, N, K)[0] == K_W4_GEMM128 and table(4, 8, N, K)[0] == K_W4_GEMM128
-        assert h4.rows_on_tiled.__wrapped__(3, N, K, torch.float16, False) is True
+        assert h4.rows_on_tiled(3, N, K, torch.float16, False) is True
         assert part1_family(8, N, K, torch.float16, False) == 0
         monkeypatch.setenv("QLINEAR_DISPATCH", "norows4")
         lib.qlinear_dispatch_reload()

@@ -494,3 +494,51 @@ def test_default_generate_samples_on_the_device_inside_the_captured_step(monkeyp
         kw2 = dict(kw, ignore_eos=False)
         assert list(dec_eos.generate_ids(prefix, use_graph=True, seed=41, **kw2)) == ahead[:stop + 1]
         assert list(dec_eos.generate_ids(prefix, use_graph=True, seed=41, **kw2)) == ahead[:stop + 1]
+
+
+def test_routing_answers_follow_a_dispatch_reload(monkeypatch):
+    """rows_on_tiled / the workspace size were lru_cached on the shape alone; after qlinear_dispatch_reload() with
+    `norows16` Python still said "part 1 serves 5..16 rows" and handed a part-1-only buffer to a kernel that reads part 2.  The cached
+    answers are keyed on the library's dispatch flags now: the module serves 8 rows correctly under either setting."""
+    lib = _lib.get_lib()
+    K, N = 4096, 4096
+    qw, sc = _rand_w4(K, N, "f16", seed=5)
+    layer = q4.DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16, device=DEV)
+    layer.apply_weights_(qw.to(DEV), sc.to(DEV))
+    x = torch.randn(8, K, device=DEV, dtype=torch.float16)
+    ref = O.w4_matmul(t2n(x.cpu()), qw.numpy(), t2n(sc), None, dtype="f16")
+    assert h4.rows_on_tiled(8, N, K, torch.float16, False) is False           # round 5's one-launch kernel on part 1
+    y0 = layer(x)
+    try:
+        monkeypatch.setenv("QLINEAR_DISPATCH", "norows16")
+        lib.qlinear_dispatch_reload()
+        assert h4.rows_on_tiled(8, N, K, torch.float16, False) is True        # ... the few-row kernel on part 2 without it
+        fresh = q4.DynamicQuantizeLinear(K, N, bias=False, dtype=torch.float16, device=DEV)
+        fresh.apply_weights_(qw.to(DEV), sc.to(DEV))
+        y1 = fresh(x)                                                          # builds what THIS routing reads
+        y2 = layer(x)                                                          # the module that had only part 1
+    finally:
+        monkeypatch.delenv("QLINEAR_DISPATCH")
+        lib.qlinear_dispatch_reload()
+    assert h4.rows_on_tiled(8, N, K, torch.float16, False) is False
+    for y in (y0, y1, y2):
+        assert O.rel_l2(t2n(y), ref) <= 2e-4
+
+
+def test_drop_canonical_never_keeps_a_stale_gated_copy_as_the_only_copy():
+    """w_in after a decode-only release holds only its gate-interleaved part 1; an in-place weight update with no forward in
+    between left that copy stale, and drop_canonical() would have made it the only copy - state_dict() then returned the OLD weights."""
+    K, hidden = 256, 96
+    g = torch.Generator(device=DEV).manual_seed(3)
+    layer = q4.DynamicQuantizeLinear(K, 2 * hidden, bias=False, dtype=torch.float16, device=DEV)
+    layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g))
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=DEV, generator=g) * 0.01 + 0.002).half())
+    layer.gated_packed(hidden)
+    if layer._packed is not None:
+        layer.release("packed")
+    assert layer._packed is None and layer._gated is not None
+    new_w = torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=DEV, generator=g)
+    layer.weight.copy_(new_w)                                                  # in place: version bump, no forward
+    assert layer.drop_canonical() > 0
+    sd = layer.state_dict()
+    assert torch.equal(sd["weight"], new_w)

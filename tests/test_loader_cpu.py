@@ -59,3 +59,24 @@ def test_decoder_from_pretrained_folder_roundtrip(tmp_path):
     assert again.model_config == lc.model_config and again.quant_type == "int4g32" and again.weight_files
     with pytest.raises(FileNotFoundError):
         ChatGLMDecoder.from_pretrained(tmp_path / "nope")
+
+
+def test_save_back_into_the_folder_it_was_loaded_from(tmp_path):
+    """from_pretrained records the folder's tokenizer file and save_pretrained copies it - saving back into the same folder
+    raised shutil.SameFileError.  And a corrupt sentencepiece file no longer aborts from_pretrained (token ids are still served)."""
+    import warnings
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    lc = L.ChatGLMLoadConfig(model_config=tiny_cfg(), quant_type="int4g32", torch_dtype="float32")
+    model = M.fill_synthetic_(L.build_model(lc), seed=6)
+    folder = tmp_path / "m"
+    L.save_model(folder, lc, model, shard=False)
+    (folder / lc.tokenizer_file).write_bytes(b"not a sentencepiece model")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        dec = ChatGLMDecoder.from_pretrained(folder, device="cpu")
+    assert dec.tokenizer is None and any("no tokenizer built" in str(x.message) for x in w)
+    assert dec.tokenizer_file is not None
+    dec.save_pretrained(folder)                                                # same folder: no SameFileError
+    assert (folder / lc.tokenizer_file).read_bytes() == b"not a sentencepiece model"
+    dec.save_pretrained(tmp_path / "other")
+    assert (tmp_path / "other" / lc.tokenizer_file).read_bytes() == b"not a sentencepiece model"

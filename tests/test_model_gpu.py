@@ -706,3 +706,37 @@ def test_int8_activation_gate_epilogue_equals_separate_ops(dtype, bias, M):
     small = Q8(K, 2 * hidden, bias=bias, dtype=dtype, device=DEV)
     small.act_quant = True
     assert small.forward_quantized_gated(a_q[:40], a_s[:40], hidden) is None and small._gated_tiled is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("geom", [(2, 32, 2, 128, 256, 100), (1, 32, 2, 128, 516, 300), (2, 4, 2, 32, 64, 20)])
+def test_rows_behind_the_write_index_are_hidden_by_every_attention_kernel(dtype, geom, monkeypatch):
+    """the 16-heads-per-group kernel hides every cache row behind widx[0] whatever the mask says; the per-head kernels (fp32,
+    D != 128, QLINEAR_DISPATCH=nogroupattn) honoured the mask alone - two functions for one (mask, widx).  Now all of them hide those rows:
+    a mask that (wrongly) opens rows behind the write index gives the result of the correct mask, on every path."""
+    from chatglm_q_amd import _lib
+    from chatglm_q_amd import fused_ops as F_
+    from chatglm_q_amd import model as M
+    B, H, Gq, D, cap, n = geom
+    g = torch.Generator(device=DEV).manual_seed(21)
+    qkv = torch.randn(B, 1, (H + 2 * Gq) * D, device=DEV, generator=g).to(dtype)
+    table = M.rotary_table(D, cap + 8).to(DEV).to(dtype).reshape(cap + 8, -1).contiguous()
+    pos = torch.full((B, 1), n + 1, dtype=torch.long, device=DEV)
+    widx = torch.tensor([n], dtype=torch.long, device=DEV)
+    good = torch.full((B, 1, cap), -1e10, device=DEV)
+    good[:, :, : n + 1] = 0
+    open_behind = torch.zeros((B, 1, cap), device=DEV)                       # nothing hidden: rows n + 1 .. cap - 1 hold garbage
+    for flag in ("nogroupattn", ""):
+        monkeypatch.setenv("QLINEAR_DISPATCH", flag)
+        _lib.get_lib().qlinear_dispatch_reload()
+        outs = []
+        for mask in (good, open_behind):
+            g2 = torch.Generator(device=DEV).manual_seed(22)
+            k = (torch.randn(B, cap, Gq, D, device=DEV, generator=g2) * 4).to(dtype)
+            v = (torch.randn(B, cap, Gq, D, device=DEV, generator=g2) * 4).to(dtype)
+            outs.append(F_.decode_attention_rope(qkv, table, pos, widx, k, v, mask, H, Gq, D, split=cap > 256))
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[1].float()).all()
+        assert torch.equal(outs[0], outs[1]), flag
+    monkeypatch.delenv("QLINEAR_DISPATCH")
+    _lib.get_lib().qlinear_dispatch_reload()

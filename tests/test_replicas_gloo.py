@@ -59,3 +59,53 @@ def test_two_replicas_max_over_ranks_and_aggregate_value():
 
 def test_single_process_passthrough():
     assert bench.max_over_ranks([0.5, 3.0], None, None) == [0.5, 3.0]
+
+
+def _last_json_line(text):
+    import json
+    lines = [ln for ln in text.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text                      # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_spawns_n_replicas_itself():
+    """`python bench.py --gpus 2` with no launcher around it (--gpus was parsed and never read): two worker processes,
+    one rendezvous, rank 0 prints the one line with n_gpus 2 and one card per rank.  Dry mode (gloo, CPU, no kernel) - what can
+    run here; the GPU box runs the same path with nccl and two devices; test_bench_refuses_more_gpus_than_visible checks the refusal."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    line = _last_json_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 7 and line["dry_run"] is True and line["value"] is None
+    assert line["scaling"] == "weak" and line["config"]["parallelism"] == "replicas"
+    assert [c["rank"] for c in line["ranks"]] == [0, 1] and line["ranks"][0]["pid"] != line["ranks"][1]["pid"]
+    assert line["max_over_ranks_is_slowest_rank"] is True
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 (RANK / WORLD_SIZE from the env)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _last_json_line(out.stdout)
+    assert line["n_gpus"] == 2 and len(line["ranks"]) == 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, n)), "--steps", "3"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "visible" in out.stderr and not out.stdout.strip()

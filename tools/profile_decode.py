@@ -13,5 +13,6 @@ for m in model.modules():
 dec = ChatGLMDecoder(None, model)
 prompt = [(37 * i + 11) % cfg.vocab_size for i in range(32)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-toks = list(dec.generate_ids(prompt, max_generated_tokens=n, greedy=True, ignore_eos=True, use_graph=True))
-print(dec.last_stats)
+greedy = "sampled" not in sys.argv[2:]                 # `sampled`: the reference's default mode (device sampler inside the graph)
+toks = list(dec.generate_ids(prompt, max_generated_tokens=n, greedy=greedy, ignore_eos=True, use_graph=True, seed=1))
+print("greedy" if greedy else "sampled", dec.last_stats)
