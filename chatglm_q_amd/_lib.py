@@ -158,6 +158,8 @@ DEV_EXPORTS = {
                                          c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "qlinear_dev_dense256_image_bytes": (c_size_t, [c_int64, c_int64]),
     "qlinear_dev_dense256_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "qlinear_dev_w8a8_splitk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "qlinear_dev_w8a8_fwd_tiled_splitk": (c_int, [c_void_p] * 6 + [c_int64] * 4 + [c_int, c_void_p, c_size_t, c_void_p]),
     "qlinear_dev_dense256_fwd": (c_int, [c_void_p] * 5 + [c_int64] * 6 + [c_int, c_int, c_void_p]),
 }
 
@@ -176,6 +178,27 @@ def _lib_stamp():
         return (True, os.stat(LIB_PATH).st_mtime_ns)
     except OSError:
         return (False, 0)
+
+
+# Which kernel a call takes - and so which derived layout it reads - follows QLINEAR_DISPATCH as the library parsed it; a reload
+# (qlinear_dispatch_reload: tests, A/B tools) can change it under every routing answer Python has cached and under every pre-bound
+# launch.  The handle's `qlinear_dispatch_reload` attribute is wrapped so that a reload bumps this counter; plans compare it per call
+# (a Python int), cached routing answers are keyed on the flags themselves (int4/hip_ops.py).  ADVICE r5 (medium).
+_dispatch_epoch = [0]
+
+
+def dispatch_epoch() -> int:
+    return _dispatch_epoch[0]
+
+
+def _wrap_dispatch_reload(lib):
+    raw = lib.qlinear_dispatch_reload
+
+    def qlinear_dispatch_reload():
+        raw()
+        _dispatch_epoch[0] += 1
+
+    lib.qlinear_dispatch_reload = qlinear_dispatch_reload
 
 
 def _try_load():
@@ -197,6 +220,7 @@ def _try_load():
         ver = lib.qlinear_abi_version()
         if ver != ABI_VERSION:
             raise OSError(f"{LIB_PATH}: ABI version {ver}, expected {ABI_VERSION}")
+        _wrap_dispatch_reload(lib)
         _lib = lib
     except (OSError, AttributeError) as e:  # missing file, missing dependency or missing symbol
         _load_error = e
@@ -241,6 +265,7 @@ def get_dev_lib():
         except (OSError, AttributeError) as e:
             raise QLinearLibraryMissing(f"libqlinear_hip_dev.so is not available ({e}); build it with "
                                         f"`make -C {os.path.join(_HERE, 'csrc')} dev`") from None
+        _wrap_dispatch_reload(lib)
         _dev_lib = lib
     return _dev_lib
 
@@ -311,8 +336,11 @@ def make_plan(name: str, values, a_slot: int, c_slot: int, st_slot: int, rows: i
     (g0, v0, p0), (g1, v1, p1), (g2, v2, p2) = (g + ((None, None, 0),) * 3)[:3]
     g_rest = g[3:]
     shape_memo = [None, None]                               # last input shape seen -> its output shape
+    epoch0, epoch = _dispatch_epoch[0], _dispatch_epoch     # the routing this plan was built under
 
     def run(x, *ex):
+        if epoch[0] != epoch0:                              # QLINEAR_DISPATCH reloaded: another kernel / layout may serve this call now
+            return None
         if (x.dtype is not dtype or x.numel() != numel or x.get_device() != idx
                 or not x.is_contiguous() or (x.requires_grad and torch.is_grad_enabled())):
             return None

@@ -133,4 +133,21 @@ int qlinear_dev_dense256_fwd(const void* A, const void* image, const void* bias,
     return dense256(dtype, gate != 0, A, image, bias, residual, C, M, N, K, lda, ldc, ldr, (hipStream_t)stream);
 }
 
+size_t qlinear_dev_w8a8_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || !w8a8_splitk_serves(M, N, K)) return 0;
+    return w8a8_splitk_workspace_bytes(M, N);
+}
+
+int qlinear_dev_w8a8_fwd_tiled_splitk(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                                  int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!Aq || !a_scale || !tiled || !S || !C) return QL_ERR_NULL_POINTER;
+    if (dtype != QL_DTYPE_F32 && dtype != QL_DTYPE_F16 && dtype != QL_DTYPE_BF16) return QL_ERR_BAD_DTYPE;
+    if (!fits_i32(M) || !fits_i32(N) || !fits_i32(K) || ldc < N) return QL_ERR_BAD_SHAPE;
+    if (!aligned(Aq, 16) || !aligned(tiled, 16)) return QL_ERR_MISALIGNED;
+    if (!w8a8_splitk_serves(M, N, K)) return QL_ERR_UNSUPPORTED;
+    if (!workspace || !aligned(workspace, 256) || workspace_bytes < w8a8_splitk_workspace_bytes(M, N)) return QL_ERR_WORKSPACE;
+    return w8a8_gemm_tiled_splitk(dtype, Aq, a_scale, (const int8_t*)tiled, S, bias, C, M, N, K, ldc, workspace, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -222,6 +222,11 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
                       hipStream_t st);
 int w8a8_gemm_tiled(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
                     int64_t M, int64_t N, int64_t K, int64_t ldc, hipStream_t st);
+// 128 x 128 tiles x 2 grid-level K slices (config 3's shape class); ws zeroed once by its owner
+size_t w8a8_splitk_workspace_bytes(int64_t M, int64_t N);
+bool w8a8_splitk_serves(int64_t M, int64_t N, int64_t K);
+int w8a8_gemm_tiled_splitk(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
+                           int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, hipStream_t st);
 int w8a8_gemm(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* W, const void* S, const void* bias,
               void* C, int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st);
 size_t w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);

@@ -241,24 +241,25 @@ int act_quant_rowwise(int dtype, const void* A, int8_t* Aq, float* a_scale, int6
 // W fragments global -> VGPR, A pieces global -> LDS by LDS-DMA (no VGPR round trip, no ds_write pass: the ablation builds put
 // the ds_write pass at 2.7 of the loop's 8.4 us).  Loads complete in issue order, so "operand X has landed" = "at most N
 // younger loads are still outstanding"; the issue order is fixed at compile time, these functions restate it.
-//   prologue:            A(0) W(0) [PF PF] A(1) W(1) A(2)                      (A(k): 4 pieces, W(k): 8 fragments of chunk-iteration k)
+//   prologue:            A(0) W(0) [PF PF] A(1) W(1) A(2)                      (A(k): 4 pieces, W(k): 4 S fragments of chunk-iteration k)
 //   iteration j, behind the MFMAs of sub-step s:   W(j + 2, s)   then   A(j + 3, s) if s < 4
 #ifndef QL_W8A8_PF
 #define QL_W8A8_PF 0                                // L2-prefetch instructions per wave behind W(0) (0: none; 2 measured 18.5 vs 17.1 us cold, 16.7 vs 14.0 us cache-hot: a 64-line gather costs the load path more than it saves)
 #endif
-constexpr int kAdmaPieces = 4, kAdmaSubs = 8, kAdmaPf = QL_W8A8_PF, kAdmaPrologue = 3 * kAdmaPieces + 2 * kAdmaSubs + kAdmaPf;
+constexpr int kAdmaPieces = 4, kAdmaPf = QL_W8A8_PF;
+constexpr int adma_prologue(int subs) { return 3 * kAdmaPieces + 2 * subs + kAdmaPf; }      // subs: W fragments per chunk iteration (4 S)
 constexpr int adma_min(int a, int b) { return a < b ? a : b; }
-constexpr int adma_issued_before(int niter, int j, int s) {      // loads issued before sub-step s of iteration j begins (closed
+constexpr int adma_issued_before(int subs, int niter, int j, int s) {      // loads issued before sub-step s of iteration j begins (closed
     // form, no loops: inner loops with a trip count that depends on the unrolled index kept hipcc from unrolling the K loop)
-    return kAdmaPrologue + kAdmaSubs * adma_min(j, niter > 2 ? niter - 2 : 0) + kAdmaPieces * adma_min(j, niter > 3 ? niter - 3 : 0) +
+    return adma_prologue(subs) + subs * adma_min(j, niter > 2 ? niter - 2 : 0) + kAdmaPieces * adma_min(j, niter > 3 ? niter - 3 : 0) +
            (j + 2 < niter ? s : 0) + (j + 3 < niter ? adma_min(s, kAdmaPieces) : 0);
 }
-constexpr int adma_idx_w(int niter, int k, int s) {              // position of W(k, s) in the issue order
-    return k == 0 ? kAdmaPieces + s : k == 1 ? 2 * kAdmaPieces + kAdmaSubs + kAdmaPf + s : adma_issued_before(niter, k - 2, s);
+constexpr int adma_idx_w(int subs, int niter, int k, int s) {              // position of W(k, s) in the issue order
+    return k == 0 ? kAdmaPieces + s : k == 1 ? 2 * kAdmaPieces + subs + kAdmaPf + s : adma_issued_before(subs, niter, k - 2, s);
 }
-constexpr int adma_idx_a_last(int niter, int k) {                // position of the last piece of A(k)
-    return k == 0 ? kAdmaPieces - 1 : k == 1 ? 2 * kAdmaPieces + kAdmaSubs + kAdmaPf - 1 : k == 2 ? kAdmaPrologue - 1
-                  : adma_issued_before(niter, k - 3, kAdmaPieces - 1) + 1;
+constexpr int adma_idx_a_last(int subs, int niter, int k) {                // position of the last piece of A(k)
+    return k == 0 ? kAdmaPieces - 1 : k == 1 ? 2 * kAdmaPieces + subs + kAdmaPf - 1 : k == 2 ? adma_prologue(subs) - 1
+                  : adma_issued_before(subs, niter, k - 3, kAdmaPieces - 1) + 1;
 }
 // NITER > 0: the K loop fully unrolled for exactly NITER iterations per K-parity group (K = NITER * KP * BK, no K tail): every
 // prefetch condition is a compile-time constant, so hipcc's vmcnt waits are exact counts.  Round 3, read in the ISA: with
@@ -267,11 +268,23 @@ constexpr int adma_idx_a_last(int niter, int k) {                // position of 
 // head of every iteration - load latency, LDS staging and MFMAs in series, 1.2 us per iteration where each alone is 0.3 - 0.5.
 // The unrolled form also spreads the next loads / LDS stores over the sub-steps (one W load behind each MFMA pair) instead
 // of issuing 10 KB per wave in one burst at the end of the iteration, where all 8 waves queue at the CU's 64 B/clk load path.
-template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false, int NITER = 0, bool ADMA = false>
+// ---- SK = 2 (round 6): a GRID-level K split on top of the two K-parity groups of a block ----------------------------------------
+// Config 3 (512 x 4096 x 4096) covers the chip with 64 x 128 tiles = 256 blocks x (64 + 128) rows x 4096 B = 201 MB pulled out of the L2s
+// for 25 MB of operands; its load-only floor is 12.7 us from HBM (tools/microbench/l2_share_probe2.hip).  128 x 128 tiles x 2 K slices
+// are 256 blocks too, pull 134 MB (floor 9.3 us) and cost one exact int32 hand-off per tile pair: the two blocks of a tile take a
+// ticket from a per-tile counter at ENTRY (the atomic's round trip hides under the K loop); the even ticket PUBLISHES its 128 x 128
+// partial (64 KB, lane-linear 16-byte pieces), release, flag = ticket + 1; the odd ticket waits for the flag (its partner holds a ticket,
+// so it is running: no dependence on an unscheduled block), acquire, adds the pieces and runs the epilogue.  Integer sums: bit-equal
+// to the unsplit kernel.  splitk_ws: uint32 tickets[kSplitkMaxTiles] | flags[kSplitkMaxTiles] | partial tiles; zeroed ONCE by the host,
+// never reset (tickets only count up: their parity is the role, their value the epoch) - the layout does not depend on the shape, so
+// launches of different shapes may take turns on one workspace (a shape-dependent layout let one shape's flags become another's tickets:
+// odd first tickets, finishers without a publisher - caught by tools/w8a8_splitk_debug.py).
+constexpr int kSplitkMaxTiles = 1024;
+template <typename T, int MT, int S, int DEPTH, int NG, bool COLG = false, int NITER = 0, bool ADMA = false, int SK = 1>
 __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(const int8_t* __restrict__ Aq, const int8_t* __restrict__ Wm, int M,
                                                          int N, int K, int nbx, int rotate, int super_rows, const float* __restrict__ a_scale,
                                                          const T* __restrict__ S_, const T* __restrict__ bias,
-                                                         T* __restrict__ C, int64_t ldc) {
+                                                         T* __restrict__ C, int64_t ldc, unsigned* __restrict__ splitk_ws = nullptr) {
     // One loop iteration of a K-parity group covers a CHUNK of BK = 128 S bytes of K (S 128-byte steps = 2 S tile-major
     // units = 4 S MFMA sub-steps): S = 2 halves the barriers per byte; MT = 4 keeps S = 1 (LDS).
     constexpr int BM = 32 * MT;
@@ -294,12 +307,31 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform on purpose: chunk indices, the K-tail
     const int grp = NG == 1 ? 0 : wave >> 2, wv = wave & 3;       // tests and the buffer bases then live in SGPRs
     const int j = lane & 31, kb = lane >> 5;
-    const TileXY tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    static_assert(SK == 1 || (SK == 2 && NITER > 0 && ADMA && !COLG && NG == 2), "the grid-level K split exists for the unrolled LDS-DMA form");
+    int slice = 0, tile_id = 0;
+    TileXY tile;
+    if constexpr (SK == 1) {
+        tile = super_rows ? xcd_tile_super(blockIdx.x, gridDim.x, nbx, super_rows) : xcd_tile(blockIdx.x, gridDim.x, nbx);
+    } else {
+        // an XCD's contiguous positions = (tile, slice) pairs, slice fastest (partners share an L2), tiles column-major: the XCD owns
+        // whole column tiles x every row tile x both slices - the sharing pattern the probe priced
+        const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3, q8 = gridDim.x >> 3, r8 = gridDim.x & 7u;
+        const unsigned p = (c < r8 ? c * (q8 + 1) : r8 * (q8 + 1) + (c - r8) * q8) + i;
+        const unsigned nby = (gridDim.x / SK) / (unsigned)nbx;
+        tile_id = (int)(p / SK);
+        slice = (int)(p % SK);
+        tile = TileXY{(int)((unsigned)tile_id / nby), (int)((unsigned)tile_id % nby)};
+    }
+    __shared__ unsigned s_ticket;
+    if constexpr (SK > 1) {
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(splitk_ws + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int m0 = tile.y * BM, n0 = tile.x * BN;
     const int kgrp = COLG ? 0 : grp;                   // K-parity index of this group
     const int ksteps64 = (K + 63) >> 6;                // tile-major units per column tile
     const int nchunks = (K + BK - 1) / BK;
-    const int niter = KP == 1 ? nchunks : (nchunks + 1) >> 1;   // both groups run the same number of iterations (barriers!)
+    const int chunk0 = SK == 1 ? 0 : slice * (nchunks / SK);    // first K chunk of this block's slice (SK > 1: nchunks % (SK KP) == 0)
+    const int niter = SK > 1 ? nchunks / (SK * KP) : KP == 1 ? nchunks : (nchunks + 1) >> 1;   // both groups run the same number of iterations (barriers!)
     const int ctiles = (N + 31) >> 5;
     const int ct_raw = tile.x * (BN / 32) + (COLG ? grp * 4 : 0) + wv;
     const int8_t* wbase = Wm + (int64_t)(ct_raw < ctiles ? ct_raw : ctiles - 1) * ksteps64 * 2048 + lane * 16;
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     auto chunk_of = [&](int i) {                       // K chunk of loop iteration i (i may run past niter: clamped by users)
         int r = i + rot;
         r = r >= niter ? r - niter : r;
-        return KP * r + kgrp;
+        return chunk0 + KP * r + kgrp;
     };
     auto load_w = [&](int i, Stage& sg) {
         int t = chunk_of(i < niter ? i : niter - 1);
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
     };
 
     if constexpr (NITER > 0 && ADMA) {
-        static_assert(DEPTH == 2 && S == 2 && ACH == kAdmaPieces && NS == kAdmaSubs && kAllStage, "the issue order restated by adma_*()");
+        static_assert(DEPTH == 2 && ACH == kAdmaPieces && NS >= kAdmaPieces && kAllStage, "the issue order restated by adma_*()");
         // per-lane source offsets of the A pieces: LDS-DMA writes lane-linear, so the swizzle goes into the SOURCE address -
         // the thread at chunk position q of the tile (row q / CPR, position cp = q % CPR) fetches source chunk cp ^ swz(row)
         unsigned a_off[ACH];
@@ -486,7 +518,7 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
 #pragma unroll
         for (int u = 0; u < ACH; ++u) issue_a(2, u);
         QL_STAMP(1);
-        vm_wait_imm<kAdmaPrologue - adma_idx_a_last(NITER, 1) - 1>();     // A(0), A(1) have landed (this wave's pieces)
+        vm_wait_imm<adma_prologue(NS) - adma_idx_a_last(NS, NITER, 1) - 1>();     // A(0), A(1) have landed (this wave's pieces)
         __syncthreads();
         QL_STAMP(2);
         read_a(0, 0, fa[0]);
@@ -498,14 +530,14 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
                 if constexpr (sub + 1 < NS) read_a(buf, sub + 1, fa[(sub + 1) & 1]);
                 else if constexpr (i + 1 < NITER) read_a(nbuf, 0, fa[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                vm_wait_imm<adma_issued_before(NITER, i, sub) - adma_idx_w(NITER, i, sub) - 1>(wr[i % DEPTH][sub]);
+                vm_wait_imm<adma_issued_before(NS, NITER, i, sub) - adma_idx_w(NS, NITER, i, sub) - 1>(wr[i % DEPTH][sub]);
                 if constexpr (i == 1 && sub == 0 && kAdmaPf == 2) asm volatile("" : "+v"(pf0), "+v"(pf1));   // older than W(1): landed; registers free from here
                 mma(fa[sub & 1], wr[i % DEPTH][sub]);
                 if constexpr (i + 2 < NITER) issue_w(i + 2, sub);
                 if constexpr (sub < ACH && i + 3 < NITER) issue_a(i + 3, sub);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (i + 2 < NITER) vm_wait_imm<adma_issued_before(NITER, i + 1, 0) - adma_idx_a_last(NITER, i + 2) - 1>();   // A(i + 2) landed
+            if constexpr (i + 2 < NITER) vm_wait_imm<adma_issued_before(NS, NITER, i + 1, 0) - adma_idx_a_last(NS, NITER, i + 2) - 1>();   // A(i + 2) landed
             if constexpr (i + 1 < NITER) __syncthreads();
         });
         QL_STAMP(3);
@@ -669,6 +701,63 @@ __global__ __launch_bounds__(NG * 256, NG == 1 ? 2 : 1) void w8a8_tiled_kernel(c
         __syncthreads();                                                       // LDS is reused for the output tiles below
     }
     QL_STAMP(5);                                       // K-parity groups combined
+    if constexpr (SK == 2) {
+        unsigned* flag = splitk_ws + kSplitkMaxTiles;                          // fixed layout: one workspace serves every shape in turn
+        constexpr int kPieces = OWN * 4;                                       // 16-byte pieces per lane
+        i32x4* mine = reinterpret_cast<i32x4*>(splitk_ws + 2 * kSplitkMaxTiles) + ((size_t)tile_id * (NG * 4) + (grp * 4 + wv)) * (kPieces * 64) + lane;
+        const unsigned ticket = s_ticket;                                      // written before the K loop's first barrier
+        // The hand-off itself in the guide's "drained sc1" form (MI355X_MICROARCH.md, hand-off price list, R1): 16-byte WRITE-THROUGH stores
+        // (sc0 sc1: the bytes leave the XCD's L2), every storing wave drains its own stores (vmcnt(0)), block barrier, ONE relaxed
+        // agent-scope flag store; the reader polls with ONE lane and fetches the pieces with sc0 sc1 loads (L1 bypassed) - no release /
+        // acquire fence anywhere.  (First version: plain stores + an agent-scope release fence in all 512 threads = `buffer_wbl2 sc1` x 2048
+        // per launch: the publishers spent 20.6 us behind their K loop, profiles/r06_w8a8_config3_splitk.txt.)
+        if ((ticket & 1u) == 0) {                                              // publisher
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {                                  // compile-time register indices: no `2 o + grp`
+                if (!owns(mt)) continue;
+                const int o = own_slot(mt);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const i32x4 v = {acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + (o * 4 + q) * 64), "v"(v) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + tile_id, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            QL_STAMP(6);
+            return;
+        }
+        if (tid == 0) {                                                        // finisher: the partner took ticket - 1, so it is running
+            unsigned spins = 0;
+            while (__hip_atomic_load(flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) {
+#ifdef QL_SPLITK_DEBUG
+                if (++spins > (1u << 18)) { __hip_atomic_store(flag + tile_id, 0xDEAD0000u | (ticket & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+#else
+                if (++spins > (1u << 24)) __builtin_trap();                    // seconds: a lost partner must be loud, not a hang
+#endif
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        {
+            i32x4 other[OWN * 4];
+#pragma unroll
+            for (int i = 0; i < OWN * 4; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(other[i]) : "v"(mine + i * 64) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (!owns(mt)) continue;
+                const int o = own_slot(mt);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][4 * q + e] += other[o * 4 + q][e];
+            }
+        }
+        __syncthreads();                                                       // the epilogue reuses LDS; everyone past the loads
+    }
 
     if (QL_W8A8_ABLATE & 64) {                         // no epilogue: one store keeps the accumulators alive
         int x = 0;
@@ -727,6 +816,44 @@ static int launch_w8a8_tiled_mt(const int8_t* Aq, const float* a_scale, const in
         (const T*)bias, (T*)C, ldc);
     return finish_launch(QL_K_W8A8_TILED);
 }
+
+#ifdef QL_DEV_EXPERIMENTS     // recorded experiment (measured slower: include/qlinear_hip_dev.h), developer library only
+// 128 x 128 tiles x 2 grid-level K slices (SK = 2 above): M % 128 == 0, N % 128 == 0, K % 512 == 0 (two slices x two parity groups x
+// NITER chunks of 128 bytes).  ws: w8a8_splitk_workspace_bytes(), zeroed once by its owner.
+size_t w8a8_splitk_workspace_bytes(int64_t M, int64_t N) {
+    const size_t tiles = (size_t)((M + 127) / 128) * (size_t)((N + 127) / 128);
+    return (size_t)(2 * kSplitkMaxTiles) * 4 + tiles * (size_t)(128 * 128 * 4);
+}
+bool w8a8_splitk_serves(int64_t M, int64_t N, int64_t K) {
+    return K == 4096 && M % 128 == 0 && N % 128 == 0 && M >= 128 && (M / 128) * (N / 128) <= kSplitkMaxTiles && (M / 128) * (N / 128) * 2 <= 2 * (int64_t)cu_count() &&
+           (M / 128) * (N / 128) * 2 >= (int64_t)cu_count() / 2 && M * K < ((int64_t)1 << 31);
+}
+template <typename T>
+static int launch_w8a8_tiled_sk2(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* Sc, const void* bias, void* C,
+                                 int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, hipStream_t st) {
+    constexpr int MT = 4, S = 1, NITER = 8;
+    const int nbx = (int)(N / 128), nby = (int)(M / 128);
+    constexpr int kLds = 2 * 4 * (32 * MT) * 128 * S;                          // two K-parity groups x four LDS-DMA buffers
+    static bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_tiled_kernel<T, MT, S, 2, 2, false, NITER, true, 2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLds) == hipSuccess;
+    }();
+    (void)attr_set;
+    w8a8_tiled_kernel<T, MT, S, 2, 2, false, NITER, true, 2><<<(unsigned)(nbx * nby * 2), 512, kLds, st>>>(
+        Aq, Wm, (int)M, (int)N, (int)K, nbx, 0, 0, a_scale, (const T*)Sc, (const T*)bias, (T*)C, ldc, (unsigned*)ws);
+    return finish_launch(QL_K_W8A8_TILED);
+}
+int w8a8_gemm_tiled_splitk(int dtype, const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,
+                           int64_t M, int64_t N, int64_t K, int64_t ldc, void* ws, hipStream_t st) {
+    switch (dtype) {
+    case QL_DTYPE_F32: return launch_w8a8_tiled_sk2<float>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, ws, st);
+    case QL_DTYPE_F16: return launch_w8a8_tiled_sk2<f16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, ws, st);
+    case QL_DTYPE_BF16: return launch_w8a8_tiled_sk2<__bf16>(Aq, a_scale, Wm, S, bias, C, M, N, K, ldc, ws, st);
+    default: return QL_ERR_BAD_DTYPE;
+    }
+}
+
+#endif
 
 template <typename T>
 static int launch_w8a8_tiled(const int8_t* Aq, const float* a_scale, const int8_t* Wm, const void* S, const void* bias, void* C,

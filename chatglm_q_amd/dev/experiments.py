@@ -303,3 +303,34 @@ def dense256_forward(a: Tensor, image: Tensor, n_out: int, bias: Tensor | None =
                                           _lib.stream_ptr(a.device))
     _lib.check(st, "qlinear_dev_dense256_fwd")
     return c.reshape(*a.shape[:-1], cols)
+
+
+# ---- round 6: config 3's GEMM on 128 x 128 tiles with a grid-level K split (measured slower: include/qlinear_hip_dev.h) --------------
+# The kernel keeps per-tile ticket counters in a workspace its owner zeroes ONCE: one per (device, stream) here.
+_splitk_ws: dict = {}
+
+
+def w8a8_splitk_serves(M: int, N: int, K: int) -> int:
+    """Workspace bytes of the 128 x 128-tile x 2-K-slice kernel for the shape, 0 when it does not serve it."""
+    return int(_lib.get_dev_lib().qlinear_dev_w8a8_splitk_workspace_bytes(M, N, K))
+
+
+def w8a8_gemm_tiled_splitk(a_q: Tensor, a_s: Tensor, tiled: Tensor, n_out: int, w_scale: Tensor, bias: Tensor | None = None) -> Tensor:
+    """``qlinear_dev_w8a8_fwd_tiled_splitk``: bit-equal to int8.hip_ops.w8a8_gemm_tiled (integer sums, the same epilogue)."""
+    lib = _lib.get_dev_lib()
+    M, K = a_q.shape
+    nbytes = w8a8_splitk_serves(M, n_out, K)
+    if not nbytes:
+        raise ValueError(f"the split-K kernel does not serve {M} x {K} x {n_out}")
+    dev = a_q.device
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _splitk_ws[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    c = torch.empty((M, n_out), device=dev, dtype=w_scale.dtype)
+    with torch.cuda.device(dev):
+        st = lib.qlinear_dev_w8a8_fwd_tiled_splitk(a_q.data_ptr(), a_s.data_ptr(), tiled.data_ptr(), w_scale.contiguous().data_ptr(),
+                                                   _lib.ptr(bias), c.data_ptr(), M, n_out, K, n_out, _lib.dtype_code(w_scale.dtype),
+                                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(st, "qlinear_dev_w8a8_fwd_tiled_splitk")
+    return c

@@ -6,6 +6,8 @@ chatglm_q/int8/qlinear.py:56-70 and chatglm_q/int8/quantizer.py:11-19.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 

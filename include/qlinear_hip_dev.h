@@ -77,6 +77,23 @@ int qlinear_dev_dense256_expand(const void* tiled, const void* S, void* image, i
 int qlinear_dev_dense256_fwd(const void* A, const void* image, const void* bias, const void* residual, void* C, int64_t M, int64_t N, int64_t K,
                              int64_t lda, int64_t ldc, int64_t ldr, int dtype, int gate, void* stream);
 
+
+/* round 6 experiment, measured SLOWER and therefore here (profiles/r06_w8a8_config3_splitk.txt: 21.5 us against 17.0 for the GEMM of
+ * config 3 - the load-only floor fell from 12.7 to 9.3 us as the probe promised, the K loop from 10.4 to 9.5 us, and the exact int32 hand-off
+ * between the two workgroups of a tile costs 2.2 us on the publishing and 6.4 us on the finishing side).
+ * int8 activations x tile-major int8 weights on 128 x 128 tiles with a GRID-level K split by 2 (csrc/w8a8.hip, SK = 2): the shape
+ * class of BASELINE config 3 (512 x 4096 -> 4096: too few rows to cover the chip with tall tiles), where the 64 x 128-tile kernel of
+ * qlinear_w8a8_fwd_tiled pulls 201 MB of operands out of the L2s for 25 MB of data.  Twice the tile, half the K range per workgroup,
+ * one exact int32 hand-off per tile pair through `workspace`: results are bit-equal to qlinear_w8a8_fwd_tiled (integer sums, the same
+ * epilogue).  qlinear_dev_w8a8_splitk_workspace_bytes: 0 when the shape is not served (then call qlinear_w8a8_fwd_tiled), else the size of
+ * `workspace` - which the caller zeroes ONCE after allocating it and then only hands back: the kernel keeps per-tile ticket counters in
+ * it that count up across calls (their parity is a workgroup's role, their value the epoch of the hand-off flag).  One workspace per
+ * stream of launches (two launches must not share it concurrently).  QL_ERR_UNSUPPORTED for other shapes, QL_ERR_WORKSPACE when small. */
+size_t qlinear_dev_w8a8_splitk_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int qlinear_dev_w8a8_fwd_tiled_splitk(const int8_t* Aq, const float* a_scale, const void* tiled, const void* S, const void* bias, void* C,
+                                  int64_t M, int64_t N, int64_t K, int64_t ldc, int dtype, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

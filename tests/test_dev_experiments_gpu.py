@@ -218,3 +218,41 @@ def test_dense256_two_launch_gemm_matches_the_fused_kernel(M, K, N, bias, dtype)
         want8 = H8.w8_forward_tiled(x, t8, N, l8.weight_scale, l8.bias)
         got8 = X.dense256_forward(x, X.dense256_image(t8, N, K, dtype, scale=l8.weight_scale), N, l8.bias)
         assert O.rel_l2(t2n(got8), t2n(want8)) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N", [(512, 4096), (256, 4096), (384, 4608), (1024, 4096)])
+def test_w8a8_grid_split_k_equals_the_product_kernel_bit_for_bit(M, N, dtype):
+    """Round 6 experiment (BASELINE config 3's shape class): int8 x int8 on 128 x 128 tiles x 2 grid-level K slices with an exact int32
+    hand-off between the two workgroups of a tile.  Integer sums and the same epilogue: bit-equal to qlinear_w8a8_fwd_tiled - one call,
+    40 back-to-back calls on rotating weights (the tickets' parity / epoch scheme), shapes taking turns on ONE workspace (the layout does
+    not depend on the shape: a shape-dependent one turned one shape's flags into another's tickets), and replayed from a graph."""
+    from chatglm_q_amd.int8 import hip_ops as h8
+    K = 4096
+    assert X.w8a8_splitk_serves(M, N, K) > 0 and X.w8a8_splitk_serves(512, 4096, 2048) == 0 and X.w8a8_splitk_serves(500, 4096, 4096) == 0
+    g = torch.Generator(device=DEV).manual_seed(13 + M)
+    ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=DEV, generator=g) for _ in range(3)]
+    tiled = [h8.tile_w8(w) for w in ws]
+    sc = (torch.rand(N, device=DEV, generator=g) * 0.01 + 0.001).to(dtype)
+    bias = (torch.randn(N, device=DEV, generator=g) * 0.1).to(dtype)
+    a_q, a_s = h8.act_quant_rowwise(torch.randn(M, K, device=DEV, dtype=torch.float16))
+    want = [h8.w8a8_gemm_tiled(a_q, a_s, t, N, sc, bias) for t in tiled]
+    want_nobias = h8.w8a8_gemm_tiled(a_q, a_s, tiled[0], N, sc)
+    assert torch.equal(X.w8a8_gemm_tiled_splitk(a_q, a_s, tiled[0], N, sc, bias), want[0])
+    assert torch.equal(X.w8a8_gemm_tiled_splitk(a_q, a_s, tiled[0], N, sc), want_nobias)
+    outs = [X.w8a8_gemm_tiled_splitk(a_q, a_s, tiled[i % 3], N, sc, bias) for i in range(40)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want[i % 3]) for i, o in enumerate(outs))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        X.w8a8_gemm_tiled_splitk(a_q, a_s, tiled[0], N, sc, bias)
+        s.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            outs = [X.w8a8_gemm_tiled_splitk(a_q, a_s, tiled[i % 3], N, sc, bias) for i in range(8)]
+        for _ in range(3):
+            gr.replay()
+        s.synchronize()
+    assert all(torch.equal(o, want[i % 3]) for i, o in enumerate(outs))
+    with pytest.raises(ValueError):
+        X.w8a8_gemm_tiled_splitk(a_q[:100], a_s[:100], tiled[0], N, sc)
