@@ -767,6 +767,10 @@ def main():
             # the figures that can still move: a whole token's QLinear bytes against the HBM peak
             result["roofline"]["decode_tok_per_s_frac_of_ceiling"] = round(result["decode_tok_per_s"] / DECODE_CEILING_TOK_S, 4)
             result["roofline"]["decode_ceiling_tok_per_s"] = DECODE_CEILING_TOK_S
+        b16 = result["extras"].get("e2e_generate_bf16", {})
+        if isinstance(b16.get("greedy"), dict) and "decode_tok_per_s" in result:
+            result["decode_tok_per_s_bf16"] = b16["greedy"]["gen_tok_per_s"]
+            result["decode_bf16_over_f16"] = round(b16["greedy"]["gen_tok_per_s"] / result["decode_tok_per_s"], 4)
         sweep = result["extras"].get("token_sweep", {})
         if isinstance(sweep, dict) and "frac_of_8TBps" in sweep:
             result["roofline"]["token_sweep_frac"] = sweep["frac_of_8TBps"]       # 113 linear launches of one token / 8 TB/s

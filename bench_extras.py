@@ -40,13 +40,14 @@ def _graph_time(torch, device, fn, reps=3):
     return best
 
 
-def _w4_layer(torch, device, K, N, bias, gen):
+def _w4_layer(torch, device, K, N, bias, gen, dtype=None):
     from chatglm_q_amd.int4.qlinear import DynamicQuantizeLinear
-    layer = DynamicQuantizeLinear(K, N, bias=bias, dtype=torch.float16, device=device)
+    dtype = dtype or torch.float16
+    layer = DynamicQuantizeLinear(K, N, bias=bias, dtype=dtype, device=device)
     layer.weight.copy_(torch.randint(0, 256, layer.weight.shape, dtype=torch.uint8, device=device, generator=gen))
-    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=device, generator=gen) * 0.02 + 0.002).half())
+    layer.weight_scale.copy_((torch.rand(layer.weight_scale.shape, device=device, generator=gen) * 0.02 + 0.002).to(dtype))
     if bias:
-        layer.bias.copy_((torch.randn(N, device=device, generator=gen) * 0.1).half())
+        layer.bias.copy_((torch.randn(N, device=device, generator=gen) * 0.1).to(dtype))
     return layer.prepare()
 
 
@@ -159,6 +160,59 @@ def per_shape(torch, device):
                                                    "launch for launch"}
     except KeyError:
         pass
+    return out
+
+
+def per_shape_bf16(torch, device):
+    """The same five decode shapes with bf16 activations / scales (`torch_dtype: "bfloat16"` is a valid load config of the reference,
+    chatglm_q/loader.py:16-38): the module default for bf16 is the STRICT arithmetic (the reference's per-weight rounding to bf16:
+    skipping it cannot land within 1e-3), which costs an fp32 product + v_cvt_pk_bf16_f32 per weight."""
+    gen = torch.Generator(device=device).manual_seed(9)
+    out = {}
+    for name, K, N, b in [("qkv_proj", 4096, 4608, True), ("o_proj", 4096, 4096, False), ("w_in", 4096, 27392, False),
+                          ("w_out", 13696, 4096, False), ("lm_head", 4096, 65024, False)]:
+        per = K * N // 2 + (K // 32) * N * 2 + K * 2 + N * 2 + (N * 2 if b else 0)
+        n_sets = max(2, min(48, int(700e6 // per) + 1))
+        reps = max(1, 96 // n_sets)
+        row = {}
+        for label, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            layers = [_w4_layer(torch, device, K, N, b, gen, dt) for _ in range(n_sets)]
+            x = torch.randn(1, K, device=device, dtype=dt)
+
+            def fn():
+                with torch.no_grad():
+                    for _ in range(reps):
+                        for l in layers:
+                            l(x)
+
+            row[label + "_us"] = round(_graph_time(torch, device, fn) / (reps * n_sets) * 1e3, 3)
+            del layers
+            torch.cuda.empty_cache()
+        row["bf16_over_f16"] = round(row["bf16_us"] / row["f16_us"], 4)
+        out[name] = row
+    return out
+
+
+def e2e_generate_bf16(torch, device):
+    """BASELINE config 4's harness with a bf16 model (strict arithmetic: the module default for bf16): greedy and the reference's default
+    sampler, graph-replayed, 128 tokens."""
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    model, cfg = _chatglm2_6b(torch, device, torch.bfloat16)
+    for mod in model.modules():
+        if hasattr(mod, "prepare"):
+            mod.prepare()
+    prompt = [(37 * i + 11) % cfg.vocab_size for i in range(32)]
+    dec = ChatGLMDecoder(None, model)
+    out = {}
+    for kw in (dict(greedy=True), dict(seed=1)):
+        list(dec.generate_ids(prompt, max_generated_tokens=8, ignore_eos=True, use_graph=True, **kw))
+    for label, kw in (("greedy", dict(greedy=True)), ("sampled_default", dict(seed=20260930))):
+        toks = list(dec.generate_ids(prompt, max_generated_tokens=128, ignore_eos=True, use_graph=True, **kw))
+        out[label] = {"generated": len(toks), "gen_tok_per_s": round(dec.last_stats["gen_tok_per_s"], 1),
+                      "avg_tok_per_s": round(dec.last_stats["avg_tok_per_s"], 1)}
+    out["workload"] = "ChatGLM2-6B int4g32 generate(), batch 1, 32-token prompt, 128 generated tokens, bf16 (strict per-weight rounding), synthetic weights"
+    del model
+    torch.cuda.empty_cache()
     return out
 
 
@@ -766,7 +820,8 @@ def run(torch, device):
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
                      ("prefill_gemm_M8192", prefill_gemm), ("prefill_gemm_power", prefill_gemm_power), ("fp32_rows_512", fp32_many_rows), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
-                     ("prefill_attention_b4_s2048", prefill_attention), ("decode_attention", decode_attention), ("e2e_generate", e2e_generate), ("int8_model_prefill", int8_model_prefill),
+                     ("prefill_attention_b4_s2048", prefill_attention), ("decode_attention", decode_attention), ("e2e_generate", e2e_generate), ("decode_shapes_bf16", per_shape_bf16), ("e2e_generate_bf16", e2e_generate_bf16),
+                     ("int8_model_prefill", int8_model_prefill),
                      ("e2e_cpu", e2e_cpu)]:
         try:
             out[name] = fn(torch, device)
