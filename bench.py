@@ -21,13 +21,12 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON 
             chatglm_q/int4/qlinear.py:20-33,50) through DynamicQuantizeLinear on the same shape: all host cores and one
             core, median of >= 7; the C oracle's time is kept as a second figure.
 
-The timed steps are replayed from captured HIP graphs (K kernel nodes each, strictly sequential on one
-stream) so that the figure is not the Python/ctypes launch overhead; `--launch eager` times plain
-launches instead.  A K-step region lasts K x 4 us: at K < 144 ONE such bracket is dominated by event / replay noise (BENCH r01-r05:
-1 479 .. 2 046 GB/s on an unchanged kernel at the driver's --steps 20), so R = ceil(1440 / K) graphs of K launches - graph r walks the
-weight rotation from set r K on, so consecutive replays stream from HBM like the roofline leg - are replayed inside the ONE barrier +
-synchronize bracket, each between its own HIP events, and `ms_per_step` = (first event -> last event) / (R K): every one of the R K launches is inside
-the bracket and the clock (`replays`, `steps_timed`, the median single block and the bracket's own wall clock are reported beside it).
+The timed steps are replayed from ONE captured HIP graph (strictly sequential kernel nodes on one stream) so that the figure is not the
+Python/ctypes launch overhead; `--launch eager` times plain launches instead.  A K-step region lasts K x 4 us: at K < 144 one such
+bracket is dominated by the graph's own launch / start-up (~12 us per replay) and by event noise (BENCH r01-r05: 1 479 .. 2 046 GB/s on an
+unchanged kernel at the driver's --steps 20), so the ONE barrier + synchronize bracket then holds R = ceil(1440 / K) times the K steps - one
+graph of R K launches walking the weight rotation - and `ms_per_step` = bracket / (R K) (`replays`, `steps_timed` and the bracket's own
+wall clock are reported beside it).
 
 Multi-GPU: the path does not shard (DESIGN.md "replicas only"): N independent replicas, one process per GPU, no data-path
 collective (the only exchange is the barrier and the max-over-ranks of the timings); scaling is "weak".  Two ways in:
@@ -610,55 +609,47 @@ def main():
 
     stream = torch.cuda.Stream(device=device)
     launch_mode = args.launch
-    # R graphs of `steps` launches; graph r starts at weight set r * steps of the rotation (docstring)
+    # K < 144: the timed region holds R = ceil(1440 / K) times the K steps, captured as ONE graph of R K launches walking the rotation
+    # (docstring): a K-node graph pays ~12 us of graph launch / start-up per replay (measured: 20-step graphs replayed back to back
+    # 4.83 us per step, each between its own events 4.56, one 1440-node graph 4.09 - the kernel did not change), which is neither a
+    # step's cost nor stable from box to box
     replays = max(1, -(-ROOF_LAUNCHES // args.steps)) if args.steps < ROOF_GRAPH else 1
-    graphs = []
+    n_timed = args.steps * replays
+    graph = None
     with torch.cuda.stream(stream):
         if launch_mode == "graph":
             try:
-                for r in range(replays):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=stream):
-                        run_steps(args.steps, offset=r * args.steps)
-                    graphs.append(g)
-                for g in graphs:                    # one untimed pass
-                    g.replay()
-                # ... after which the last replays' weight sets sit in the 256 MB memory-side cache: the sets the FIRST timed replay
-                # does not touch run once more, untimed, so that the timed region streams its weights from HBM whatever --steps the
-                # caller picks
-                flush_sets = max(0, len(layers) - args.steps)
-                run_steps(flush_sets, offset=args.steps)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    run_steps(n_timed)
+                graph.replay()                      # one untimed replay
+                # ... whose last weight sets would otherwise sit in the 256 MB memory-side cache for the timed replay: the sets the FIRST
+                # launches of the timed region do not touch run once more, untimed
+                flush_sets = max(0, len(layers) - min(n_timed, len(layers) // 2))
+                run_steps(flush_sets, offset=min(n_timed, len(layers) // 2))
                 stream.synchronize()
             except Exception as e:                  # pragma: no cover - capture unsupported
                 print(f"[bench] graph capture failed ({e}); falling back to eager", file=sys.stderr)
-                graphs = []
+                graph = None
                 launch_mode = "eager"
-                replays = 1
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(replays)]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         launches_before = _lib.launch_count()
         barrier()
         t0 = time.perf_counter()
-        for r in range(replays):
-            events[r][0].record(stream)
-            if graphs:
-                graphs[r].replay()
-            else:
-                run_steps(args.steps)
-            events[r][1].record(stream)
+        ev0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            run_steps(n_timed)
+        ev1.record(stream)
         stream.synchronize()
         barrier()
         t1 = time.perf_counter()
     wall_s = t1 - t0
-    blocks_ms = sorted(a.elapsed_time(b) for a, b in events)
-    # the clock: first event -> last event over all R x K launches of the bracket, per K steps (R == 1: the one block).  The median
-    # single block is kept beside it: a K-node graph pays its own launch latency once per replay (~0.3 us per step at K = 20), which
-    # the back-to-back stream overlaps with the previous replay's tail
-    span_ms = events[0][0].elapsed_time(events[-1][1])
-    ev_ms = span_ms / replays
-    block_med = _pct(blocks_ms, 0.5)
-    wall_s, ev_ms, block_med, ev_min, ev_max = max_over_ranks([wall_s, ev_ms, block_med, blocks_ms[0], blocks_ms[-1]], dist, device)
-    if not graphs:
-        assert _lib.launch_count() - launches_before >= args.steps, "steps did not go through the HIP library"
+    ev_ms = ev0.elapsed_time(ev1) / replays          # per K steps
+    wall_s, ev_ms = max_over_ranks([wall_s, ev_ms], dist, device)
+    if graph is None:
+        assert _lib.launch_count() - launches_before >= n_timed, "steps did not go through the HIP library"
 
     # the timed region's own HIP events (recorded inside the barrier + synchronize bracket, max over ranks) are the clock: the
     # host's perf_counter around the same bracket adds the two synchronize() round trips to a region that lasts ~6 ms at the
@@ -690,10 +681,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6),
         "ms_per_step_wall_clock": round(ms_per_step_wall, 6),
-        "replays": replays,                                   # K-step blocks inside the one barrier + synchronize bracket
-        "steps_timed": args.steps * replays,
-        "ms_per_step_median_block": round(block_med / args.steps, 6),   # one K-step replay between its own events, median of R
-        "ms_per_step_block_min_max": [round(ev_min / args.steps, 6), round(ev_max / args.steps, 6)],
+        "replays": replays,                                   # the one barrier + synchronize bracket holds replays x steps launches
+        "steps_timed": n_timed,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -777,7 +766,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline()
     cards = gather_cards(dict(device_card(torch, device), rank=rank, roofline_median_us=round(roof["median_us"], 4),
-                              us_per_launch_timed_region=round(span_ms / replays * 1e3 / args.steps, 4)), dist, world)
+                              us_per_launch_timed_region=round(ev_ms * 1e3 / args.steps, 4)), dist, world)
     result["ranks"] = cards
     if rank == 0:
         print(json.dumps(result))

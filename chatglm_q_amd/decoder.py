@@ -387,7 +387,10 @@ def _existing(p):
 
 class ChatGLMDecoder:
     def __init__(self, config, model: ChatGLM2Model, tokenizer=None, eos_token_id: Optional[int] = None, device=None,
-                 max_sequence_length: Optional[int] = None, time_log: bool = False):
+                 max_sequence_length: Optional[int] = None, time_log: bool = False, low_footprint: bool = False):
+        # low_footprint: the decoder's sessions drop the canonical GPU buffers of every int4 module once the derived layouts a phase
+        # reads exist (DecodeSession(low_footprint=True): state_dict() / save_pretrained rebuild them byte for byte)
+        self.low_footprint = low_footprint
         self.config = config
         self.model = model
         self.tokenizer = tokenizer
@@ -398,13 +401,18 @@ class ChatGLMDecoder:
         self.last_stats: dict = {}
 
     @staticmethod
-    def from_pretrained(path, device=None, torch_dtype=None, tokenizer=None, eos_token: str = "</s>", time_log: bool = False):
+    def from_pretrained(path, device=None, torch_dtype=None, tokenizer=None, eos_token: str = "</s>", time_log: bool = False,
+                        low_footprint: Optional[bool] = None):
         """A reference-format checkpoint folder (``config.json`` + safetensors shards, chatglm_q/loader.py:69-110) -> a decoder
         whose ``generate`` / ``generate_ids`` run this build's fused path by default: preallocated cache, 5 launches per layer,
         one HIP graph per token on a GPU (chatglm_q/decoder.py:49-58 is the reference's constructor of the same name; the hub
         download it falls back to needs a network and is not offered).  ``device`` defaults to the GPU when there is one.
         ``tokenizer``: any object with ``encode`` / ``decode``; when omitted and the folder's sentencepiece file can be read, a
-        plain SentencePiece wrapper is used (the reference's chat markers and punctuation fix-ups are text handling, out of scope)."""
+        plain SentencePiece wrapper is used (the reference's chat markers and punctuation fix-ups are text handling, out of scope).
+        ``low_footprint`` (None = yes on a GPU): a decoder loaded for generation keeps ONE copy of every int4 weight per consumer -
+        the canonical buffers are dropped once the derived layouts exist and rebuilt byte for byte when ``save_pretrained`` /
+        ``state_dict()`` ask for them: ChatGLM2-6B int4g32 resident 7.1 GB (prefill + decode layouts) instead of 11.85 GB; the reference's
+        guidance is "6G+" (readme.md:72); ``DecodeSession(decode_only=True, low_footprint=True)`` goes to 3.4 GB for decode-only serving."""
         from pathlib import Path
         from .loader import load_model
         path = Path(path)
@@ -436,8 +444,10 @@ class ChatGLMDecoder:
                 eos_id = tokenizer[eos_token]               # the reference tokenizer's lookup (chatglm_q/decoder.py:44)
             except (KeyError, TypeError):
                 eos_id = None
+        if low_footprint is None:
+            low_footprint = torch.device(device).type == "cuda"
         dec = ChatGLMDecoder(config, model, tokenizer, eos_token_id=eos_id, device=device,
-                             max_sequence_length=config.model_config.max_sequence_length, time_log=time_log)
+                             max_sequence_length=config.model_config.max_sequence_length, time_log=time_log, low_footprint=low_footprint)
         dec.tokenizer_file = tokenizer_path if tokenizer_path is not None else (tok_file_of(tokenizer) or _existing(path / config.tokenizer_file))
         return dec
 
@@ -465,8 +475,8 @@ class ChatGLMDecoder:
         if sess is not None and self._session_key == key and sess.capacity >= capacity and not sess.busy:
             return sess.reset()
         if sess is not None and sess.busy:                      # an unfinished generator still owns it: leave it alone
-            return DecodeSession(self.model, 1, capacity, use_graph)
-        self._session, self._session_key = DecodeSession(self.model, 1, capacity, use_graph), key
+            return DecodeSession(self.model, 1, capacity, use_graph, low_footprint=self.low_footprint)
+        self._session, self._session_key = DecodeSession(self.model, 1, capacity, use_graph, low_footprint=self.low_footprint), key
         return self._session
 
     @torch.no_grad()

@@ -124,3 +124,32 @@ def test_low_footprint_mode_drops_the_canonical_copy_and_round_trips_byte_for_by
     q.drop_canonical()
     assert torch.equal(q(x), y) and torch.equal(q.state_dict()["weight"], sd["weight"])
     assert q.to("cpu").weight.shape == sd["weight"].shape and not q.canonical_dropped and torch.equal(q.weight, sd["weight"].cpu())
+
+
+def test_from_pretrained_on_a_gpu_is_low_footprint_and_round_trips(tmp_path):
+    """Round 6 hygiene: ``ChatGLMDecoder.from_pretrained`` on a GPU defaults to the low-footprint mode - after a
+    generation no int4 module holds its canonical buffers any more - and ``save_pretrained`` still writes the checkpoint byte for byte;
+    ``low_footprint=False`` keeps the canonical copies; both decoders generate the same tokens (greedy and seeded sampling)."""
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    seed = int(R["seed"][0])
+    folder = _folder(tmp_path, seed, "lf")
+    dec = ChatGLMDecoder.from_pretrained(folder, device=DEV)
+    assert dec.low_footprint is True
+    full = ChatGLMDecoder.from_pretrained(folder, device=DEV, low_footprint=False)
+    prompt = [3, 17, 200, 5, 77, 400, 9]
+    kw = dict(max_generated_tokens=6, ignore_eos=True)
+    a = list(dec.generate_ids(prompt, greedy=True, **kw))
+    b = list(full.generate_ids(prompt, greedy=True, **kw))
+    assert a == b
+    assert list(dec.generate_ids(prompt, seed=5, **kw)) == list(full.generate_ids(prompt, seed=5, **kw))
+    int4 = [m for m in dec.model.modules() if hasattr(m, "canonical_dropped")]
+    assert int4 and all(m.canonical_dropped for m in int4)
+    assert not any(m.canonical_dropped for m in full.model.modules() if hasattr(m, "canonical_dropped"))
+    held = lambda d: sum(sum(m.derived_nbytes().values()) + (0 if m.canonical_dropped else m.weight.numel() + 2 * m.weight_scale.numel())  # noqa: E731
+                         for m in d.model.modules() if hasattr(m, "canonical_dropped"))
+    assert held(dec) < 0.8 * held(full)
+    dec.save_pretrained(tmp_path / "again")
+    lc2, back = L.load_model(tmp_path / "again", device="cpu")
+    want = L.load_model(folder, device="cpu")[1].state_dict()
+    for k, v in back.state_dict().items():
+        assert torch.equal(v, want[k]), k
