@@ -465,7 +465,7 @@ def spawn_replicas(args, argv):
     if not args.dry_run:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if n > have:
+        if n > have and os.environ.get("QLINEAR_BENCH_SHARE_GPU") != "1":
             print(f"[bench] --gpus {n}: only {have} device(s) visible", file=sys.stderr)
             return 2
     with socket.socket() as sk:
@@ -571,6 +571,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback for device work")
+    if os.environ.get("QLINEAR_BENCH_SHARE_GPU") == "1":      # testing aid (a 1-GPU box, --backend gloo): every replica on device 0
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
