@@ -712,10 +712,10 @@ def main():
             "frac_rocprof": (round(bytes_per_step / (prof["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS, 4) if prof else None),
             "rocprof_kernel_avg_ns": prof["avg_ns"] if prof else None,
             "rocprof_source": prof_src,
-            "rocprof_note": "constant read from the committed profile summary, not a measurement of this run.  rocprofv3 adds ~0.9 us to every "
-                            "launch: in its own trace of the graph-replayed leg the dispatches run back to back (start-to-start 5.08 us, duration "
-                            "5.04 us, gap 0) and this bench's event clock under the profiler reads 5.5 us, against 4.1 - 4.2 us launch to launch "
-                            "without it (profiles/r06_summary.json: headline_three_clocks)",
+            "rocprof_note": "constant read from the committed profile summary, not a measurement of this run.  rocprofv3 adds ~0.8 - 0.9 us to "
+                            "every launch: in its own trace of the graph-replayed leg the dispatches run back to back (start-to-start 4.9 - 5.1 us, "
+                            "duration within 0.04 us of it, gap 0) and this bench's event clock under the profiler reads 5.2 - 5.5 us, against 4.1 - "
+                            "4.2 us launch to launch without it (profiles/r06_summary.json: headline_three_clocks)",
             # the floor of ONE dependent launch of this size, measured in this run (floor_leg): empty launch, pure streaming read of the
             # same bytes, device copy rate
             "floor": floor,
