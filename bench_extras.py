@@ -216,6 +216,33 @@ def e2e_generate_bf16(torch, device):
     return out
 
 
+def e2e_generate_int8(torch, device):
+    """The reference's other model family (`quant_type: "int8"`, chatglm_q/loader.py:16-38) through the same harness: per-channel int8
+    weights, weight-only, fp16 activations - twice the int4g32 model's bytes per token."""
+    from chatglm_q_amd import model as M
+    from chatglm_q_amd.decoder import ChatGLMDecoder
+    cfg = M.ChatGLM2Config()
+    with torch.device(device):
+        model = M.create_quant_int8_model(cfg, dtype=torch.float16)
+    M.fill_synthetic_(model, 0)
+    model.eval()
+    prompt = [(37 * i + 11) % cfg.vocab_size for i in range(32)]
+    dec = ChatGLMDecoder(None, model)
+    out = {}
+    for kw in (dict(greedy=True), dict(seed=1)):
+        list(dec.generate_ids(prompt, max_generated_tokens=8, ignore_eos=True, use_graph=True, **kw))
+    for label, kw in (("greedy", dict(greedy=True)), ("sampled_default", dict(seed=20260930))):
+        toks = list(dec.generate_ids(prompt, max_generated_tokens=128, ignore_eos=True, use_graph=True, **kw))
+        out[label] = {"generated": len(toks), "gen_tok_per_s": round(dec.last_stats["gen_tok_per_s"], 1),
+                      "avg_tok_per_s": round(dec.last_stats["avg_tok_per_s"], 1)}
+    bytes_per_token = 2 * LINEAR_BYTES_PER_TOKEN * 0.94      # int8 codes: 2 x the nibbles; scales per channel instead of per group
+    out["greedy"]["linear_frac_of_8TBps"] = round(out["greedy"]["gen_tok_per_s"] * bytes_per_token / 8e12, 4)
+    out["workload"] = "ChatGLM2-6B int8 per-channel generate(), batch 1, 32-token prompt, 128 generated tokens, fp16, synthetic weights"
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def w8_decode(torch, device):
     from chatglm_q_amd.int8.qlinear import DynamicQuantizeLinear
     gen = torch.Generator(device=device).manual_seed(11)
@@ -820,7 +847,7 @@ def run(torch, device):
     for name, fn in [("token_sweep", token_sweep), ("decode_shapes", per_shape), ("w8_decode", w8_decode),
                      ("w8a8_config3", w8a8_config3),
                      ("prefill_gemm_M8192", prefill_gemm), ("prefill_gemm_power", prefill_gemm_power), ("fp32_rows_512", fp32_many_rows), ("int8_prefill_gemm_M8192", int8_prefill_gemm),
-                     ("prefill_attention_b4_s2048", prefill_attention), ("decode_attention", decode_attention), ("e2e_generate", e2e_generate), ("decode_shapes_bf16", per_shape_bf16), ("e2e_generate_bf16", e2e_generate_bf16),
+                     ("prefill_attention_b4_s2048", prefill_attention), ("decode_attention", decode_attention), ("e2e_generate", e2e_generate), ("decode_shapes_bf16", per_shape_bf16), ("e2e_generate_bf16", e2e_generate_bf16), ("e2e_generate_int8", e2e_generate_int8),
                      ("int8_model_prefill", int8_model_prefill),
                      ("e2e_cpu", e2e_cpu)]:
         try:
