@@ -339,6 +339,18 @@ __global__ __launch_bounds__(SB) void top_p_sample_kernel(const T* __restrict__ 
         contig = true;
         u32 hi = kmax;                                       // invariant: count(key >= lo) >= k > count(key > hi)
         int c_lo = cnt;                                      // (a full segment with a small total: no bisection, the list is collected again, contiguous)
+        // A masked row (constrained decoding: most logits at -inf) lands here with lo = key(-inf) every token: ask first whether fewer than k
+        // logits are finite - then the k-th value IS -inf and the 31 bisection steps between -inf and the maximum (4 us each) are one
+        if (c_lo > S_CAP && lo == okey(-INFINITY) && lo < hi) {
+            int n = 0;
+            walk([&](int c, const float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) n += (v[e] > -INFINITY && c * 8 + e < N) ? 1 : 0;
+            });
+            n = block_sum_i(n, sh.wcnt);
+            if (n < k) hi = lo;                              // ties at -inf decide: the compaction below
+            else { lo = lo + 1; c_lo = n; }                  // every finite value is >= key(-inf) + 1
+        }
         while (lo < hi && c_lo > S_CAP) {
             const u32 mid = lo + ((hi - lo - 1) >> 1) + 1;   // lo < mid <= hi
             int n = 0;

@@ -14,6 +14,7 @@ CASES = {
     "tiny_n_lt_k":     (9007, 37, "normal3", "f16", 100, 0.8, 1.0),        # fewer logits than top_k
     "ties_coarse":     (9008, 65024, "coarse", "f16", 100, 0.8, 1.0),      # logits on a 0.5 grid: ties across the k-th place
     "masked_inf":      (9009, 65024, "masked", "f16", 100, 0.8, 1.0),      # all but 40 logits at -inf (constrained decoding)
+    "masked_500":      (9015, 65024, "masked500", "f16", 100, 0.8, 1.0),   # 500 logits allowed: more than top_k finite values among the -inf
     "sorted_ascending": (9010, 65024, "ascending", "f32", 100, 0.8, 1.0),  # defeats the first threshold: the bisection path
     "all_equal":       (9011, 4096, "equal", "f16", 100, 0.8, 1.0),        # one tie group
     "top_k_1":         (9012, 65024, "normal3", "f16", 1, 0.8, 1.0),
@@ -39,6 +40,10 @@ def logits_for(name: str) -> np.ndarray:
         x = np.full(N, -np.inf)
         keep = rs.choice(N, 40, replace=False)
         x[keep] = rs.standard_normal(40) * 2.0
+    elif recipe == "masked500":
+        x = np.full(N, -np.inf)
+        keep = rs.choice(N, 500, replace=False)
+        x[keep] = rs.standard_normal(500) * 2.0
     elif recipe == "ascending":
         x = np.sort(rs.standard_normal(N) * 3.0)
     elif recipe == "equal":
