@@ -805,11 +805,14 @@ static int dev_variant() { return QL_TUNE("QL_VARIANT", 0); }
 // blocks per CU (> 40 KB: w_out with 2 rows, 55 KB) more, smaller blocks only multiply the staging traffic (1024
 // blocks x 55 KB = 56 MB against 28 MB of weights: 20.4 us instead of 13.9), so the split is halved until the staged
 // bytes no longer exceed the weight bytes.  Small tiles keep the finer split (qkv_proj, 4 rows: 11.5 vs 14.1 us).
+#ifndef QL_KS_BLOCK_BOUND
+#define QL_KS_BLOCK_BOUND 1024
+#endif
 static int choose_ksplit(int64_t quads, int64_t G, int mb = 1) {
     const int forced = QL_TUNE("QLINEAR_W4_KSPLIT", 0);
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     int ks = 1;
-    while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < 1024) ks *= 2;
+    while (ks < 4 && G / (ks * 2) >= 64 && quads * ks / 4 < QL_KS_BLOCK_BOUND) ks *= 2;
     if (mb > 1 && mb * G * 64 > 40 * 1024)
         while (ks > 1 && (quads * ks / 4) * mb * (G * 32) * 2 > quads * 4 * G * 16) ks /= 2;
     return ks;
