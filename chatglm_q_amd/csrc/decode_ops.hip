@@ -497,9 +497,13 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // q = 8 (p / 8) + (att_blocks + p) % 8 (np' = np rounded down to a multiple of 8), i.e. only ones of its own XCD, and
 // reads their bytes once with plain (cacheable) 16-byte loads.  Measured on attention + o_proj (int4g32 4096 x 4096,
 // capacity 256; tools/attention_prefetch.py): 10.8 us without; everything prefetched from the start 10.9 (the
-// attention's own loads queue behind 9.4 MB); started ~1.7 us late and capped at ~7 MB 10.3.
+// attention's own loads queue behind 9.4 MB); started ~1.7 us late and capped at ~7 MB 10.3 - against ROUND 2's attention kernel.
+// Round 6 re-measured the cap on the whole decode step (tools/decode_ab.py, profiles/r06_prefetch_budget_ab.txt) against round 5's faster
+// attention launch: the 7 MB no longer fit its shadow - the launch ended when the PREFETCHERS did - and cost the step 3 % (871 - 875 tok/s
+// against 888 - 891 with no prefetch at all); 1 / 2 / 3 / 4 MB: 892 / 895 / 902 / 904, 5 MB and more 875: a cliff between 4 and 5 MB.  3 MB: a
+// quarter of the gain's width away from the cliff.
 #ifndef QL_PF_BUDGET_KB
-#define QL_PF_BUDGET_KB (7 << 10)
+#define QL_PF_BUDGET_KB (3 << 10)
 #endif
 #ifndef QL_PF_SLEEP
 #define QL_PF_SLEEP 8
