@@ -675,7 +675,7 @@ def e2e_generate(torch, device):
         "chunk": CH, "seconds": round(dt, 4), "tokens_per_s": round(B * S / dt, 1),
         "linear_TFLOPs_if_all_time_were_linear": round(lin_flops / dt / 1e12, 1),
         "note": "whole forward incl. attention (qlinear_prefill_attention: one launch per layer on the matrix cores, scores never "
-                "written; QLINEAR_PREFILL_ATTENTION=0 = the reference op sequence as two batched GEMMs + one mask / softmax launch, "
+                "written; chatglm_q_amd.model.PREFILL_ATTENTION = False = the reference op sequence as two batched GEMMs + one mask / softmax launch, "
                 "0.122 s) and norms; lm_head for the last position only"}
     # batched greedy decode (graph-replayed step, 32-token prompts): aggregate tokens per second
     bd = {}
