@@ -500,13 +500,17 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // attention's own loads queue behind 9.4 MB); started ~1.7 us late and capped at ~7 MB 10.3 - against ROUND 2's attention kernel.
 // Round 6 re-measured the cap on the whole decode step (tools/decode_ab.py, profiles/r06_prefetch_budget_ab.txt) against round 5's faster
 // attention launch: the 7 MB no longer fit its shadow - the launch ended when the PREFETCHERS did - and cost the step 3 % (871 - 875 tok/s
-// against 888 - 891 with no prefetch at all); 1 / 2 / 3 / 4 MB: 892 / 895 / 902 / 904, 5 MB and more 875: a cliff between 4 and 5 MB.  3 MB: a
-// quarter of the gain's width away from the cliff.
+// against 888 - 891 with no prefetch at all); 1 / 2 / 3 / 4 MB: 892 / 895 / 902 / 904, 5 MB and more 875: a cliff between 4 and 5 MB.  The
+// cliff is the START DELAY's: with the prefetchers starting at once (the delay protected round 2's attention loads; round 5's kernel does not
+// care) 5 / 6 / 7 / 9.4 MB run 898 / 901 / 904 / 899 - no cliff on either side.  7 MB from the start.
 #ifndef QL_PF_BUDGET_KB
-#define QL_PF_BUDGET_KB (3 << 10)
+#define QL_PF_BUDGET_KB (7 << 10)
 #endif
 #ifndef QL_PF_SLEEP
-#define QL_PF_SLEEP 8
+#define QL_PF_SLEEP 0
+#endif
+#ifndef QL_PF_BLOCKS
+#define QL_PF_BLOCKS 256        // prefetch workgroups at most (about one per CU)
 #endif
 constexpr int64_t kPrefetchBudget = (int64_t)QL_PF_BUDGET_KB << 10;   // bytes that fit in the attention's shadow
 __device__ __forceinline__ void prefetch_blocks(const Prefetch& pf, int p, int np, int att_blocks) {
@@ -1624,7 +1628,7 @@ static int launch_attention(const void* Q, void* Kc, void* Vc, const float* mask
             // prefetch workgroups: about one per CU (they only issue loads); none without a descriptor, none when the
             // attention itself fills the chip (windows of a long context, large batches: measured slower)
             const int att_blocks = (int)(B * G);
-            const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < 256 ? ((pf.blocks + 7) & ~7) : 256) : 0;
+            const int npf = pf.blocks > 0 && one_window && att_blocks <= 16 ? (pf.blocks < QL_PF_BLOCKS ? ((pf.blocks + 7) & ~7) : QL_PF_BLOCKS) : 0;
             dim3 gridg((unsigned)(att_blocks + npf), (unsigned)(one_window ? 1 : nwin));
 #ifdef QL_DEV_TUNING
             if (QL_TUNE("QLINEAR_ATTENTION_R2", 0)) {         // round 2's kernel (8 waves x 32 positions: 6.3 us against 6.6 for 4 x 64)
