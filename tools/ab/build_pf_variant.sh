@@ -6,4 +6,4 @@ cd "$(dirname "$0")/../.."
 CS=chatglm_q_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-fast-math -mllvm -amdgpu-kernarg-preload-count=16"
 /opt/rocm/bin/hipcc $FLAGS $2 -c $CS/prefill_attention.hip -o /tmp/prefill_attention_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/libql_pf_$1.so $(ls $CS/*.o | grep -v "prefill_attention.o\|_span.o\|_trace.o\|_nomath.o") /tmp/prefill_attention_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/microbench/libql_pf_$1.so $(ls $CS/*.o | grep -v -e "/prefill_attention.o" -e "_span.o" -e "_trace.o" -e "_nomath.o" -e "/dev_" -e "probe_kernels.o") /tmp/prefill_attention_$1.o
