@@ -178,3 +178,10 @@ def test_strided_rows_and_argument_errors():
         fused_ops.top_p_sample(view, tok[:2], None, 10, 0.8, 1.0)
     with pytest.raises(ValueError):
         fused_ops.top_p_sample(wide[:, ::2], tok, None, 10, 0.8, 1.0)
+    # top_k beyond the kernel's 1024 on a larger vocabulary: refused loudly (generate_ids then keeps the composed torch sampler);
+    # on a vocabulary of at most 1024 entries any top_k is the whole row
+    big = torch.zeros((1, 4096), dtype=torch.float16, device=_dev())
+    with pytest.raises(ValueError):
+        fused_ops.top_p_sample(big, tok[:1], None, 2000, 0.8, 1.0)
+    p_all, i_all, _ = fused_ops.top_p_sample(view[:1], tok[:1], None, 5000, 1.0, 1.0, return_distribution=True)
+    assert p_all.shape[1] == 1000 and abs(float(p_all.sum()) - 1.0) < 1e-5
