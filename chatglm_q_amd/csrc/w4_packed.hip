@@ -635,8 +635,12 @@ __device__ __forceinline__ void w4_packed_gemv_16_body(const T* __restrict__ A, 
     }
 }
 
+// QL_GEMV_MIN_WAVES (A/B builds): minimum waves per SIMD the one-row (MB == 1) instantiations are compiled for, i.e. a register cap of 512 / n
+#ifndef QL_GEMV_MIN_WAVES
+#define QL_GEMV_MIN_WAVES 1
+#endif
 template <typename T, int MB, int ACH, int KS, bool STRICT, int VAR = 0, int PRO = PRO_NONE>
-__global__ __launch_bounds__(256) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
+__global__ __launch_bounds__(256, (MB == 1 ? QL_GEMV_MIN_WAVES : 1)) void w4_packed_gemv_16_kernel(const T* __restrict__ A, const u32x4* __restrict__ Wt,
                                                                 const T* __restrict__ Sp, const void* pro_delta,
                                                                 const void* pro_ln_weight, int N, int K, int M, int lda32,
                                                                 const T* __restrict__ bias, T* __restrict__ C, int64_t ldc,
